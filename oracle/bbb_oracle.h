@@ -1,0 +1,115 @@
+/*
+ * bbb_oracle.h -- CPU restatement (plain C) of the basebandboard AWGN / PRBS hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is the parity oracle: only tests/, the smoke
+ * check in __graft_entry__.py and the `cpu_baseline` leg of bench.py may load it.
+ * The product (basebandboard_amd/, libbbb_hip.so) never links, imports or calls it.
+ *
+ * Parity status: PINNED for LUTOPT / CLT tree / PRBS by tests/golden/{lutopt_clt,prbs,gf2}.json,
+ * which tools/make_golden.py derives from the models embedded in the reference's own
+ * tests (rng.py:134-135, rng.py:173-181, prbs.py:112-113) and from literal known-answer
+ * strings in the reference's Rust tests.  The PRBSErrorDetector FSM has no literal
+ * trace anywhere in the reference (its only test uses unseeded random errors and
+ * needs migen): it is pinned by re-running the reference's test *protocol*
+ * (prbs.py:124-163) as a property.  BER counters / Eb-N0 mapping do not exist in the
+ * reference: build-defined, "parity unpinned" (sanity: Q-function).
+ *
+ * All file:line citations are relative to the reference checkout root.
+ */
+#ifndef BBB_ORACLE_H
+#define BBB_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BBO_MAX_K 512
+#define BBO_WORDS (BBO_MAX_K / 64)
+
+/* A LUTOPT recurrence: row r of A lists the old-state bit indices XORed into new bit r
+ * (gateware/bbb/rng.py:38-40; packed form rng.py:42-55). */
+typedef struct {
+    int k;
+    int ntaps[BBO_MAX_K];
+    uint16_t taps[BBO_MAX_K][8];
+} bbo_lutopt;
+
+/* Parse the 0/1 text matrix format of software/rnghunt/matrices/N (line r, char c = A[r][c];
+ * written by rnghunt.rs:51-53, read by util/pack.py:6-18).  Returns 0, or -1 on error. */
+int bbo_lutopt_load(bbo_lutopt *m, const char *path);
+/* Build from packed tap lists (rng.py:42-55): taps_flat holds row 0's taps, then row 1's ...;
+ * row_off[r]..row_off[r+1] delimit row r. */
+int bbo_lutopt_from_packed(bbo_lutopt *m, int k, const uint16_t *taps_flat, const uint32_t *row_off);
+
+/* One synchronous step x' = A x over GF(2) (rng.py:38-40).  State bit i lives at
+ * x[i/64] >> (i%64) & 1, i.e. bit i of the HDL integer (rng.py:135). */
+void bbo_lutopt_step(const bbo_lutopt *m, const uint64_t *x, uint64_t *xnew);
+
+/* CLTGRNG adder tree, literally: log2(n) levels of y[j] = x[2j] - x[2j+1]
+ * (rng.py:96-105; clt-grng-evaluate.py:10-15).  Returns the UN-truncated tree value. */
+int bbo_clt_tree(const uint64_t *x, int n);
+/* Same value by the closed form sum_i (-1)^popcount(i) x[i]. */
+int bbo_clt_popcount(const uint64_t *x, int n);
+/* Truncate to log2(n) bits, signed (CLTGRNG.x is Signal((logn, True)), rng.py:78,108). */
+int bbo_clt_wrap(int tree_value, int n);
+
+/* Sequential AWGN stream: out[i] = wrap(tree(A^(first_step+i+1) init)), i < nsamples.
+ * For k = 256 the output is int8 (tx.py:68-71).  `init` is ceil(k/64) words. */
+void bbo_awgn_stream_i8(const bbo_lutopt *m, const uint64_t *init, uint64_t first_step,
+                        uint64_t nsamples, int8_t *out);
+/* Faster k=256-only evaluation of the same stream (byte-indexed column tables +
+ * popcount closed form); used as the timed CPU baseline.  Must equal bbo_awgn_stream_i8. */
+void bbo_awgn_stream_i8_fast256(const bbo_lutopt *m, const uint64_t *init, uint64_t first_step,
+                                uint64_t nsamples, int8_t *out);
+/* Final state after `nsteps` steps from init. */
+void bbo_lutopt_run(const bbo_lutopt *m, const uint64_t *init, uint64_t nsteps, uint64_t *xout);
+
+/* PRBS-k Fibonacci LFSR (gateware/bbb/prbs.py:14,32-35; model prbs.py:112-113).
+ * Returns the tap for k or 0 when k is not one of 7,9,11,15,20,23,31 (prbs.py:29-30). */
+int bbo_prbs_tap(int k);
+/* Emit nbits bits (one per byte, 0/1) starting from LFSR state *state; updates *state. */
+int bbo_prbs_bits(int k, uint64_t *state, uint64_t nbits, uint8_t *bits);
+/* Same stream packed LSB-first into 64-bit words: bit t -> word t/64, bit t%64. */
+int bbo_prbs_packed(int k, uint64_t *state, uint64_t nbits, uint64_t *words);
+/* Word-parallel variant used for the timed CPU baseline (same output as bbo_prbs_packed). */
+int bbo_prbs_packed_fast(int k, uint64_t *state, uint64_t nbits, uint64_t *words);
+/* Count mismatches between `words` (packed as above) and the PRBS from *state. */
+int bbo_prbs_check_packed(int k, uint64_t *state, uint64_t nbits, const uint64_t *words, uint64_t *nerr);
+
+/* PRBSErrorDetector, cycle exact (prbs.py:61-99).  For clock i the input wire holds
+ * bits[i]; err[i], reload[i] are the values of `err` and `reload` sampled after that
+ * clock edge -- exactly what the reference's testbench reads (prbs.py:146-150). */
+int bbo_prbs_detector_run(int k, const uint8_t *bits, uint64_t n, uint8_t *err, uint8_t *reload);
+
+/* TX noise path + RX slicer (tx.py:75-81, rx.py:29), one sample per bit:
+ *   noise = wrap12(g * noise_var), x = wrap12(level(bit) + noise), decision = (x >= 0)
+ * level(bit) = bit ? +amp : -amp.  Returns decision (0/1). */
+int bbo_txrx_decide(int g_i8, int bit, int amp, int noise_var);
+
+typedef struct {
+    int prbs_k;            /* PRBS order */
+    uint64_t prbs_state;   /* initial LFSR state (reference reset value: 1) */
+    int amp;               /* BPSK level, +-amp added to the noise (12-bit signed domain) */
+    int noise_var;         /* 4-bit unsigned multiplier of the CLT sample (tx.py:52,76) */
+    uint64_t warmup;       /* LUTOPT steps discarded before the first sample (rng.py:161-162 uses 2*logn) */
+    uint64_t first_bit;    /* offset into both streams (for sharded trials) */
+    uint64_t nbits;        /* bits in this trial */
+} bbo_trial;
+/* BUILD-DEFINED (not in the reference): count decision errors of BPSK over PRBS-k
+ * through the CLT AWGN stream.  bit t uses PRBS bit (first_bit+t) and the CLT sample of
+ * state A^(warmup+first_bit+t+1) init. */
+int bbo_ber_trial(const bbo_lutopt *m, const uint64_t *init, const bbo_trial *t,
+                  uint64_t *bits_out, uint64_t *errors_out);
+
+/* rnghunt BinaryMatrix::recur restated (binary_matrix.rs:53-76): column-major u64 words,
+ * MSbit = row 0; x given as one bit per byte; emits bit 0 of each successive A x. */
+int bbo_rnghunt_recur(int nrows, int ncols, const uint64_t *col_words, const uint8_t *x_bits,
+                      int n, uint8_t *out_bits);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

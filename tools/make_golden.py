@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""Generate the golden known-answer fixtures under tests/golden/.
+
+The reference's HDL modules cannot be imported here (they need `migen`, which is
+not installed), so the vectors are produced by re-evaluating, with plain
+Python/numpy, the *software models embedded in the reference's own tests* -- the
+exact expressions the reference uses as ITS oracle for the HDL:
+
+  LUTOPT      gateware/bbb/rng.py:134-135   x = mod(dot(a, x), 2); int from x[::-1]
+  CLT tree    gateware/bbb/rng.py:173-181   (same tree as software/clt-grng/clt-grng-evaluate.py:10-15)
+  PRBS        gateware/bbb/prbs.py:112-113  two-line integer LFSR model, TAPS prbs.py:14
+  rnghunt     software/rnghunt/src/binary_matrix.rs:183-192 (test_recur KAT, literal)
+              software/rnghunt/src/berlekamp_massey.rs:40,45 (PRBS-9 / PRBS-11 strings, literal)
+
+Matrices come from basebandboard_amd/data/lutopt_N.txt (imported from the
+reference by tools/import_matrices.py).  Nothing here is imported from the build's
+own oracle or product code, so the fixtures are independent of both.
+Run in the build container:  python3 tools/make_golden.py
+"""
+import json
+import pathlib
+
+import numpy as np
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+DATA = ROOT / "basebandboard_amd" / "data"
+OUT = ROOT / "tests" / "golden"
+
+TAPS = {7: 6, 9: 5, 11: 9, 15: 14, 20: 3, 23: 18, 31: 28}   # prbs.py:14
+
+
+def load_matrix(n):
+    rows = [l.strip() for l in open(DATA / f"lutopt_{n}.txt") if l.strip()]
+    return np.array([[int(c) for c in r] for r in rows], dtype=np.uint8)
+
+
+def lutopt_states(a, init, nsteps):
+    """rng.py:126-135 model: column vector x, x[0] = LSB of the integer."""
+    k = a.shape[0]
+    x = np.zeros((k, 1), dtype=np.uint8)
+    for i in range(k):
+        x[i] = (init >> i) & 1
+    a64 = a.astype(np.int64)
+    out = []
+    for _ in range(nsteps):
+        x = np.mod(np.dot(a64, x), 2)
+        out.append(int(''.join(str(int(xi)) for xi in x[::-1].flatten()), 2))
+    return out
+
+
+def clt_tree(x_int, n):
+    """rng.py:173-181: LSB-first bit list, log2(n) levels of y[p//2] = x[p] - x[p+1]."""
+    logn = int(np.log2(n))
+    x = np.array([int(c) for c in bin(x_int)[2:].rjust(n, "0")[::-1]])
+    for level in range(logn):
+        level_n = 2**(logn - level)
+        y = np.zeros(level_n//2, dtype=np.int16)
+        for pair in range(0, level_n, 2):
+            y[pair//2] = x[pair] - x[pair+1]
+        x = y
+    return int(x[0])
+
+
+def wrap_signed(v, bits):
+    """CLTGRNG.x is Signal((logn, True)) (rng.py:78): the tree value truncated to logn bits, signed."""
+    v &= (1 << bits) - 1
+    return v - (1 << bits) if v >> (bits - 1) else v
+
+
+def prbs_bits(k, nbits, lfsr=1):
+    bits = []
+    for _ in range(nbits):
+        bit = ((lfsr >> (k-1)) ^ (lfsr >> TAPS[k]-1)) & 1      # prbs.py:112
+        lfsr = ((lfsr << 1) | bit) & ((1 << k)-1)              # prbs.py:113
+        bits.append(bit)
+    return bits, lfsr
+
+
+def main():
+    OUT.mkdir(parents=True, exist_ok=True)
+    # ---- LUTOPT + CLT -------------------------------------------------------
+    lut = {}
+    for n, nsteps in ((16, 256), (32, 256), (64, 256), (128, 256), (256, 4096)):
+        a = load_matrix(n)
+        logn = int(np.log2(n))
+        states = lutopt_states(a, 1, nsteps)
+        tree = [clt_tree(s, n) for s in states]
+        lut[str(n)] = {
+            "init": "0x1",
+            "states_hex": [hex(s) for s in states[:64]],
+            "state_last_hex": hex(states[-1]),
+            "clt_tree": tree,                                   # un-truncated tree value
+            "clt_out": [wrap_signed(t, logn) for t in tree],    # logn-bit signed output
+        }
+    # a second seed for n256: init = 0xDEADBEEF... pattern (bit i of the integer = x[i])
+    a = load_matrix(256)
+    init2 = int("0123456789abcdef" * 4, 16)
+    st = lutopt_states(a, init2, 512)
+    lut["256_seed2"] = {
+        "init": hex(init2),
+        "states_hex": [hex(s) for s in st[:8]],
+        "state_last_hex": hex(st[-1]),
+        "clt_out": [wrap_signed(clt_tree(s, 256), 8) for s in st],
+    }
+    # extreme input: bits set exactly where the tree weight is +1 -> +128 -> wraps to -128
+    mplus = sum(1 << i for i in range(256) if bin(i).count("1") % 2 == 0)
+    lut["256_extreme"] = {"x_hex": hex(mplus), "clt_tree": clt_tree(mplus, 256),
+                          "clt_out": wrap_signed(clt_tree(mplus, 256), 8)}
+    json.dump(lut, open(OUT / "lutopt_clt.json", "w"), indent=0)
+
+    # ---- PRBS ---------------------------------------------------------------
+    pr = {}
+    for k in TAPS:
+        bits, s = prbs_bits(k, 4096)
+        pr[str(k)] = {"init": 1, "bits": "".join(map(str, bits)), "state_after": s}
+        b2, s2 = prbs_bits(k, 1024, lfsr=(0x5A5A5A5A & ((1 << k) - 1)) | 1)
+        pr[str(k) + "_seed2"] = {"init": (0x5A5A5A5A & ((1 << k) - 1)) | 1,
+                                 "bits": "".join(map(str, b2)), "state_after": s2}
+    # literal strings held by the reference's Rust tests (cross-pin of PRBS9 / PRBS11)
+    pr["rnghunt_bm_prbs9"] = "0000100011000010011"       # berlekamp_massey.rs:40
+    pr["rnghunt_bm_prbs11"] = "00000000101000000100010"  # berlekamp_massey.rs:45
+    json.dump(pr, open(OUT / "prbs.json", "w"), indent=0)
+
+    # ---- rnghunt GF(2) KATs (literals from the Rust unit tests) -------------
+    gf2 = {
+        "test_recur": {   # binary_matrix.rs:183-192: column-major words, MSbit = row 0
+            "nrows": 8, "ncols": 8,
+            "col_words_hex": ["0x7400000000000000", "0x5800000000000000", "0xC500000000000000",
+                              "0xD000000000000000", "0xD500000000000000", "0xE600000000000000",
+                              "0xF100000000000000", "0x4700000000000000"],
+            "x_bits": [1, 0, 1, 0, 1, 0, 1, 0], "n": 24,
+            "out_bits": [1, 0, 1, 1, 0, 0, 0, 1, 1, 1, 0, 0, 0, 1, 1, 1, 0, 0, 0, 1, 1, 1, 0, 0],
+        }
+    }
+    json.dump(gf2, open(OUT / "gf2.json", "w"), indent=0)
+    print("wrote", sorted(p.name for p in OUT.iterdir()))
+
+
+if __name__ == "__main__":
+    main()
