@@ -1,0 +1,98 @@
+"""ctypes binding of libbbb_hip.so (C ABI: include/bbb.h).
+
+The library is the product: if it is missing or cannot be loaded this module raises --
+there is no Python/NumPy/CPU fallback for any of the compute entry points.
+"""
+import ctypes as C
+import pathlib
+
+_HERE = pathlib.Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libbbb_hip.so"
+
+BBB_OK, BBB_EINVAL, BBB_ENOMEM, BBB_EHIP, BBB_EIO, BBB_ENODEV, BBB_EUNSUP = 0, -1, -2, -3, -4, -5, -6
+
+# every symbol include/bbb.h declares (tests/test_abi.py checks the list against the header)
+SYMBOLS = [
+    "bbb_abi_version", "bbb_strerror", "bbb_last_error_detail", "bbb_device_count", "bbb_free",
+    "bbb_lutopt_load_matrix_file", "bbb_lutopt_create", "bbb_lutopt_destroy", "bbb_lutopt_set_stream",
+    "bbb_lutopt_is_specialised", "bbb_lutopt_profile", "bbb_lutopt_profile_read", "bbb_lutopt_state_at", "bbb_awgn_fill_i8", "bbb_awgn_fill_i16",
+    "bbb_clt_tree_i16", "bbb_prbs_fill", "bbb_prbs_check", "bbb_prbs_check_dev", "bbb_prbs_state_at",
+    "bbb_prbs_detector_run", "bbb_ber_trials", "bbb_ber_trials_dev",
+]
+
+
+class BbbError(RuntimeError):
+    def __init__(self, code, what, detail):
+        super().__init__(f"{what}: {detail}" if detail else what)
+        self.code = code
+
+
+class TrialCfg(C.Structure):
+    """bbb_trial_cfg"""
+    _fields_ = [("prbs_k", C.c_int32), ("amp", C.c_int32), ("noise_var", C.c_int32), ("reserved", C.c_int32),
+                ("prbs_state", C.c_uint64), ("warmup", C.c_uint64), ("first_bit", C.c_uint64),
+                ("nbits", C.c_uint64)]
+
+
+class Ber(C.Structure):
+    """bbb_ber"""
+    _fields_ = [("bits", C.c_uint64), ("errors", C.c_uint64)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libbbb_hip.so (once).  Raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  basebandboard_amd has no CPU fallback.")
+    l = C.CDLL(str(LIB_PATH))
+    vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
+    u64p = C.POINTER(C.c_uint64)
+    l.bbb_abi_version.restype = i32
+    l.bbb_strerror.restype = C.c_char_p
+    l.bbb_strerror.argtypes = [i32]
+    l.bbb_last_error_detail.restype = C.c_char_p
+    l.bbb_device_count.argtypes = [C.POINTER(i32)]
+    l.bbb_free.argtypes = [vp]
+    l.bbb_free.restype = None
+    l.bbb_lutopt_load_matrix_file.argtypes = [C.c_char_p, C.POINTER(i32), C.POINTER(C.POINTER(C.c_uint16)),
+                                              C.POINTER(C.POINTER(C.c_uint32))]
+    l.bbb_lutopt_create.argtypes = [C.POINTER(vp), i32, C.POINTER(C.c_uint16), C.POINTER(C.c_uint32), u64p, i32]
+    l.bbb_lutopt_destroy.argtypes = [vp]
+    l.bbb_lutopt_set_stream.argtypes = [vp, vp]
+    l.bbb_lutopt_is_specialised.argtypes = [vp]
+    l.bbb_lutopt_state_at.argtypes = [vp, u64, u64p]
+    l.bbb_lutopt_profile.argtypes = [vp, i32]
+    l.bbb_lutopt_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), u64p, i32]
+    l.bbb_awgn_fill_i8.argtypes = [vp, vp, u64, u64]
+    l.bbb_awgn_fill_i16.argtypes = [vp, vp, u64, u64]
+    l.bbb_clt_tree_i16.argtypes = [i32, vp, u64, vp, i32, vp]
+    l.bbb_prbs_fill.argtypes = [i32, u64, u64, u64, vp, i32, vp]
+    l.bbb_prbs_check.argtypes = [i32, u64, u64, u64, vp, u64p, i32, vp]
+    l.bbb_prbs_check_dev.argtypes = [i32, u64, u64, u64, vp, vp, i32, vp]
+    l.bbb_prbs_state_at.argtypes = [i32, u64, u64, u64p]
+    l.bbb_prbs_detector_run.argtypes = [i32, vp, u64, u64, vp, vp, i32, vp]
+    l.bbb_ber_trials.argtypes = [vp, C.POINTER(TrialCfg), i32, C.POINTER(Ber)]
+    l.bbb_ber_trials_dev.argtypes = [vp, C.POINTER(TrialCfg), i32, vp]
+    for name in SYMBOLS:
+        getattr(l, name)          # AttributeError here = header and library out of step
+    _lib = l
+    return l
+
+
+def check(rc, what):
+    """Map a BBB_E* code to the exception the reference interface raises for it."""
+    if rc == BBB_OK:
+        return
+    l = lib()
+    detail = l.bbb_last_error_detail().decode(errors="replace")
+    name = l.bbb_strerror(rc).decode()
+    if rc == BBB_EINVAL:
+        raise ValueError(detail or name)          # e.g. "k=8 invalid for PRBS" (prbs.py:29-30)
+    raise BbbError(rc, f"{what} failed ({name})", detail)

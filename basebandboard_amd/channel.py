@@ -1,0 +1,109 @@
+"""BPSK-over-PRBS through CLT AWGN, sliced and counted -- the Monte-Carlo loop built from the
+reference's TX noise path (gateware/bbb/tx.py:70-81) and RX slicer (gateware/bbb/rx.py:29).
+
+The reference has no error counter and no Eb/N0 notion (prbs.py:79 raises an unconsumed pulse;
+the noise level is the 4-bit `noise_var` multiplier, tx.py:52): the counters, the Eb/N0 <->
+(amp, noise_var) mapping and the sharding of trials over GPUs are defined here.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from .prbs import TAPS
+
+SIGMA_G = 8.0          # CLTGRNG standard deviation for n = 256: sqrt(2**(8-2)) (rng.py:63-65)
+
+
+def ebn0_db(amp, noise_var):
+    """Eb/N0 realised by r = +-amp + noise_var * g with Var[g] = 64: amp^2 / (2 sigma^2)."""
+    if noise_var == 0:
+        return math.inf
+    return 10.0 * math.log10(amp * amp / (2.0 * (SIGMA_G * noise_var) ** 2))
+
+
+def amp_for_ebn0(db, noise_var):
+    """Nearest integer BPSK level for a target Eb/N0 at the given noise multiplier."""
+    return int(round(SIGMA_G * noise_var * math.sqrt(2.0 * 10.0 ** (db / 10.0))))
+
+
+def ber_theory(db):
+    """Q(sqrt(2 Eb/N0)) -- the Gaussian-channel sanity value (the CLT tails are lighter)."""
+    return 0.5 * math.erfc(math.sqrt(10.0 ** (db / 10.0)))
+
+
+class Trial:
+    """One (Eb/N0 point, seed-offset) trial; field meaning as bbb_trial_cfg in include/bbb.h."""
+
+    def __init__(self, nbits, amp, noise_var, prbs_k=31, prbs_state=1, warmup=16, first_bit=0):
+        if prbs_k not in TAPS:
+            raise ValueError("k={} invalid for PRBS".format(prbs_k))
+        self.nbits, self.amp, self.noise_var = int(nbits), int(amp), int(noise_var)
+        self.prbs_k, self.prbs_state = int(prbs_k), int(prbs_state)
+        self.warmup, self.first_bit = int(warmup), int(first_bit)
+
+    def as_c(self):
+        return _lib.TrialCfg(self.prbs_k, self.amp, self.noise_var, 0, self.prbs_state, self.warmup,
+                             self.first_bit, self.nbits)
+
+
+def run_trials(urng, trials):
+    """Run trials on `urng`'s GPU; returns a list of (bits, errors)."""
+    if not trials:
+        return []
+    cfgs = (_lib.TrialCfg * len(trials))(*[t.as_c() for t in trials])
+    out = (_lib.Ber * len(trials))()
+    urng._bind_stream()
+    _lib.check(_lib.lib().bbb_ber_trials(urng._h, cfgs, len(trials), out), "bbb_ber_trials")
+    return [(o.bits, o.errors) for o in out]
+
+
+def run_trials_into(urng, trials, counters):
+    """Accumulate into an int64 CUDA tensor [len(trials), 2] without synchronising (the buffer a
+    multi-GPU sweep all-reduces)."""
+    if counters.dtype != torch.int64 or not counters.is_cuda or not counters.is_contiguous() \
+            or counters.numel() < 2 * len(trials):
+        raise ValueError("counters must be a contiguous int64 CUDA tensor with 2 words per trial")
+    if not trials:
+        return counters
+    cfgs = (_lib.TrialCfg * len(trials))(*[t.as_c() for t in trials])
+    urng._bind_stream()
+    _lib.check(_lib.lib().bbb_ber_trials_dev(urng._h, cfgs, len(trials), C.c_void_p(counters.data_ptr())),
+               "bbb_ber_trials_dev")
+    return counters
+
+
+# ---- sharding a sweep over ranks (one process per GPU) -----------------------------------------
+
+def shard(ntrials, rank, world):
+    """Static round-robin: trial i runs on rank i % world."""
+    return list(range(rank, ntrials, world))
+
+
+def sweep(trials, runner, rank=0, world=1, group=None):
+    """Run this rank's share of `trials` and sum the 64-bit counters over ranks with ONE all-reduce.
+
+    `runner(local_trials, counters_view)` must add (bits, errors) of each local trial into the rows
+    of `counters_view` ([len(local), 2] int64, on the device the process group reduces on); on a
+    GPU rank it is `lambda ts, c: run_trials_into(urng, ts, c)`.  Integer sums are order
+    independent, so the result equals the single-rank result exactly.
+    Returns an int64 tensor [len(trials), 2] holding the global counters on every rank.
+    """
+    import torch.distributed as dist
+    mine = shard(len(trials), rank, world)
+    local = runner([trials[i] for i in mine], len(mine))
+    total = torch.zeros((len(trials), 2), dtype=torch.int64, device=local.device)
+    if mine:
+        total[torch.tensor(mine, device=local.device)] = local
+    if world > 1:
+        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+    return total
+
+
+def gpu_runner(urng):
+    """The `runner` for `sweep` on a GPU rank."""
+    def run(local_trials, n):
+        c = torch.zeros((n, 2), dtype=torch.int64, device=torch.device("cuda", urng.device))
+        return run_trials_into(urng, local_trials, c)
+    return run

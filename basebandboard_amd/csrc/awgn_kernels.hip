@@ -1,0 +1,321 @@
+// awgn_kernels.hip -- LUTOPT uniform generator + CLT Gaussian adder tree on gfx950.
+//
+// Reference semantics (paths relative to the reference checkout):
+//   LUTOPT   gateware/bbb/rng.py:14-55    x'[r] = XOR of x[taps[r]], all rows from the old state
+//   CLTGRNG  gateware/bbb/rng.py:58-108   log2(n)-level tree of y[j] = x[2j] - x[2j+1]
+//            software/clt-grng/clt-grng-evaluate.py:8-16  (same tree in numpy)
+//
+// GPU formulation.  The reference is ONE generator emitting one sample per clock.  Here the
+// sequential stream is cut into G contiguous segments of L samples; generator g starts from
+// A^(first_step + g*L) * init (GF(2) jump-ahead), so the concatenation is bit-identical to the
+// reference stream.  32 generators are packed per lane (bit-slicing: VGPR p = state bit p of
+// 32 generators), a wave therefore advances 2048 generators per step with ~1000 V_BITOP3/XOR
+// instructions (tools/gen_lutopt_kernel.py emits the straight-line network for the matrix).
+//
+// Kernels
+//   seed_levels_kernel   start states by doubling: S[2^d + i] = (A^L)^(2^d) * S[i]
+//   bitslice_kernel      [G][k bits] -> planes [k][lanes] (32x32 bit transposes)
+//   awgn256_kernel       the hot kernel (n256 matrix of gateware/bbb/rng_recurrences.py:172-259)
+//   awgn_generic_kernel  any k <= 512 / any taps, table driven, planes in global scratch
+//   clt_tree_kernel      adder tree of caller-supplied words (clt-grng-evaluate.py loop body)
+//
+// Roofline of awgn256_kernel: integer VALU (about 33 lane-ops per 1-byte sample); the sample
+// stream is 1 B/sample of HBM writes, issued as 16-byte stores, one per generator per 16 steps.
+#include "bbb_common.hpp"
+#include "bitslice_util.hpp"
+#include "awgn_launch.hpp"
+#include "gen/lutopt256_gen.inc"
+
+namespace bbb {
+
+// ---------------------------------------------------------------------------------------------
+// Start states by doubling.  cols holds, per level d, the COLUMNS of B_d = A^(L*2^d):
+// cols[(d*k + c)*W32 + w]; y = B x is the XOR of the columns c with x[c] = 1.
+// ---------------------------------------------------------------------------------------------
+struct State16 { uint32_t w[16]; };
+
+template <int W32>
+__device__ __forceinline__ void gf2_colmul(const uint32_t *__restrict cols, int k, const uint32_t (&x)[W32],
+                                           uint32_t (&y)[W32]) {
+#pragma unroll
+    for (int w = 0; w < W32; w++) y[w] = 0;
+#pragma unroll
+    for (int cw = 0; cw < W32; cw++) {
+        const uint32_t xw = x[cw];
+        if (cw * 32 >= k) break;
+#pragma unroll 8
+        for (int cb = 0; cb < 32; cb++) {
+            const uint32_t m = (uint32_t)(-(int32_t)((xw >> cb) & 1u));
+            const uint32_t *col = cols + (size_t)(cw * 32 + cb) * W32;   // wave-uniform address
+#pragma unroll
+            for (int w = 0; w < W32; w++) y[w] ^= col[w] & m;
+        }
+    }
+}
+
+// One launch covers levels [d0, d1).  For d1 - d0 > 1 it must be a single block (block-level
+// barriers order the levels); the host uses that for the first, tiny levels.
+template <int W32>
+__global__ void __launch_bounds__(256)
+seed_levels_kernel(const uint32_t *__restrict cols, int k, State16 s0, int d0, int d1, unsigned long long G,
+                   uint32_t *__restrict S) {
+    const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d0 == 0 && tid == 0) {
+#pragma unroll
+        for (int w = 0; w < W32; w++) S[w] = s0.w[w];
+    }
+    if (d0 == 0) __syncthreads();
+    for (int d = d0; d < d1; d++) {
+        const unsigned long long lo = 1ull << d;
+        if (tid < lo && lo + tid < G) {
+            uint32_t x[W32], y[W32];
+#pragma unroll
+            for (int w = 0; w < W32; w++) x[w] = S[tid * W32 + w];
+            gf2_colmul<W32>(cols + (size_t)d * k * W32, k, x, y);
+#pragma unroll
+            for (int w = 0; w < W32; w++) S[(lo + tid) * W32 + w] = y[w];
+        }
+        if (d + 1 < d1) __syncthreads();
+    }
+}
+
+// [G][W32] packed states -> bit planes.  Thread (LG, wq) gathers word wq of the 32 generators of
+// lane LG and transposes: planes[(32*wq + p) * nlanes + LG] bit j = state bit 32*wq+p of g(LG, j).
+template <int W32>
+__global__ void __launch_bounds__(256)
+bitslice_kernel(const uint32_t *__restrict S, unsigned long long G, unsigned nlanes, int k,
+                uint32_t *__restrict planes) {
+    const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long LG = t % nlanes;       // consecutive threads -> consecutive lanes (coalesced stores)
+    const unsigned wq = (unsigned)(t / nlanes);
+    if (wq * 32 >= (unsigned)k) return;
+    const unsigned long long wave = LG >> 6;
+    const unsigned lane = (unsigned)(LG & 63);
+    uint32_t q[32];
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+        const unsigned long long g = gen_index(wave, lane, j);
+        q[j] = g < G ? S[g * W32 + wq] : 0u;
+    }
+    transpose32(q);
+#pragma unroll
+    for (int p = 0; p < 32; p++)
+        if (wq * 32 + p < (unsigned)k) planes[(size_t)(wq * 32 + p) * nlanes + LG] = q[p];
+}
+
+// ---------------------------------------------------------------------------------------------
+// The hot kernel: n256, one wave per block, one wave per SIMD (the 256-plane state plus the
+// update's temporaries need the whole 512-register file).
+//
+// Per round of 16 steps a lane leaves 16 bytes for each of its 32 generators:
+//   step t   -> 8 count planes cnt[b] (bit j = bit b of generator j's sample) -> LDS P[t][b][lane]
+//   round end-> for w = 0..3: Q[8*tt+b] = P[4w+tt][b]; transpose32(Q): Q[j] = the 4 sample
+//               bytes of generator j for steps 4w..4w+3; staged back to LDS, re-read as 16 B
+//               per generator and stored with one global_store_dwordx4.
+// All LDS traffic is lane-private (dword index = row*64 + lane: conflict-free, no barriers).
+// ---------------------------------------------------------------------------------------------
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+awgn256_kernel(const uint32_t *__restrict planes, int8_t *__restrict dst, unsigned long long nsamples,
+               unsigned L, unsigned long long G, unsigned nlanes) {
+    __shared__ uint32_t P[16 * 8 * 64];
+    const unsigned lane = threadIdx.x;
+    const unsigned long long wave = blockIdx.x;
+    const unsigned long long LG = wave * 64 + lane;
+
+    uint32_t a[256], b[256], cnt[8];
+#pragma unroll
+    for (int p = 0; p < 256; p++) a[p] = planes[(size_t)p * nlanes + LG];
+
+    const unsigned rounds = L / 16;
+#pragma unroll 1
+    for (unsigned r = 0; r < rounds; r++) {
+#pragma unroll 1
+        for (unsigned tt = 0; tt < 8; tt++) {
+            lutopt256_step(a, b, cnt);
+#pragma unroll
+            for (int q = 0; q < 8; q++) P[((2 * tt) * 8 + q) * 64 + lane] = cnt[q];
+            lutopt256_step(b, a, cnt);
+#pragma unroll
+            for (int q = 0; q < 8; q++) P[((2 * tt + 1) * 8 + q) * 64 + lane] = cnt[q];
+        }
+#pragma unroll 1
+        for (unsigned w = 0; w < 4; w++) {
+            uint32_t q[32];
+#pragma unroll
+            for (int i = 0; i < 32; i++) q[i] = P[(w * 32 + i) * 64 + lane];
+            transpose32(q);
+#pragma unroll
+            for (int j = 0; j < 32; j++) P[(w * 32 + j) * 64 + lane] = q[j];
+        }
+#pragma unroll 4
+        for (unsigned j = 0; j < 32; j++) {
+            const unsigned long long g = gen_index(wave, lane, j);
+            const unsigned long long off = g * L + (unsigned long long)r * 16;
+            if (g < G && off < nsamples) {
+                u32x4 v;
+                v.x = P[(0 * 32 + j) * 64 + lane];
+                v.y = P[(1 * 32 + j) * 64 + lane];
+                v.z = P[(2 * 32 + j) * 64 + lane];
+                v.w = P[(3 * 32 + j) * 64 + lane];
+                if (off + 16 <= nsamples) {
+                    *reinterpret_cast<u32x4 *>(dst + off) = v;
+                } else {
+                    const unsigned n = (unsigned)(nsamples - off);
+                    for (unsigned e = 0; e < n; e++) dst[off + e] = (int8_t)((v[e >> 2] >> (8 * (e & 3))) & 0xff);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Table-driven kernel for any power-of-two k <= 512 and any tap lists (slow path: used for the
+// reference's small test matrices and for k != 256).  State planes live in global scratch
+// [2][k][nlanes]; every lane touches only its own column, so no synchronisation is needed.
+// T = sum_i y_i is kept as a 10-plane ripple counter.
+// ---------------------------------------------------------------------------------------------
+template <typename OutT>
+__global__ void __launch_bounds__(64)
+awgn_generic_kernel(int k, int logk, const uint16_t *__restrict taps, const uint32_t *__restrict row_off,
+                    uint32_t *__restrict planes2, OutT *__restrict dst, unsigned long long nsamples, unsigned L,
+                    unsigned long long G, unsigned nlanes) {
+    const unsigned lane = threadIdx.x;
+    const unsigned long long wave = blockIdx.x;
+    const unsigned long long LG = wave * 64 + lane;
+    uint32_t *cur = planes2, *nxt = planes2 + (size_t)k * nlanes;
+    for (unsigned t = 0; t < L; t++) {
+        uint32_t c[10];
+#pragma unroll
+        for (int q = 0; q < 10; q++) c[q] = 0;
+        for (int r = 0; r < k; r++) {
+            uint32_t acc = 0;
+            for (uint32_t e = row_off[r]; e < row_off[r + 1]; e++) acc ^= cur[(size_t)taps[e] * nlanes + LG];
+            nxt[(size_t)r * nlanes + LG] = acc;
+            uint32_t carry = (__builtin_popcount((unsigned)r) & 1) ? ~acc : acc;   // weight -1 bits enter complemented
+#pragma unroll
+            for (int q = 0; q < 10; q++) {
+                const uint32_t tcar = c[q] & carry;
+                c[q] ^= carry;
+                carry = tcar;
+            }
+        }
+        for (unsigned j = 0; j < 32; j++) {
+            const unsigned long long g = gen_index(wave, lane, j);
+            const unsigned long long off = g * L + t;
+            if (g < G && off < nsamples) {
+                int T = 0;
+#pragma unroll
+                for (int q = 0; q < 10; q++) T |= (int)((c[q] >> j) & 1u) << q;
+                int v = (T - (k >> 1)) & (k - 1);                 // log2(k)-bit two's complement (rng.py:78,108)
+                if (v >> (logk - 1)) v -= k;
+                dst[off] = (OutT)v;
+            }
+        }
+        uint32_t *sw = cur; cur = nxt; nxt = sw;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adder tree on caller-supplied words (clt-grng-evaluate.py:8-16), closed form: +1 weight where
+// popcount(bit index) is even.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+clt_tree_kernel(int nwords, const unsigned long long *__restrict states, unsigned long long nstates,
+                int16_t *__restrict out) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nstates) return;
+    int pos = 0, all = 0;
+    for (int w = 0; w < nwords; w++) {
+        const unsigned long long x = states[i * nwords + w];
+        const unsigned long long m = (__builtin_popcount((unsigned)w) & 1) ? ~kThueMorse64 : kThueMorse64;
+        pos += __builtin_popcountll(x & m);
+        all += __builtin_popcountll(x);
+    }
+    out[i] = (int16_t)(2 * pos - all);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------------------
+template <int W32>
+static int seed_and_slice(int k, const uint32_t *d_cols, const uint32_t *s0, uint64_t G, uint32_t *d_states,
+                          unsigned nlanes, uint32_t *d_planes, hipStream_t st) {
+    State16 s;
+    for (int w = 0; w < 16; w++) s.w[w] = w < W32 ? s0[w] : 0u;
+    int levels = 0;
+    while ((1ull << levels) < G) levels++;
+    const int first = levels < 8 ? levels : 8;
+    // levels [0, first): one block of 256 threads (at most 128 sources per level)
+    hipLaunchKernelGGL((seed_levels_kernel<W32>), dim3(1), dim3(256), 0, st, d_cols, k, s, 0, first,
+                       (unsigned long long)G, d_states);
+    for (int d = first; d < levels; d++) {
+        const uint64_t n = 1ull << d;
+        hipLaunchKernelGGL((seed_levels_kernel<W32>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_cols, k, s,
+                           d, d + 1, (unsigned long long)G, d_states);
+    }
+    const uint64_t threads = (uint64_t)nlanes * (uint64_t)((k + 31) / 32);
+    hipLaunchKernelGGL((bitslice_kernel<W32>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, d_states,
+                       (unsigned long long)G, nlanes, k, d_planes);
+    BBB_HIP(hipGetLastError());
+    return BBB_OK;
+}
+
+int awgn_seed_launch(int k, const uint32_t *d_cols, const uint32_t *s0, uint64_t G, uint32_t *d_states,
+                     unsigned nlanes, uint32_t *d_planes, hipStream_t st) {
+    switch ((k + 31) / 32) {
+    case 1: return seed_and_slice<1>(k, d_cols, s0, G, d_states, nlanes, d_planes, st);
+    case 2: return seed_and_slice<2>(k, d_cols, s0, G, d_states, nlanes, d_planes, st);
+    case 4: return seed_and_slice<4>(k, d_cols, s0, G, d_states, nlanes, d_planes, st);
+    case 8: return seed_and_slice<8>(k, d_cols, s0, G, d_states, nlanes, d_planes, st);
+    case 16: return seed_and_slice<16>(k, d_cols, s0, G, d_states, nlanes, d_planes, st);
+    default: return fail(BBB_EINVAL, "k must be a power of two in [16, 512]");
+    }
+}
+
+int awgn256_fill_launch(const uint32_t *d_planes, int8_t *dst, uint64_t nsamples, unsigned L, uint64_t G,
+                        unsigned nlanes, hipStream_t st) {
+    const unsigned nwaves = nlanes / 64;
+    hipLaunchKernelGGL(awgn256_kernel, dim3(nwaves), dim3(64), 0, st, d_planes, dst, (unsigned long long)nsamples, L,
+                       (unsigned long long)G, nlanes);
+    BBB_HIP(hipGetLastError());
+    return BBB_OK;
+}
+
+int awgn_generic_fill_launch(int k, const uint16_t *d_taps, const uint32_t *d_row_off, uint32_t *d_planes2,
+                             void *dst, int elem_size, uint64_t nsamples, unsigned L, uint64_t G, unsigned nlanes,
+                             hipStream_t st) {
+    int logk = 0;
+    while ((1 << logk) < k) logk++;
+    const unsigned nwaves = nlanes / 64;
+    if (elem_size == 1)
+        hipLaunchKernelGGL((awgn_generic_kernel<int8_t>), dim3(nwaves), dim3(64), 0, st, k, logk, d_taps, d_row_off,
+                           d_planes2, (int8_t *)dst, (unsigned long long)nsamples, L, (unsigned long long)G, nlanes);
+    else
+        hipLaunchKernelGGL((awgn_generic_kernel<int16_t>), dim3(nwaves), dim3(64), 0, st, k, logk, d_taps, d_row_off,
+                           d_planes2, (int16_t *)dst, (unsigned long long)nsamples, L, (unsigned long long)G, nlanes);
+    BBB_HIP(hipGetLastError());
+    return BBB_OK;
+}
+
+int clt_tree_launch(int k, const uint64_t *states, uint64_t nstates, int16_t *out, hipStream_t st) {
+    if (nstates == 0) return BBB_OK;
+    hipLaunchKernelGGL(clt_tree_kernel, dim3((unsigned)((nstates + 255) / 256)), dim3(256), 0, st, (k + 63) / 64,
+                       (const unsigned long long *)states, (unsigned long long)nstates, out);
+    BBB_HIP(hipGetLastError());
+    return BBB_OK;
+}
+
+bool awgn256_matches(int k, const uint16_t *taps, const uint32_t *row_off) {
+    if (k != 256) return false;
+    uint32_t e = 0;
+    for (int r = 0; r < 256; r++) {
+        if (row_off[r + 1] - row_off[r] != LUTOPT256_NTAPS[r]) return false;
+        for (uint32_t j = row_off[r]; j < row_off[r + 1]; j++)
+            if (taps[j] != LUTOPT256_TAPS[e++]) return false;
+    }
+    return true;
+}
+
+}  // namespace bbb

@@ -1,0 +1,30 @@
+// awgn_launch.hpp -- host-side launch entry points of the generator kernels.
+#pragma once
+#include "bbb_common.hpp"
+
+namespace bbb {
+
+// start states S[g] = B^g s0 (B given per doubling level as column lists) and their bit planes
+int awgn_seed_launch(int k, const uint32_t *d_cols, const uint32_t *s0, uint64_t G, uint32_t *d_states,
+                     unsigned nlanes, uint32_t *d_planes, hipStream_t st);
+int awgn256_fill_launch(const uint32_t *d_planes, int8_t *dst, uint64_t nsamples, unsigned L, uint64_t G,
+                        unsigned nlanes, hipStream_t st);
+int awgn_generic_fill_launch(int k, const uint16_t *d_taps, const uint32_t *d_row_off, uint32_t *d_planes2,
+                             void *dst, int elem_size, uint64_t nsamples, unsigned L, uint64_t G, unsigned nlanes,
+                             hipStream_t st);
+int clt_tree_launch(int k, const uint64_t *states, uint64_t nstates, int16_t *out, hipStream_t st);
+bool awgn256_matches(int k, const uint16_t *taps, const uint32_t *row_off);
+
+// fused BER trial kernels (ber_kernels.hip)
+struct TrialDev {            // one trial as the kernel sees it
+    int32_t prbs_k, prbs_tap;
+    int32_t nthr[2];         // number of decision-flip thresholds for bit = 0 / bit = 1
+    int32_t thr[2][4];       // error indicator for bit b = XOR_i [ T >= thr[b][i] ],  T = sample + 128 (mod 256)
+    uint32_t L;              // bits per generator
+    uint64_t G, nbits;
+};
+int ber256_launch(const uint32_t *d_planes, const uint32_t *d_prbs_planes, const TrialDev &t, unsigned nlanes,
+                  unsigned long long *d_counters, hipStream_t st);
+int prbs_state_at_host(int k, uint64_t init_state, uint64_t nbits, uint64_t *state);
+
+}  // namespace bbb

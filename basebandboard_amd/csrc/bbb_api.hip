@@ -1,0 +1,522 @@
+// bbb_api.hip -- the extern "C" boundary of libbbb_hip.so (see include/bbb.h).
+// Host logic only: argument checks, GF(2) jump-ahead plans, workspace, kernel launches.
+#include "bbb_common.hpp"
+#include "awgn_launch.hpp"
+#include "gf2.hpp"
+
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <vector>
+
+namespace bbb {
+
+std::string &last_error() {
+    static thread_local std::string s;
+    return s;
+}
+
+int use_device(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(BBB_ENODEV, "no HIP device visible");
+    if (device < 0 || device >= n) return fail(BBB_ENODEV, "device index out of range");
+    hipDeviceProp_t p;
+    BBB_HIP(hipGetDeviceProperties(&p, device));
+    if (std::strncmp(p.gcnArchName, "gfx950", 6) != 0)
+        return fail(BBB_ENODEV, std::string("device is ") + p.gcnArchName + ", this library is built for gfx950 only");
+    BBB_HIP(hipSetDevice(device));
+    return BBB_OK;
+}
+
+// device copy of the doubling matrices for one segment length L
+struct JumpPlan {
+    uint32_t *d_cols = nullptr;   // [levels][k][W32]
+    int levels = 0;
+};
+
+}  // namespace bbb
+
+using namespace bbb;
+
+struct bbb_lutopt {
+    int k = 0, W64 = 0, W32 = 0, device = 0;
+    bool specialised = false;
+    hipStream_t stream = nullptr;
+    std::vector<uint16_t> taps;
+    std::vector<uint32_t> row_off;
+    uint64_t init[8] = {0};
+    std::unique_ptr<GF2Powers> pw;                 // powers of A
+    std::map<uint64_t, JumpPlan> plans;            // keyed by L
+    std::map<uint64_t, JumpPlan> prbs_plans;       // keyed by (k << 48 | L)
+    // workspace
+    uint32_t *d_states = nullptr; size_t states_cap = 0;      // [G][W32]
+    uint32_t *d_planes = nullptr; size_t planes_cap = 0;      // [2][k][nlanes] (second half: generic kernel)
+    uint32_t *d_pstates = nullptr; size_t pstates_cap = 0;    // PRBS [G]
+    uint32_t *d_pplanes = nullptr; size_t pplanes_cap = 0;    // PRBS [32][nlanes]
+    uint16_t *d_taps = nullptr;
+    uint32_t *d_row_off = nullptr;
+    unsigned long long *d_counters = nullptr; size_t counters_cap = 0;
+    // which stream position the planes in d_planes currently describe
+    bool planes_valid = false;
+    uint64_t planes_first = 0, planes_L = 0, planes_G = 0;
+    unsigned max_waves = 1024;
+    // optional per-call device timing of the generator kernels (bbb_lutopt_profile)
+    bool profiling = false;
+    struct ProfEv { hipEvent_t e0, e1, e2; };
+    std::vector<ProfEv> prof_pending;
+    double prof_seed_ms = 0, prof_main_ms = 0;
+    uint64_t prof_calls = 0;
+};
+
+namespace {
+
+int grow(uint32_t **p, size_t *cap, size_t need_words) {
+    if (*cap >= need_words) return BBB_OK;
+    if (*p) BBB_HIP(hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    BBB_HIP(hipMalloc((void **)p, need_words * sizeof(uint32_t)));
+    *cap = need_words;
+    return BBB_OK;
+}
+
+// columns of (M^(2^d)) for d < levels, packed [d][c][W32], uploaded to the device
+int build_plan(const GF2Mat &M, int levels, JumpPlan *plan) {
+    const int k = M.n, W32 = (k + 31) / 32;
+    std::vector<uint32_t> host((size_t)levels * k * W32, 0);
+    GF2Mat cur = M;
+    for (int d = 0; d < levels; d++) {
+        if (d) cur = cur.mul(cur);
+        for (int c = 0; c < k; c++)
+            for (int r = 0; r < k; r++)
+                if (cur.get(r, c)) host[((size_t)d * k + c) * W32 + (r >> 5)] |= 1u << (r & 31);
+    }
+    BBB_HIP(hipMalloc((void **)&plan->d_cols, host.size() * sizeof(uint32_t)));
+    BBB_HIP(hipMemcpy(plan->d_cols, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    plan->levels = levels;
+    return BBB_OK;
+}
+
+constexpr int kPlanLevels = 26;   // up to 2^26 generators
+
+int get_plan(bbb_lutopt *h, uint64_t L, JumpPlan **out) {
+    auto it = h->plans.find(L);
+    if (it == h->plans.end()) {
+        JumpPlan p;
+        int rc = build_plan(h->pw->power(L), kPlanLevels, &p);
+        if (rc) return rc;
+        it = h->plans.emplace(L, p).first;
+    }
+    *out = &it->second;
+    return BBB_OK;
+}
+
+int get_prbs_plan(bbb_lutopt *h, int k, uint64_t L, JumpPlan **out) {
+    const uint64_t key = ((uint64_t)k << 56) ^ L;
+    auto it = h->prbs_plans.find(key);
+    if (it == h->prbs_plans.end()) {
+        JumpPlan p;
+        GF2Powers pw(prbs_matrix(k, prbs_tap(k)));
+        int rc = build_plan(pw.power(L), kPlanLevels, &p);
+        if (rc) return rc;
+        it = h->prbs_plans.emplace(key, p).first;
+    }
+    *out = &it->second;
+    return BBB_OK;
+}
+
+// Partition n stream positions into G segments of L; granule = store alignment of a segment.
+void partition(const bbb_lutopt *h, uint64_t n, unsigned granule, uint64_t *L, uint64_t *G, unsigned *nlanes) {
+    const uint64_t gmax = (uint64_t)h->max_waves * 2048;
+    uint64_t l = (n + gmax - 1) / gmax;
+    if (l < 64) l = 64;
+    l = (l + granule - 1) / granule * granule;
+    const uint64_t g = (n + l - 1) / l;
+    const uint64_t waves = (g + 2047) / 2048;
+    *L = l;
+    *G = g;
+    *nlanes = (unsigned)(waves * 64);
+}
+
+// make d_planes hold the bit-sliced states A^(first + g*L) init, g < G
+int prepare_planes(bbb_lutopt *h, uint64_t first, uint64_t L, uint64_t G, unsigned nlanes) {
+    if (h->planes_valid && h->planes_first == first && h->planes_L == L && h->planes_G == G) return BBB_OK;
+    JumpPlan *plan;
+    int rc = get_plan(h, L, &plan);
+    if (rc) return rc;
+    if ((rc = grow(&h->d_states, &h->states_cap, (size_t)G * h->W32))) return rc;
+    if ((rc = grow(&h->d_planes, &h->planes_cap, (size_t)2 * h->k * nlanes))) return rc;
+    uint64_t s0[8];
+    h->pw->apply(first, h->init, s0);
+    uint32_t s32[16] = {0};
+    for (int w = 0; w < h->W32; w++) s32[w] = (uint32_t)(s0[w >> 1] >> (32 * (w & 1)));
+    h->planes_valid = false;
+    rc = awgn_seed_launch(h->k, plan->d_cols, s32, G, h->d_states, nlanes, h->d_planes, h->stream);
+    if (rc) return rc;
+    h->planes_valid = true;
+    h->planes_first = first; h->planes_L = L; h->planes_G = G;
+    return BBB_OK;
+}
+
+int awgn_fill(bbb_lutopt *h, void *dst, int elem_size, uint64_t nsamples, uint64_t first_step) {
+    if (!h) return fail(BBB_EINVAL, "null handle");
+    if (nsamples == 0) return BBB_OK;
+    if (!dst || ((uintptr_t)dst & 15)) return fail(BBB_EINVAL, "dst must be a 16-byte aligned device pointer");
+    if (first_step + nsamples < first_step) return fail(BBB_EINVAL, "first_step + nsamples overflows");
+    if (elem_size == 1 && h->k > 256) return fail(BBB_EUNSUP, "k > 256 needs the int16 output");
+    if (h->device < 0) return fail(BBB_ENODEV, "host-only handle (device -1) cannot generate samples");
+    BBB_HIP(hipSetDevice(h->device));
+    uint64_t L, G;
+    unsigned nlanes;
+    partition(h, nsamples, 16, &L, &G, &nlanes);
+    bbb_lutopt::ProfEv ev{};
+    if (h->profiling) {
+        BBB_HIP(hipEventCreate(&ev.e0)); BBB_HIP(hipEventCreate(&ev.e1)); BBB_HIP(hipEventCreate(&ev.e2));
+        BBB_HIP(hipEventRecord(ev.e0, h->stream));
+    }
+    int rc = prepare_planes(h, first_step, L, G, nlanes);
+    if (rc) return rc;
+    if (h->specialised && elem_size == 1) {
+        if (h->profiling) BBB_HIP(hipEventRecord(ev.e1, h->stream));
+        rc = awgn256_fill_launch(h->d_planes, (int8_t *)dst, nsamples, (unsigned)L, G, nlanes, h->stream);
+        if (h->profiling) {
+            BBB_HIP(hipEventRecord(ev.e2, h->stream));
+            h->prof_pending.push_back(ev);
+        }
+        return rc;
+    }
+    h->planes_valid = false;    // the table-driven kernel advances the planes in place
+    return awgn_generic_fill_launch(h->k, h->d_taps, h->d_row_off, h->d_planes, dst, elem_size, nsamples, (unsigned)L, G,
+                                    nlanes, h->stream);
+}
+
+// tabulate the channel of tx.py:75-81 / rx.py:29 into threshold lists over T = sample + 128
+int wrap12(int v) {
+    unsigned u = (unsigned)v & 0xfffu;
+    return (u & 0x800u) ? (int)u - 4096 : (int)u;
+}
+int channel_thresholds(int amp, int noise_var, TrialDev *t) {
+    for (int bv = 0; bv < 2; bv++) {
+        int n = 0, prev = 0;
+        for (int T = 0; T < 256; T++) {
+            const int g = T - 128;                                  // int8 CLT sample
+            const int noise = wrap12(g * noise_var);                // tx.py:75-77
+            const int x = wrap12((bv ? amp : -amp) + noise);        // tx.py:80-81
+            const int decided = x >= 0;                             // rx.py:29
+            const int err = decided != bv;
+            if (err != prev) {
+                if (n == 4) return fail(BBB_EUNSUP, "channel needs more than 4 decision thresholds");
+                t->thr[bv][n++] = T;
+                prev = err;
+            }
+        }
+        t->nthr[bv] = n;
+    }
+    return BBB_OK;
+}
+
+int ber_run(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, unsigned long long *counters_dev) {
+    if (!h->specialised) return fail(BBB_EUNSUP, "BER trials need the n256 generator");
+    for (int i = 0; i < ncfg; i++) {
+        const bbb_trial_cfg &c = cfgs[i];
+        const int tap = prbs_tap(c.prbs_k);
+        if (!tap) return fail(BBB_EINVAL, "k=" + std::to_string(c.prbs_k) + " invalid for PRBS");
+        if (c.prbs_state == 0 || (c.prbs_state >> c.prbs_k)) return fail(BBB_EINVAL, "PRBS state must be in [1, 2^k)");
+        if (c.amp < 0 || c.amp > 2047 || c.noise_var < 0 || c.noise_var > 15)
+            return fail(BBB_EINVAL, "amp must be 0..2047 and noise_var 0..15");
+        if (c.nbits == 0) continue;
+        TrialDev t{};
+        t.prbs_k = c.prbs_k;
+        t.prbs_tap = tap;
+        int rc = channel_thresholds(c.amp, c.noise_var, &t);
+        if (rc) return rc;
+        uint64_t L, G;
+        unsigned nlanes;
+        partition(h, c.nbits, 2, &L, &G, &nlanes);
+        t.L = (uint32_t)L; t.G = G; t.nbits = c.nbits;
+        if ((rc = prepare_planes(h, c.warmup + c.first_bit, L, G, nlanes))) return rc;
+        // PRBS start states: the same doubling machinery with the k x k LFSR companion matrix
+        JumpPlan *pp;
+        if ((rc = get_prbs_plan(h, c.prbs_k, L, &pp))) return rc;
+        if ((rc = grow(&h->d_pstates, &h->pstates_cap, (size_t)G))) return rc;
+        if ((rc = grow(&h->d_pplanes, &h->pplanes_cap, (size_t)32 * nlanes))) return rc;
+        uint64_t ps0 = 0;
+        if ((rc = prbs_state_at_host(c.prbs_k, c.prbs_state, c.first_bit, &ps0))) return rc;
+        uint32_t ps32[16] = {(uint32_t)ps0};
+        if ((rc = awgn_seed_launch(c.prbs_k, pp->d_cols, ps32, G, h->d_pstates, nlanes, h->d_pplanes, h->stream))) return rc;
+        if ((rc = ber256_launch(h->d_planes, h->d_pplanes, t, nlanes, counters_dev + 2 * (size_t)i, h->stream))) return rc;
+    }
+    return BBB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bbb_abi_version(void) { return BBB_ABI_VERSION; }
+
+const char *bbb_strerror(int code) {
+    switch (code) {
+    case BBB_OK: return "ok";
+    case BBB_EINVAL: return "invalid argument";
+    case BBB_ENOMEM: return "out of memory";
+    case BBB_EHIP: return "HIP runtime error";
+    case BBB_EIO: return "matrix file unreadable or malformed";
+    case BBB_ENODEV: return "no gfx950 device";
+    case BBB_EUNSUP: return "unsupported request";
+    default: return "unknown error";
+    }
+}
+
+const char *bbb_last_error_detail(void) { return last_error().c_str(); }
+
+int bbb_device_count(int *count) {
+    if (!count) return fail(BBB_EINVAL, "null count");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+    return BBB_OK;
+}
+
+void bbb_free(void *p) { std::free(p); }
+
+int bbb_lutopt_load_matrix_file(const char *path, int *k, uint16_t **taps, uint32_t **row_off) {
+    if (!path || !k || !taps || !row_off) return fail(BBB_EINVAL, "null argument");
+    FILE *f = std::fopen(path, "r");
+    if (!f) return fail(BBB_EIO, std::string("cannot open ") + path);
+    std::vector<std::string> rows;
+    char line[BBB_MAX_K + 16];
+    while (std::fgets(line, sizeof line, f)) {
+        std::string s(line);
+        while (!s.empty() && (s.back() == '\n' || s.back() == '\r' || s.back() == ' ')) s.pop_back();
+        if (!s.empty()) rows.push_back(s);
+    }
+    std::fclose(f);
+    const int n = (int)rows.size();
+    if (n == 0 || n > BBB_MAX_K) return fail(BBB_EIO, "matrix must have 1..512 rows");
+    std::vector<uint16_t> t;
+    std::vector<uint32_t> off(1, 0);
+    for (int r = 0; r < n; r++) {
+        if ((int)rows[r].size() != n) return fail(BBB_EIO, "matrix is not square");
+        for (int c = 0; c < n; c++) {
+            if (rows[r][c] == '1') t.push_back((uint16_t)c);
+            else if (rows[r][c] != '0') return fail(BBB_EIO, "matrix holds a character other than 0/1");
+        }
+        off.push_back((uint32_t)t.size());
+    }
+    *taps = (uint16_t *)std::malloc(sizeof(uint16_t) * (t.empty() ? 1 : t.size()));
+    *row_off = (uint32_t *)std::malloc(sizeof(uint32_t) * off.size());
+    if (!*taps || !*row_off) return fail(BBB_ENOMEM, "malloc");
+    std::memcpy(*taps, t.data(), sizeof(uint16_t) * t.size());
+    std::memcpy(*row_off, off.data(), sizeof(uint32_t) * off.size());
+    *k = n;
+    return BBB_OK;
+}
+
+int bbb_lutopt_create(bbb_lutopt **out, int k, const uint16_t *taps, const uint32_t *row_off,
+                      const uint64_t *init_words, int device) {
+    if (!out || !taps || !row_off || !init_words) return fail(BBB_EINVAL, "null argument");
+    if (k < 16 || k > BBB_MAX_K || (k & (k - 1))) return fail(BBB_EINVAL, "k must be a power of two in [16, 512]");
+    GF2Mat A(k);
+    for (int r = 0; r < k; r++) {
+        const uint32_t n = row_off[r + 1] - row_off[r];
+        if (row_off[r + 1] < row_off[r] || n < 1 || n > 8) return fail(BBB_EINVAL, "every row needs 1..8 taps");
+        for (uint32_t j = row_off[r]; j < row_off[r + 1]; j++) {
+            if (taps[j] >= k) return fail(BBB_EINVAL, "tap index out of range");
+            if (A.get(r, taps[j])) return fail(BBB_EINVAL, "duplicate tap in a row");
+            A.set(r, taps[j]);
+        }
+    }
+    // device == -1: a host-only handle for the jump-ahead algebra (bbb_lutopt_state_at);
+    // every compute entry point on it fails with BBB_ENODEV -- there is no CPU compute path.
+    if (device != -1) {
+        int rc = use_device(device);
+        if (rc) return rc;
+    }
+    std::unique_ptr<bbb_lutopt> h(new bbb_lutopt);
+    h->k = k;
+    h->W64 = (k + 63) / 64;
+    h->W32 = (k + 31) / 32;
+    h->device = device;
+    h->taps.assign(taps, taps + row_off[k]);
+    h->row_off.assign(row_off, row_off + k + 1);
+    bool any = false;
+    for (int w = 0; w < h->W64; w++) {
+        uint64_t v = init_words[w];
+        if (w == h->W64 - 1 && (k & 63)) v &= (1ull << (k & 63)) - 1ull;
+        h->init[w] = v;
+        any |= v != 0;
+    }
+    (void)any;   // an all-zero state is legal in the HDL too (it just stays zero)
+    h->pw.reset(new GF2Powers(A));
+    h->specialised = awgn256_matches(k, taps, row_off);
+    if (device == -1) {
+        *out = h.release();
+        return BBB_OK;
+    }
+    hipDeviceProp_t p;
+    BBB_HIP(hipGetDeviceProperties(&p, device));
+    h->max_waves = (unsigned)p.multiProcessorCount * 4;    // one wave per SIMD
+    BBB_HIP(hipMalloc((void **)&h->d_taps, sizeof(uint16_t) * h->taps.size()));
+    BBB_HIP(hipMalloc((void **)&h->d_row_off, sizeof(uint32_t) * h->row_off.size()));
+    BBB_HIP(hipMemcpy(h->d_taps, h->taps.data(), sizeof(uint16_t) * h->taps.size(), hipMemcpyHostToDevice));
+    BBB_HIP(hipMemcpy(h->d_row_off, h->row_off.data(), sizeof(uint32_t) * h->row_off.size(), hipMemcpyHostToDevice));
+    *out = h.release();
+    return BBB_OK;
+}
+
+int bbb_lutopt_destroy(bbb_lutopt *h) {
+    if (!h) return BBB_OK;
+    if (h->device < 0) { delete h; return BBB_OK; }
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    for (auto &p : h->plans) (void)hipFree(p.second.d_cols);
+    for (auto &p : h->prbs_plans) (void)hipFree(p.second.d_cols);
+    for (void *p : {(void *)h->d_states, (void *)h->d_planes, (void *)h->d_pstates, (void *)h->d_pplanes,
+                    (void *)h->d_taps, (void *)h->d_row_off, (void *)h->d_counters})
+        (void)hipFree(p);
+    delete h;
+    return BBB_OK;
+}
+
+int bbb_lutopt_set_stream(bbb_lutopt *h, void *hip_stream) {
+    if (!h) return fail(BBB_EINVAL, "null handle");
+    h->stream = (hipStream_t)hip_stream;
+    return BBB_OK;
+}
+
+int bbb_lutopt_is_specialised(const bbb_lutopt *h) { return h && h->specialised ? 1 : 0; }
+
+int bbb_lutopt_profile(bbb_lutopt *h, int enable) {
+    if (!h) return fail(BBB_EINVAL, "null handle");
+    h->profiling = enable != 0;
+    return BBB_OK;
+}
+
+int bbb_lutopt_profile_read(bbb_lutopt *h, double *seed_ms, double *kernel_ms, uint64_t *calls, int reset) {
+    if (!h) return fail(BBB_EINVAL, "null handle");
+    for (auto &ev : h->prof_pending) {
+        BBB_HIP(hipEventSynchronize(ev.e2));
+        float a = 0, b = 0;
+        BBB_HIP(hipEventElapsedTime(&a, ev.e0, ev.e1));
+        BBB_HIP(hipEventElapsedTime(&b, ev.e1, ev.e2));
+        h->prof_seed_ms += a; h->prof_main_ms += b; h->prof_calls++;
+        (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); (void)hipEventDestroy(ev.e2);
+    }
+    h->prof_pending.clear();
+    if (seed_ms) *seed_ms = h->prof_seed_ms;
+    if (kernel_ms) *kernel_ms = h->prof_main_ms;
+    if (calls) *calls = h->prof_calls;
+    if (reset) { h->prof_seed_ms = h->prof_main_ms = 0; h->prof_calls = 0; }
+    return BBB_OK;
+}
+
+int bbb_lutopt_state_at(bbb_lutopt *h, uint64_t nsteps, uint64_t *state_words) {
+    if (!h || !state_words) return fail(BBB_EINVAL, "null argument");
+    h->pw->apply(nsteps, h->init, state_words);
+    return BBB_OK;
+}
+
+int bbb_awgn_fill_i8(bbb_lutopt *h, int8_t *dst_dev, uint64_t nsamples, uint64_t first_step) {
+    return awgn_fill(h, dst_dev, 1, nsamples, first_step);
+}
+
+int bbb_awgn_fill_i16(bbb_lutopt *h, int16_t *dst_dev, uint64_t nsamples, uint64_t first_step) {
+    return awgn_fill(h, dst_dev, 2, nsamples, first_step);
+}
+
+int bbb_clt_tree_i16(int k, const uint64_t *states_dev, uint64_t nstates, int16_t *out_dev, int device,
+                     void *hip_stream) {
+    if (k < 2 || k > BBB_MAX_K || (k & (k - 1)) || (k & 63)) return fail(BBB_EINVAL, "k must be 64, 128, 256 or 512");
+    if (nstates && (!states_dev || !out_dev)) return fail(BBB_EINVAL, "null device pointer");
+    int rc = use_device(device);
+    if (rc) return rc;
+    return clt_tree_launch(k, states_dev, nstates, out_dev, (hipStream_t)hip_stream);
+}
+
+int bbb_prbs_fill(int k, uint64_t init_state, uint64_t first_bit, uint64_t nbits, uint64_t *dst_packed_dev,
+                  int device, void *hip_stream) {
+    if (nbits && !dst_packed_dev) return fail(BBB_EINVAL, "null device pointer");
+    if (!prbs_tap(k)) return fail(BBB_EINVAL, "k=" + std::to_string(k) + " invalid for PRBS");
+    int rc = use_device(device);
+    if (rc) return rc;
+    return prbs_fill_launch(k, init_state, first_bit, nbits, dst_packed_dev, (hipStream_t)hip_stream);
+}
+
+int bbb_prbs_check_dev(int k, uint64_t init_state, uint64_t first_bit, uint64_t nbits,
+                       const uint64_t *src_packed_dev, uint64_t *nerr_dev, int device, void *hip_stream) {
+    if ((nbits && !src_packed_dev) || !nerr_dev) return fail(BBB_EINVAL, "null device pointer");
+    if (!prbs_tap(k)) return fail(BBB_EINVAL, "k=" + std::to_string(k) + " invalid for PRBS");
+    int rc = use_device(device);
+    if (rc) return rc;
+    return prbs_check_launch(k, init_state, first_bit, nbits, src_packed_dev, nerr_dev, (hipStream_t)hip_stream);
+}
+
+int bbb_prbs_check(int k, uint64_t init_state, uint64_t first_bit, uint64_t nbits, const uint64_t *src_packed_dev,
+                   uint64_t *nerr, int device, void *hip_stream) {
+    if (!nerr) return fail(BBB_EINVAL, "null nerr");
+    if (!prbs_tap(k)) return fail(BBB_EINVAL, "k=" + std::to_string(k) + " invalid for PRBS");
+    int rc = use_device(device);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)hip_stream;
+    uint64_t *d = nullptr;
+    BBB_HIP(hipMalloc((void **)&d, sizeof(uint64_t)));
+    rc = BBB_OK;
+    if (hipMemsetAsync(d, 0, sizeof(uint64_t), st) != hipSuccess) rc = fail(BBB_EHIP, "hipMemsetAsync");
+    if (!rc) rc = bbb_prbs_check_dev(k, init_state, first_bit, nbits, src_packed_dev, d, device, hip_stream);
+    if (!rc && hipMemcpyAsync(nerr, d, sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess) rc = fail(BBB_EHIP, "hipMemcpyAsync");
+    if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = fail(BBB_EHIP, "hipStreamSynchronize");
+    (void)hipFree(d);
+    return rc;
+}
+
+int bbb_prbs_state_at(int k, uint64_t init_state, uint64_t nbits, uint64_t *state) {
+    if (!state) return fail(BBB_EINVAL, "null state");
+    if (init_state >> (k > 0 && k < 64 ? k : 63)) return fail(BBB_EINVAL, "PRBS state must be < 2^k");
+    return prbs_state_at_host(k, init_state, nbits, state);
+}
+
+int bbb_prbs_detector_run(int k, const uint8_t *bits_dev, uint64_t nstreams, uint64_t n, uint8_t *err_dev,
+                          uint8_t *reload_dev, int device, void *hip_stream) {
+    if (!prbs_tap(k)) return fail(BBB_EINVAL, "k=" + std::to_string(k) + " invalid for PRBS");
+    if (nstreams && n && !bits_dev) return fail(BBB_EINVAL, "null device pointer");
+    int rc = use_device(device);
+    if (rc) return rc;
+    return prbs_detector_launch(k, bits_dev, nstreams, n, err_dev, reload_dev, (hipStream_t)hip_stream);
+}
+
+int bbb_ber_trials_dev(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, uint64_t *counters_dev) {
+    if (!h || (ncfg && (!cfgs || !counters_dev)) || ncfg < 0) return fail(BBB_EINVAL, "null argument");
+    if (h->device < 0) return fail(BBB_ENODEV, "host-only handle (device -1) cannot run trials");
+    BBB_HIP(hipSetDevice(h->device));
+    return ber_run(h, cfgs, ncfg, (unsigned long long *)counters_dev);
+}
+
+int bbb_ber_trials(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, bbb_ber *out) {
+    if (!h || (ncfg && (!cfgs || !out)) || ncfg < 0) return fail(BBB_EINVAL, "null argument");
+    if (ncfg == 0) return BBB_OK;
+    if (h->device < 0) return fail(BBB_ENODEV, "host-only handle (device -1) cannot run trials");
+    BBB_HIP(hipSetDevice(h->device));
+    const size_t need = 2 * (size_t)ncfg;
+    if (h->counters_cap < need) {
+        if (h->d_counters) BBB_HIP(hipFree(h->d_counters));
+        h->d_counters = nullptr;
+        h->counters_cap = 0;
+        BBB_HIP(hipMalloc((void **)&h->d_counters, need * sizeof(unsigned long long)));
+        h->counters_cap = need;
+    }
+    BBB_HIP(hipMemsetAsync(h->d_counters, 0, need * sizeof(unsigned long long), h->stream));
+    int rc = ber_run(h, cfgs, ncfg, h->d_counters);
+    if (rc) return rc;
+    std::vector<unsigned long long> host(need);
+    BBB_HIP(hipMemcpyAsync(host.data(), h->d_counters, need * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    BBB_HIP(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < ncfg; i++) {
+        out[i].bits = host[2 * (size_t)i];
+        out[i].errors = host[2 * (size_t)i + 1];
+    }
+    return BBB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,295 @@
+// prbs_kernels.hip -- PRBS-k generation / checking / error-detector kernels for gfx950.
+//
+// Reference semantics: gateware/bbb/prbs.py
+//   PRBS              :17-35   bit = s[k-1] ^ s[tap-1]; s = (s << 1 | bit) mod 2^k; reset s = 1
+//   TAPS              :14
+//   PRBSErrorDetector :38-99
+//
+// GPU formulation (not a translation: the reference emits one bit per clock).
+// The emitted stream obeys b[t] = b[t-k] ^ b[t-tap]; squaring over GF(2) gives
+// b[t] = b[t - k*2^m] ^ b[t - tap*2^m] for every m.  With m = 13 the lags are multiples of
+// 128 64-bit words, so if a wave lays the stream out in ROWS of 128 words (lane l owns words
+// 2l, 2l+1 of every row = one 16-byte store per lane, 1 KiB per wave instruction) then
+//     row[q] = row[q-k] ^ row[q-tap]            -- purely lane-local, two 64-bit XORs per 16 B.
+// Each wave owns a contiguous region of rows, keeps a k-row window in registers and streams.
+// The first k rows of a region are built in LDS by the same identity at m = 6..12 (word lags
+// k*2^j, tap*2^j), starting from k words that lanes derive from the LFSR state jumped to the
+// region start with precomputed powers T^(2^i) of the LFSR companion matrix.
+//
+// Roofline: HBM.  fill writes 1/8 B per bit, check reads 1/8 B per bit; ~0.4 VALU op per byte.
+#include "bbb_common.hpp"
+#include "gf2.hpp"
+
+#include <mutex>
+#include <vector>
+
+namespace bbb {
+
+typedef unsigned long long u64;
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+
+__host__ __device__ constexpr int tap_of(int k) {
+    return k == 7 ? 6 : k == 9 ? 5 : k == 11 ? 9 : k == 15 ? 14 : k == 20 ? 3 : k == 23 ? 18 : k == 31 ? 28 : 0;
+}
+static int k_index(int k) {
+    switch (k) { case 7: return 0; case 9: return 1; case 11: return 2; case 15: return 3;
+                 case 20: return 4; case 23: return 5; case 31: return 6; default: return -1; }
+}
+
+// T^(2^i) for i = 0..63 as k rows of 32-bit masks (row r: new bit r = parity(row & s)).
+struct PrbsPowTable { uint32_t rows[64][32]; };
+__device__ PrbsPowTable d_prbs_pow[7];
+
+static const PrbsPowTable &host_pow_table(int k) {
+    static PrbsPowTable tabs[7];
+    static std::once_flag once[7];
+    const int ki = k_index(k);
+    std::call_once(once[ki], [&] {
+        GF2Powers pw(prbs_matrix(k, tap_of(k)));
+        for (int i = 0; i < 64; i++) {
+            const GF2Mat &m = pw.pow2(i);
+            for (int r = 0; r < 32; r++) tabs[ki].rows[i][r] = r < k ? (uint32_t)m.row(r)[0] : 0u;
+        }
+    });
+    return tabs[ki];
+}
+
+static int upload_pow_table(int k) {
+    static std::mutex mu;
+    static bool done[64][7];
+    int dev = 0;
+    BBB_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> g(mu);
+    const int ki = k_index(k);
+    if (dev < 64 && done[dev][ki]) return BBB_OK;
+    const PrbsPowTable &t = host_pow_table(k);
+    BBB_HIP(hipMemcpyToSymbol(HIP_SYMBOL(d_prbs_pow), &t, sizeof t, sizeof(PrbsPowTable) * (size_t)ki));
+    if (dev < 64) done[dev][ki] = true;
+    return BBB_OK;
+}
+
+int prbs_state_at_host(int k, uint64_t init_state, uint64_t nbits, uint64_t *state) {
+    if (!tap_of(k)) return fail(BBB_EINVAL, "k=" + std::to_string(k) + " invalid for PRBS");
+    const PrbsPowTable &t = host_pow_table(k);
+    uint32_t s = (uint32_t)init_state;
+    for (int i = 0; nbits; i++, nbits >>= 1) {
+        if (!(nbits & 1)) continue;
+        uint32_t ns = 0;
+        for (int r = 0; r < k; r++) ns |= (uint32_t)(__builtin_popcount(t.rows[i][r] & s) & 1) << r;
+        s = ns;
+    }
+    *state = s;
+    return BBB_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Streaming generator / checker.  One wave per block; block b owns rows [b*rpw, (b+1)*rpw).
+// ---------------------------------------------------------------------------------------------
+template <int K>
+__device__ __forceinline__ uint32_t lfsr_matvec(const uint32_t *__restrict rows, uint32_t s) {
+    uint32_t ns = 0;
+#pragma unroll
+    for (int r = 0; r < K; r++) ns |= (uint32_t)(__builtin_popcount(rows[r] & s) & 1) << r;
+    return ns;
+}
+
+template <int K, bool CHECK>
+__global__ void __launch_bounds__(64)
+prbs_stream_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwords, u64 rows_per_wave,
+                   u64 *__restrict buf, u64 *__restrict nerr) {
+    constexpr int TAP = tap_of(K);
+    constexpr uint32_t SMASK = (uint32_t)((1ull << K) - 1ull);
+    __shared__ __attribute__((aligned(16))) u64 X[K * 128];
+    const int lane = threadIdx.x;
+    const u64 row0 = (u64)blockIdx.x * rows_per_wave;
+    const u64 word0 = row0 * 128;
+    if (word0 >= nwords) return;
+    const PrbsPowTable &pw = d_prbs_pow[ki];
+
+    // 1. LFSR state at the first bit of this region: s = T^(t0) * init (lane r evaluates row r).
+    const u64 t0 = first_bit + word0 * 64;
+    uint32_t s = (uint32_t)init_state;
+    for (int i = 0; i < 64; i++) {
+        if (!((t0 >> i) & 1)) continue;
+        const uint32_t row = lane < K ? pw.rows[i][lane] : 0u;
+        s = (uint32_t)__ballot(__builtin_popcount(row & s) & 1);
+    }
+    // 2. lane i < K forms word i of the region: jump a further 64*i bits, then clock 64 times.
+    if (lane < K) {
+        uint32_t si = s;
+#pragma unroll
+        for (int m = 0; m < 5; m++) {
+            const uint32_t sj = lfsr_matvec<K>(pw.rows[6 + m], si);
+            si = ((lane >> m) & 1) ? sj : si;
+        }
+        u64 w = 0;
+        for (int j = 0; j < 64; j++) {
+            const uint32_t bit = ((si >> (K - 1)) ^ (si >> (TAP - 1))) & 1u;
+            si = ((si << 1) | bit) & SMASK;
+            w |= (u64)bit << j;
+        }
+        X[lane] = w;
+    }
+    __syncthreads();
+    // 3. grow the known prefix K -> 128K words: level j uses word lags K*2^j and TAP*2^j.
+    {
+        int known = K;
+#pragma unroll 1
+        for (int j = 0; j < 7; j++) {
+            const int lagk = K << j, lagt = TAP << j, target = K << (j + 1);
+            while (known < target) {
+                const int cnt = min(lagt, target - known);
+                for (int base = 0; base < cnt; base += 64) {
+                    const int o = base + lane;
+                    if (o < cnt) X[known + o] = X[known + o - lagk] ^ X[known + o - lagt];
+                }
+                known += cnt;
+                __syncthreads();
+            }
+        }
+    }
+    // 4. register window: V[q] = words (2*lane, 2*lane+1) of row q, q < K.
+    u64x2 V[K];
+#pragma unroll
+    for (int q = 0; q < K; q++) V[q] = *reinterpret_cast<const u64x2 *>(&X[q * 128 + 2 * lane]);
+
+    const u64 rows_total = (nwords - word0 + 127) / 128;
+    const u64 nrows = rows_total < rows_per_wave ? rows_total : rows_per_wave;
+    const u64 last_word = nwords - 1;
+    const u64 last_mask = (nbits & 63) ? ((1ull << (nbits & 63)) - 1ull) : ~0ull;
+    u64 errs = 0;
+
+    for (u64 q0 = 0; q0 < nrows; q0 += K) {
+        u64x2 D[K];
+        if (CHECK) {
+#pragma unroll
+            for (int i = 0; i < K; i++) {
+                const u64 w = word0 + (q0 + i) * 128 + 2 * (u64)lane;
+                D[i] = (u64x2){0, 0};
+                if (q0 + i < nrows) {
+                    if (w + 1 <= last_word) D[i] = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(buf + w));
+                    else if (w <= last_word) D[i].x = buf[w];
+                }
+            }
+        }
+        if (q0 > 0) {
+#pragma unroll
+            for (int i = 0; i < K; i++) V[i] ^= V[(i - TAP + K) % K];   // row[q] = row[q-K] ^ row[q-TAP]
+        }
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            if (q0 + i >= nrows) break;
+            const u64 w = word0 + (q0 + i) * 128 + 2 * (u64)lane;
+            u64x2 v = V[i];
+            if (w == last_word) v.x &= last_mask;
+            if (w + 1 == last_word) v.y &= last_mask;
+            if (CHECK) {
+                u64x2 d = D[i] ^ v;
+                if (w > last_word) d.x = 0;
+                if (w + 1 > last_word) d.y = 0;
+                if (w == last_word) d.x &= last_mask;
+                if (w + 1 == last_word) d.y &= last_mask;
+                errs += (u64)(__builtin_popcountll(d.x) + __builtin_popcountll(d.y));
+            } else {
+                if (w + 1 <= last_word) *reinterpret_cast<u64x2 *>(buf + w) = v;
+                else if (w <= last_word) buf[w] = v.x;
+            }
+        }
+    }
+    if (CHECK) {
+        // wave-level reduction, then ONE 64-bit atomic per wave
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) errs += __shfl_xor(errs, off, 64);
+        if (lane == 0 && errs) atomicAdd(nerr, errs);
+    }
+}
+
+template <bool CHECK>
+static int launch_stream(int k, u64 init_state, u64 first_bit, u64 nbits, u64 *buf, u64 *nerr, hipStream_t st) {
+    const int ki = k_index(k);
+    if (ki < 0) return fail(BBB_EINVAL, "k=" + std::to_string(k) + " invalid for PRBS");
+    if (init_state == 0 || init_state >> k) return fail(BBB_EINVAL, "PRBS state must be in [1, 2^k)");
+    if (nbits == 0) return BBB_OK;
+    if ((uintptr_t)buf & 15) return fail(BBB_EINVAL, "packed PRBS buffer must be 16-byte aligned");
+    if (first_bit + nbits < first_bit) return fail(BBB_EINVAL, "first_bit + nbits overflows");
+    int rc = upload_pow_table(k);
+    if (rc) return rc;
+    const u64 nwords = (nbits + 63) / 64;
+    const u64 rows = (nwords + 127) / 128;
+    const u64 target_waves = 256 * 5;
+    u64 rpw = (rows + target_waves - 1) / target_waves;
+    const u64 min_rpw = 8 * (u64)k;
+    if (rpw < min_rpw) rpw = min_rpw;
+    const u64 nblocks = (rows + rpw - 1) / rpw;
+    if (nblocks > 0x7fffffffull) return fail(BBB_EINVAL, "nbits too large");
+    dim3 grid((unsigned)nblocks), block(64);
+#define BBB_PRBS_CASE(KK)                                                                                    \
+    case KK:                                                                                                 \
+        hipLaunchKernelGGL((prbs_stream_kernel<KK, CHECK>), grid, block, 0, st, ki, init_state, first_bit,   \
+                           nbits, nwords, rpw, buf, nerr);                                                   \
+        break;
+    switch (k) {
+        BBB_PRBS_CASE(7) BBB_PRBS_CASE(9) BBB_PRBS_CASE(11) BBB_PRBS_CASE(15)
+        BBB_PRBS_CASE(20) BBB_PRBS_CASE(23) BBB_PRBS_CASE(31)
+    }
+#undef BBB_PRBS_CASE
+    BBB_HIP(hipGetLastError());
+    return BBB_OK;
+}
+
+int prbs_fill_launch(int k, uint64_t init_state, uint64_t first_bit, uint64_t nbits, uint64_t *dst, hipStream_t st) {
+    return launch_stream<false>(k, init_state, first_bit, nbits, (u64 *)dst, nullptr, st);
+}
+int prbs_check_launch(int k, uint64_t init_state, uint64_t first_bit, uint64_t nbits, const uint64_t *src,
+                      uint64_t *nerr_dev, hipStream_t st) {
+    return launch_stream<true>(k, init_state, first_bit, nbits, (u64 *)const_cast<uint64_t *>(src), (u64 *)nerr_dev, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// PRBSErrorDetector, cycle exact (prbs.py:61-99): one independent detector per lane.
+// Registers: bit_in (:66), prbs reset 1 (:62,:68), err_sr reset all-ones (:80-81), reload_ctr.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+prbs_detector_kernel(int k, int tap, const uint8_t *__restrict bits, u64 nstreams, u64 n,
+                     uint8_t *__restrict err, uint8_t *__restrict reload) {
+    const u64 sidx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (sidx >= nstreams) return;
+    const u64 mask = (1ull << k) - 1ull;
+    u64 prbs = 1, err_sr = mask;
+    int bit_in = 0, reload_ctr = 0;
+    const uint8_t *in = bits + sidx * n;
+    for (u64 i = 0; i < n; i++) {
+        const int feedback = (int)(((prbs >> (k - 1)) ^ (prbs >> (tap - 1))) & 1ull);
+        const int rl = reload_ctr != 0;
+        const int prbs_in = rl ? bit_in : feedback;              // :75-76
+        const int e = bit_in != feedback;                        // :79
+        const int err_count = __builtin_popcountll(err_sr);      // :86-87
+        prbs = ((prbs << 1) | (u64)prbs_in) & mask;              // :68
+        u64 esr = ((err_sr << 1) | (u64)e) & mask;               // :81
+        if (err_count > k / 2) {                                 // :92-94 (overrides the shift)
+            reload_ctr = k + k / 2;
+            esr = 0;
+        } else if (rl) {                                         // :95-97
+            reload_ctr -= 1;
+        }
+        err_sr = esr;
+        bit_in = in[i] & 1;                                      // :66
+        if (err) err[sidx * n + i] = (uint8_t)(bit_in != (int)(((prbs >> (k - 1)) ^ (prbs >> (tap - 1))) & 1ull));
+        if (reload) reload[sidx * n + i] = (uint8_t)(reload_ctr != 0);
+    }
+}
+
+int prbs_detector_launch(int k, const uint8_t *bits, uint64_t nstreams, uint64_t n, uint8_t *err,
+                         uint8_t *reload, hipStream_t st) {
+    const int tap = tap_of(k);
+    if (!tap) return fail(BBB_EINVAL, "k=" + std::to_string(k) + " invalid for PRBS");
+    if (nstreams == 0 || n == 0) return BBB_OK;
+    const u64 nblocks = (nstreams + 255) / 256;
+    if (nblocks > 0x7fffffffull) return fail(BBB_EINVAL, "too many streams");
+    hipLaunchKernelGGL(prbs_detector_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, k, tap, bits,
+                       (u64)nstreams, (u64)n, err, reload);
+    BBB_HIP(hipGetLastError());
+    return BBB_OK;
+}
+
+}  // namespace bbb

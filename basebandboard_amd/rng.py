@@ -1,0 +1,168 @@
+"""Uniform and Gaussian random number generators -- host-side mirror of gateware/bbb/rng.py.
+
+`LUTOPT` and `CLTGRNG` keep the reference's constructor surface (rng.py:21-55, 70-78).  Where the
+reference's HDL emits one value per clock, these objects emit whole streams into HBM: sample i of
+`CLTGRNG.generate` is the value the reference's `grng.x` shows for LUTOPT state number
+first_step + i + 1 (its log2(n)-clock pipeline delay, rng.py:67-68, removed).  All computation
+happens in libbbb_hip.so on the GPU; torch only owns the device memory.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, recurrences
+
+
+def _stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _int_to_words(v, k):
+    n = (k + 63) // 64
+    return (C.c_uint64 * n)(*[(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(n)])
+
+
+class LUTOPT:
+    """Uniform random integers from a binary linear recurrence x' = A x (rng.py:14-40).
+
+    `a` is the k x k 0/1 recurrence matrix, `init` the initial state as an integer whose bit i is
+    state element i (rng.py:30,135).  `x` after n clocks is `state_at(n)`.
+    """
+
+    def __init__(self, a, init=1, device=0):
+        a = np.asarray(a)
+        if a.ndim != 2 or a.shape[0] != a.shape[1]:
+            raise ValueError("recurrence matrix must be square")
+        self._setup([np.nonzero(row)[0].tolist() for row in a], init, device)   # rng.py:38-39
+
+    @classmethod
+    def from_packed(cls, packed, init=1, device=0):
+        """From a list of k lists holding the positions of the 1 entries of each row (rng.py:42-55)."""
+        self = cls.__new__(cls)
+        self._setup([list(r) for r in packed], init, device)
+        return self
+
+    @classmethod
+    def from_matrix_file(cls, path, init=1, device=0):
+        """From a software/rnghunt/matrices/N style text file, parsed by the library."""
+        l = _lib.lib()
+        k = C.c_int()
+        taps = C.POINTER(C.c_uint16)()
+        off = C.POINTER(C.c_uint32)()
+        _lib.check(l.bbb_lutopt_load_matrix_file(str(path).encode(), C.byref(k), C.byref(taps), C.byref(off)),
+                   "bbb_lutopt_load_matrix_file")
+        try:
+            packed = [[taps[j] for j in range(off[r], off[r + 1])] for r in range(k.value)]
+        finally:
+            l.bbb_free(taps)
+            l.bbb_free(off)
+        return cls.from_packed(packed, init, device)
+
+    @classmethod
+    def shipped(cls, n=256, init=1, device=0):
+        """The maximum-period matrix the reference uses for width n (rng_recurrences.py)."""
+        return cls.from_matrix_file(recurrences.matrix_path(n), init, device)
+
+    def _setup(self, packed, init, device):
+        l = _lib.lib()
+        self.k = len(packed)
+        self.packed = packed
+        self.init = int(init)
+        self.device = int(device)
+        flat = (C.c_uint16 * max(1, sum(len(r) for r in packed)))(*[c for r in packed for c in r])
+        offs = [0]
+        for r in packed:
+            offs.append(offs[-1] + len(r))
+        off = (C.c_uint32 * len(offs))(*offs)
+        if self.init < 0 or self.init >> self.k:
+            raise ValueError("init does not fit in k bits")
+        h = C.c_void_p()
+        _lib.check(l.bbb_lutopt_create(C.byref(h), self.k, flat, off, _int_to_words(self.init, self.k), self.device),
+                   "bbb_lutopt_create")
+        self._h = h
+
+    @property
+    def a(self):
+        a = np.zeros((self.k, self.k), dtype=np.uint8)
+        for r, taps in enumerate(self.packed):
+            a[r, taps] = 1
+        return a
+
+    @property
+    def specialised(self):
+        return bool(_lib.lib().bbb_lutopt_is_specialised(self._h))
+
+    def state_at(self, nsteps):
+        """Integer value of `x` after nsteps clocks from reset."""
+        out = (C.c_uint64 * ((self.k + 63) // 64))()
+        _lib.check(_lib.lib().bbb_lutopt_state_at(self._h, nsteps, out), "bbb_lutopt_state_at")
+        return sum(int(w) << (64 * i) for i, w in enumerate(out))
+
+    def profile(self, enable=True):
+        """Time the generator kernels on the device (hipEvents on the launch stream)."""
+        _lib.check(_lib.lib().bbb_lutopt_profile(self._h, int(enable)), "bbb_lutopt_profile")
+
+    def profile_read(self, reset=True):
+        """(seed_ms, kernel_ms, calls) accumulated since the last reset; waits for the events."""
+        a, b, n = C.c_double(), C.c_double(), C.c_uint64()
+        _lib.check(_lib.lib().bbb_lutopt_profile_read(self._h, C.byref(a), C.byref(b), C.byref(n), int(reset)),
+                   "bbb_lutopt_profile_read")
+        return a.value, b.value, n.value
+
+    def _bind_stream(self):
+        _lib.check(_lib.lib().bbb_lutopt_set_stream(self._h, _stream_ptr(self.device)), "bbb_lutopt_set_stream")
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                _lib.lib().bbb_lutopt_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+
+class CLTGRNG:
+    """Gaussian integers by tree-summing the bits of a wide uniform word (rng.py:58-108).
+
+    Mean 0, variance 2**(log2(n) - 2); output width log2(n) bits, signed (rng.py:63-66,78).
+    """
+
+    def __init__(self, urng):
+        n = urng.k
+        if n & (n - 1):
+            raise ValueError("urng width must be a power of two")     # rng.py:72-76
+        self.urng = urng
+        self.n = n
+        self.dtype = torch.int8 if n <= 256 else torch.int16
+
+    @property
+    def variance(self):
+        return 2.0 ** (int(np.log2(self.n)) - 2)
+
+    def generate(self, nsamples, first_step=0, out=None):
+        """nsamples consecutive samples, starting with the one for LUTOPT state first_step + 1."""
+        u = self.urng
+        dev = torch.device("cuda", u.device)
+        if out is None:
+            out = torch.empty(int(nsamples), dtype=self.dtype, device=dev)
+        if out.dtype != self.dtype or out.numel() < nsamples or not out.is_contiguous() or out.device != dev:
+            raise ValueError(f"out must be a contiguous {self.dtype} tensor on {dev} with >= nsamples elements")
+        u._bind_stream()
+        fn = _lib.lib().bbb_awgn_fill_i8 if self.dtype == torch.int8 else _lib.lib().bbb_awgn_fill_i16
+        _lib.check(fn(u._h, C.c_void_p(out.data_ptr()), int(nsamples), int(first_step)), "bbb_awgn_fill")
+        return out[:nsamples]
+
+    @staticmethod
+    def tree(states, n):
+        """Adder-tree value (un-truncated) of caller-supplied uniform words: `states` is an int64 CUDA
+        tensor [nstates, n/64] holding the bit patterns (software/clt-grng/clt-grng-evaluate.py:8-16)."""
+        if states.dtype != torch.int64 or states.dim() != 2 or states.shape[1] * 64 != n or not states.is_cuda:
+            raise ValueError("states must be an int64 CUDA tensor of shape [nstates, n/64]")
+        states = states.contiguous()
+        out = torch.empty(states.shape[0], dtype=torch.int16, device=states.device)
+        dev = states.device.index or 0
+        _lib.check(_lib.lib().bbb_clt_tree_i16(n, C.c_void_p(states.data_ptr()), states.shape[0],
+                                               C.c_void_p(out.data_ptr()), dev, _stream_ptr(dev)), "bbb_clt_tree_i16")
+        return out

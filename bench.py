@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Headline benchmark: CLT Gaussian noise (AWGN) sample generation on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = one pass of the hot path over one batch: 1e9 int8 CLT samples of the reference's
+LUTOPT-256 -> CLTGRNG generator (BASELINE.json configs[1]; the reference has no "CLT-12 /
+xorshift32" generator) written to HBM.  Step s of rank r generates
+stream positions [16 + (s*world + r)*1e9, +1e9): a different part of the SAME sequential stream
+every step and every rank, so nothing is cached between steps and ranks are independent shards
+(weak scaling, no data-path collective).  Seeding (GF(2) jump-ahead on the GPU) is inside the
+timed region.
+
+The JSON line also carries
+  roofline     achieved HBM-write GB/s of the sample kernel (algorithmic 1 B/sample / its mean
+               launch time from hipEvents on the launch stream) against the 8 TB/s HBM peak.
+               The kernel is integer-VALU bound (~1250 lane-ops per 32 samples), so this fraction
+               is expected to be far below 1; `valu_*` fields give the bound that applies.
+  cpu_baseline the CPU oracle (k=256 fast path, 1 thread, -march=native) timed on this host
+               on a bounded sample (rank 0, N = 1 only).
+  extra        PRBS-31 generate+check loopback and a BER sweep, measured after the timed region.
+"""
+import argparse
+import json
+import os
+import pathlib
+import sys
+import time
+
+ROOT = pathlib.Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+NSAMP = 1_000_000_000
+WARM_STATE = 16                  # 2*log2(256): the reference test's warm-up (rng.py:161-162)
+HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+VALU_OPS_PER_SAMPLE = None       # filled from the generated network's op count
+
+
+def cpu_baseline():
+    """Time the oracle's k=256 fast path on this host (checker code used as the reported CPU
+    baseline only).  Bounded sample: ~2e8 samples (10-30 s)."""
+    import numpy as np
+    import oracle as O
+    so = O.build(native=True, out="/tmp/libbbb_oracle_native.so", force=True)
+    lib = O.lib(path=so)
+    m = O.Lutopt(path=O.data_path(256), _lib=lib)
+    n = 20_000_000
+    t0 = time.perf_counter()
+    m.awgn(1, WARM_STATE, n, fast=True)
+    dt = time.perf_counter() - t0
+    reps = max(1, min(10, int(15.0 / max(dt, 1e-3))))
+    t0 = time.perf_counter()
+    for i in range(reps):
+        m.awgn(1, WARM_STATE + i * n, n, fast=True)
+    dt = time.perf_counter() - t0
+    return {"value": round(reps * n / dt / 1e9, 5), "unit": "Gsample/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} x {n} samples of the same stream (oracle k=256 byte-table path, gcc -O3 -march=native, "
+                      f"host has {os.cpu_count()} logical cores)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import basebandboard_amd as bbb
+    from basebandboard_amd import channel
+    u = bbb.LUTOPT.shipped(256, init=1, device=local_rank)
+    assert u.specialised, "bench must run the generated gfx950 kernel"
+    g = bbb.CLTGRNG(u)
+    buf = torch.empty(NSAMP, dtype=torch.int8, device=f"cuda:{local_rank}")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def first_step(step):
+        return WARM_STATE + (step * world + rank) * NSAMP
+
+    # parity spot check before timing (rank 0): a prefix of step 0 against the oracle
+    verified = None
+    g.generate(NSAMP, first_step=first_step(0), out=buf)
+    if rank == 0:
+        import numpy as np
+        import oracle as O
+        m = O.Lutopt(path=O.data_path(256))
+        verified = bool(np.array_equal(buf[:1_000_000].cpu().numpy(), m.awgn(1, WARM_STATE, 1_000_000, fast=True)))
+        tail0 = NSAMP - 4096
+        verified = verified and bool(np.array_equal(buf[tail0:].cpu().numpy(),
+                                                    m.awgn(u.state_at(WARM_STATE + tail0), 0, 4096, fast=True)))
+    for s in range(1, args.warmup + 1):
+        g.generate(NSAMP, first_step=first_step(s), out=buf)
+    u.profile(True)
+    u.profile_read(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        g.generate(NSAMP, first_step=first_step(args.warmup + 1 + s), out=buf)
+    barrier()
+    dt = time.perf_counter() - t0
+    seed_ms, kern_ms, calls = u.profile_read(reset=True)
+    u.profile(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    value = world * args.steps * NSAMP / dt / 1e9
+    kern_avg_ms = kern_ms / max(calls, 1)
+    achieved = NSAMP / (kern_avg_ms * 1e-3) / 1e9 if kern_avg_ms > 0 else 0.0
+
+    # PMC-measured HBM write bytes per launch, if a profile summary of this command is committed
+    traffic = None
+    pmc = ROOT / "profiles" / "r01_awgn256_pmc.json"
+    if pmc.exists():
+        try:
+            traffic = json.load(open(pmc)).get("awgn256_kernel_hbm_write_bytes_per_launch")
+        except Exception:
+            traffic = None
+    ops_per_step = 1002
+    try:
+        inc = (ROOT / "basebandboard_amd" / "csrc" / "gen" / "lutopt256_gen.inc").read_text()
+        import re
+        ops_per_step = int(re.search(r"// (\d+) VALU ops per step", inc).group(1))
+    except Exception:
+        pass
+
+    extra = {}
+    if not args.no_extra:
+        # PRBS-31 loopback (BASELINE configs[2]): 1e10 bits written then read back and checked
+        nbits = 10_000_000_000
+        p = bbb.PRBS(31, device=local_rank)
+        det = bbb.PRBSErrorDetector(31, device=local_rank)
+        pbuf = torch.empty((nbits + 63) // 64, dtype=torch.int64, device=f"cuda:{local_rank}")
+        p.generate(nbits, out=pbuf)
+        torch.cuda.synchronize()
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        reps = 5
+        nerr = None
+        gen_ms = chk_ms = 0.0
+        for _ in range(reps):
+            e0.record(); p.generate(nbits, out=pbuf); e1.record()
+            nerr = det.count_errors(pbuf, nbits); e2.record()
+            torch.cuda.synchronize()
+            gen_ms += e0.elapsed_time(e1); chk_ms += e1.elapsed_time(e2)
+        extra["prbs31_loopback"] = {
+            "bits": nbits, "errors": int(nerr),
+            "gen_gbit_s": round(nbits * reps / gen_ms / 1e6, 1), "check_gbit_s": round(nbits * reps / chk_ms / 1e6, 1),
+            "gen_hbm_write_gb_s": round(nbits / 8 * reps / gen_ms / 1e6, 1),
+            "check_hbm_read_gb_s": round(nbits / 8 * reps / chk_ms / 1e6, 1),
+            "hbm_frac_write": round(nbits / 8 * reps / gen_ms / 1e6 / HBM_PEAK_GBS, 4),
+            "hbm_frac_read": round(nbits / 8 * reps / chk_ms / 1e6 / HBM_PEAK_GBS, 4)}
+        del pbuf
+        # BER sweep (BASELINE configs[3]/[4]): Eb/N0 0..10 dB, 1e9 bits/point, sharded over ranks
+        # (point i -> rank i % world), ONE all-reduce (RCCL) of the uint64 counters.
+        nv = 8
+        trials = [channel.Trial(nbits=1_000_000_000, amp=channel.amp_for_ebn0(db, nv), noise_var=nv) for db in range(11)]
+        torch.cuda.synchronize(); barrier()
+        tb = time.perf_counter()
+        total = channel.sweep(trials, channel.gpu_runner(u), rank=rank, world=world)
+        torch.cuda.synchronize(); barrier()
+        tber = time.perf_counter() - tb
+        tot = total.cpu().tolist()
+        extra["ber_sweep"] = {
+            "points": [{"ebn0_db": round(channel.ebn0_db(t.amp, nv), 3), "amp": t.amp, "noise_var": nv, "bits": b, "errors": e,
+                        "ber": e / b if b else None, "q_theory": channel.ber_theory(channel.ebn0_db(t.amp, nv))}
+                       for t, (b, e) in zip(trials, tot)],
+            "gbit_s": round(sum(b for b, _ in tot) / tber / 1e9, 2), "seconds": round(tber, 4),
+            "reduce": "torch.distributed.all_reduce(int64[11,2], SUM) over RCCL" if world > 1 else "single rank"}
+
+    if rank == 0:
+        out = {
+            "metric": "awgn_clt_gsamples_per_s", "value": round(value, 3), "unit": "Gsample/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32 bit-sliced GF(2) / int8 out", "data": "synthetic",
+            "config": {"workload": "CLT AWGN (LUTOPT-256 -> CLTGRNG adder tree), 1e9 int8 samples/step/GPU, init=1, "
+                                   "warm-up 16, sequential reference stream (BASELINE configs[1]; reference-faithful "
+                                   "generator, no xorshift/CLT-12 exists in the reference)",
+                       "samples_per_step_per_gpu": NSAMP, "seeding_in_timed_region": True,
+                       "verified_vs_oracle": verified},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "awgn256_kernel", "kernel_ms_avg": round(kern_avg_ms, 4),
+                         "seed_ms_avg": round(seed_ms / max(calls, 1), 4), "launches_timed": int(calls),
+                         "algorithmic_bytes_per_launch": NSAMP,
+                         "true_bound": "integer VALU (bit-sliced XOR/majority network), not HBM",
+                         "valu_lane_ops_per_sample": round(ops_per_step / 32.0, 2),
+                         "valu_net_tlaneops_s": round(ops_per_step / 32.0 * achieved / 1e3, 2)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        if extra:
+            out["extra"] = extra
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

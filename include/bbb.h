@@ -1,0 +1,162 @@
+/*
+ * bbb.h -- C ABI of libbbb_hip.so: the MI355X (gfx950) implementation of basebandboard's
+ * AWGN / PRBS Monte-Carlo path.
+ *
+ * The reference has no FFI for this path (it is migen gateware plus one numpy script),
+ * so each entry point below names the reference interface whose semantics it carries;
+ * paths are relative to the reference checkout.  A host in any language binds these
+ * directly (INTEGRATION.md shows the ctypes and Rust `extern "C"` stubs).
+ *
+ * Conventions
+ *  - plain C types only; every function returns BBB_OK (0) or a negative BBB_E* code;
+ *    nothing throws across the boundary.  bbb_strerror() names a code,
+ *    bbb_last_error_detail() gives the failing HIP call of the calling thread.
+ *  - pointers named *_dev are device memory on the handle's / call's device (hipMalloc or
+ *    a torch tensor's data_ptr()); all other pointers are host memory.
+ *  - work is enqueued on the given hipStream_t (passed as void*; NULL = default stream)
+ *    and is asynchronous unless the function returns a result to host memory.
+ *  - there is NO CPU execution path: a call without a usable gfx950 device fails with
+ *    BBB_ENODEV.
+ *  - a handle is not thread-safe; different handles may be used from different threads.
+ *  - bit order: state bit i of a k-bit state is word[i/64] >> (i%64) & 1, the bit order of
+ *    the HDL integer (gateware/bbb/rng.py:135); packed PRBS bit t is word[t/64] >> (t%64) & 1.
+ */
+#ifndef BBB_H
+#define BBB_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BBB_OK        0
+#define BBB_EINVAL   -1   /* bad argument; includes "k invalid for PRBS" (prbs.py:29-30, 55-56) */
+#define BBB_ENOMEM   -2
+#define BBB_EHIP     -3   /* a HIP runtime call failed */
+#define BBB_EIO      -4   /* matrix file unreadable / malformed */
+#define BBB_ENODEV   -5   /* no gfx950 device available */
+#define BBB_EUNSUP   -6   /* valid request this build has no kernel for */
+
+#define BBB_ABI_VERSION 1
+#define BBB_MAX_K 512
+
+int bbb_abi_version(void);
+const char *bbb_strerror(int code);
+const char *bbb_last_error_detail(void);
+int bbb_device_count(int *count);
+/* free() for buffers returned by bbb_lutopt_load_matrix_file */
+void bbb_free(void *p);
+
+/* ---- uniform + Gaussian generator: LUTOPT -> CLTGRNG ------------------------------------ */
+
+typedef struct bbb_lutopt bbb_lutopt;
+
+/* Read a recurrence matrix in the text format of software/rnghunt/matrices/N (N lines of N
+ * chars '0'/'1', line r char c = A[r][c]; written by software/rnghunt/src/bin/rnghunt.rs:51-53,
+ * read by software/rnghunt/util/pack.py:6-18) into packed tap lists: row r's taps are
+ * taps[row_off[r] .. row_off[r+1]) -- the `packed` argument of LUTOPT.from_packed
+ * (gateware/bbb/rng.py:42-55).  Caller frees *taps and *row_off with bbb_free. */
+int bbb_lutopt_load_matrix_file(const char *path, int *k, uint16_t **taps, uint32_t **row_off);
+
+/* LUTOPT(a, init) / LUTOPT.from_packed(packed, init): gateware/bbb/rng.py:21-55.
+ * k must be a power of two in [16, 512] (CLTGRNG needs it: rng.py:72-76); every row 1..8 taps.
+ * init_words = ceil(k/64) words; the reference default is 1 (bit 0 set, rng.py:21).
+ * device = -1 makes a host-only handle: bbb_lutopt_state_at works (pure GF(2) algebra), every
+ * compute call on it returns BBB_ENODEV. */
+int bbb_lutopt_create(bbb_lutopt **h, int k, const uint16_t *taps, const uint32_t *row_off,
+                      const uint64_t *init_words, int device);
+int bbb_lutopt_destroy(bbb_lutopt *h);
+int bbb_lutopt_set_stream(bbb_lutopt *h, void *hip_stream);
+/* 1 when the handle runs the generated straight-line kernel (the n256 matrix of
+ * gateware/bbb/rng_recurrences.py:172-259 used by tx.py:70), 0 for the table-driven one. */
+int bbb_lutopt_is_specialised(const bbb_lutopt *h);
+
+/* Device-side timing of the generator kernels with hipEvents recorded on the handle's stream
+ * around every bbb_awgn_fill_i8 of a specialised handle: [start, seeding kernels, sample kernel].
+ * bbb_lutopt_profile_read waits for the recorded events and returns the accumulated
+ * milliseconds (seeding / sample kernel) and the number of calls; reset != 0 clears the sums. */
+int bbb_lutopt_profile(bbb_lutopt *h, int enable);
+int bbb_lutopt_profile_read(bbb_lutopt *h, double *seed_ms, double *kernel_ms, uint64_t *calls, int reset);
+
+/* LUTOPT.x after `nsteps` clocks from reset (rng.py:38-40), by GF(2) jump-ahead
+ * (the x' = A x algebra of software/rnghunt/src/binary_matrix.rs:53-76). Host result. */
+int bbb_lutopt_state_at(bbb_lutopt *h, uint64_t nsteps, uint64_t *state_words);
+
+/* The CLTGRNG sample stream (gateware/bbb/rng.py:70-108; tx.py:70-71):
+ *   dst_dev[i] = trunc_signed_log2k( tree( A^(first_step + i + 1) * init ) ),  0 <= i < nsamples
+ * i.e. sample i is the adder-tree value of the LUTOPT state after first_step+i+1 clocks,
+ * exactly the sequential stream a single CLTGRNG emits (pipeline delay removed).
+ * Output is int8 (for k = 256: -128..127, +128 wraps to -128 as the 8-bit Signal does).
+ * dst_dev must be 16-byte aligned.  Asynchronous on the handle's stream. */
+int bbb_awgn_fill_i8(bbb_lutopt *h, int8_t *dst_dev, uint64_t nsamples, uint64_t first_step);
+/* Same stream as int16 (needed for k = 512, whose CLTGRNG output is 9 bits: rng.py:78). */
+int bbb_awgn_fill_i16(bbb_lutopt *h, int16_t *dst_dev, uint64_t nsamples, uint64_t first_step);
+
+/* CLTGRNG adder tree on caller-supplied uniform words (the loop body of
+ * software/clt-grng/clt-grng-evaluate.py:8-16): states_dev holds nstates states of
+ * ceil(k/64) u64 words each; out_dev[i] = un-truncated tree value (int16). */
+int bbb_clt_tree_i16(int k, const uint64_t *states_dev, uint64_t nstates, int16_t *out_dev,
+                     int device, void *hip_stream);
+
+/* ---- PRBS generator / checker ---------------------------------------------------------- */
+
+/* PRBS(k).x (gateware/bbb/prbs.py:23-35; TAPS prbs.py:14): bits first_bit .. first_bit+nbits-1
+ * of the sequence started from LFSR state init_state (reference reset value 1), packed
+ * LSB-first into u64 words.  Writes ceil(nbits/64) words; unused high bits of the last
+ * word are zero.  dst_dev must be 16-byte aligned. */
+int bbb_prbs_fill(int k, uint64_t init_state, uint64_t first_bit, uint64_t nbits,
+                  uint64_t *dst_packed_dev, int device, void *hip_stream);
+/* Phase-known checker: number of positions where src differs from the same PRBS.  This is
+ * the steady-state (`reload == 0`) behaviour of PRBSErrorDetector.err (prbs.py:79) summed
+ * over the stream.  *nerr is a host result (the call synchronises the stream). */
+int bbb_prbs_check(int k, uint64_t init_state, uint64_t first_bit, uint64_t nbits,
+                   const uint64_t *src_packed_dev, uint64_t *nerr, int device, void *hip_stream);
+/* Same, accumulating into a device counter (no synchronisation): *nerr_dev += mismatches. */
+int bbb_prbs_check_dev(int k, uint64_t init_state, uint64_t first_bit, uint64_t nbits,
+                       const uint64_t *src_packed_dev, uint64_t *nerr_dev, int device,
+                       void *hip_stream);
+/* LFSR state after nbits clocks (prbs.py:35 iterated), by jump-ahead.  Host result. */
+int bbb_prbs_state_at(int k, uint64_t init_state, uint64_t nbits, uint64_t *state);
+
+/* PRBSErrorDetector (gateware/bbb/prbs.py:43-99), cycle exact, for `nstreams` independent
+ * detectors run in parallel (one per GPU lane).  bits_dev[s*n + i] is the input wire of
+ * stream s during clock i (0/1); err_dev / reload_dev [s*n + i] are `err` and `reload`
+ * sampled after that clock edge -- what the reference testbench reads (prbs.py:146-150).
+ * Either output may be NULL. */
+int bbb_prbs_detector_run(int k, const uint8_t *bits_dev, uint64_t nstreams, uint64_t n,
+                          uint8_t *err_dev, uint8_t *reload_dev, int device, void *hip_stream);
+
+/* ---- fused Monte-Carlo trial: PRBS -> BPSK + scaled CLT noise -> slicer -> error count --- */
+
+/* One trial.  Bit t (0 <= t < nbits) uses PRBS bit first_bit+t and the CLT sample of LUTOPT
+ * state A^(warmup+first_bit+t+1) init; the channel is the TX noise path and RX slicer:
+ *   noise = wrap12(sample * noise_var)            gateware/bbb/tx.py:75-77
+ *   x     = wrap12((bit ? +amp : -amp) + noise)   gateware/bbb/tx.py:80-81
+ *   bit^  = (x >= 0)                              gateware/bbb/rx.py:29
+ * and an error is bit^ != bit.  The counters and the (amp, noise_var) <-> Eb/N0 mapping are
+ * build-defined: the reference has neither. */
+typedef struct {
+    int32_t  prbs_k;       /* 7, 9, 11, 15, 20, 23 or 31 */
+    int32_t  amp;          /* 0..2047 */
+    int32_t  noise_var;    /* 0..15 (4-bit unsigned, tx.py:52) */
+    int32_t  reserved;
+    uint64_t prbs_state;   /* initial LFSR state, non-zero, < 2^k */
+    uint64_t warmup;       /* LUTOPT clocks discarded first (rng.py:161-162 uses 2*log2 k) */
+    uint64_t first_bit;
+    uint64_t nbits;
+} bbb_trial_cfg;
+
+typedef struct { uint64_t bits, errors; } bbb_ber;
+
+/* Run ncfg trials on the handle's generator; out[i] (host) receives trial i's counters. */
+int bbb_ber_trials(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, bbb_ber *out);
+/* Same, adding into device counters counters_dev[2*i] (bits), [2*i+1] (errors) without
+ * synchronising -- the buffer a multi-GPU host hands to one RCCL all-reduce (ncclUint64, sum). */
+int bbb_ber_trials_dev(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, uint64_t *counters_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BBB_H */

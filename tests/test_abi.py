@@ -1,0 +1,135 @@
+"""The C-ABI library loads, exports every symbol include/bbb.h declares, and its host-only entry
+points behave (no compute call is made: there is no GPU here and no CPU compute path)."""
+import ctypes as C
+import re
+
+import numpy as np
+import pytest
+
+import basebandboard_amd as bbb
+from basebandboard_amd import _lib
+from conftest import ROOT
+
+
+def header_symbols():
+    text = (ROOT / "include" / "bbb.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(bbb_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported():
+    lib = _lib.lib()
+    syms = header_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), s
+    assert sorted(_lib.SYMBOLS) == syms
+    assert lib.bbb_abi_version() == 1
+
+
+def test_no_torch_types_or_oracle_in_product():
+    """The boundary is plain C; the product never touches the oracle."""
+    hdr = re.sub(r"/\*.*?\*/", "", (ROOT / "include" / "bbb.h").read_text(), flags=re.S)
+    assert "torch" not in hdr and "at::" not in hdr and "Tensor" not in hdr
+    for p in (ROOT / "basebandboard_amd").rglob("*"):
+        if p.suffix in (".py", ".hip", ".hpp", ".cpp", ".inc"):
+            assert "oracle" not in p.read_text().lower(), p
+
+
+def test_strerror_and_invalid_arguments():
+    lib = _lib.lib()
+    assert lib.bbb_strerror(0) == b"ok"
+    assert b"invalid" in lib.bbb_strerror(_lib.BBB_EINVAL)
+    s = C.c_uint64()
+    assert lib.bbb_prbs_state_at(8, 1, 10, C.byref(s)) == _lib.BBB_EINVAL
+    assert b"k=8 invalid for PRBS" in lib.bbb_last_error_detail()
+    assert lib.bbb_prbs_fill(12, 1, 0, 64, None, 0, None) == _lib.BBB_EINVAL
+    assert lib.bbb_prbs_detector_run(10, None, 1, 1, None, None, 0, None) == _lib.BBB_EINVAL
+    with pytest.raises(ValueError, match="k=10 invalid for PRBS"):
+        bbb.PRBS(10)
+    with pytest.raises(ValueError, match="k=10 invalid for PRBS"):
+        bbb.PRBSErrorDetector(10)
+    assert sorted(bbb.TAPS) == [7, 9, 11, 15, 20, 23, 31]
+
+
+def test_compute_without_gpu_fails_loudly():
+    """No device here: compute entry points must return BBB_ENODEV, never compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    lib = _lib.lib()
+    assert lib.bbb_prbs_fill(31, 1, 0, 64, C.c_void_p(16), 0, None) == _lib.BBB_ENODEV
+    with pytest.raises(_lib.BbbError) as e:
+        bbb.LUTOPT.shipped(256)
+    assert e.value.code == _lib.BBB_ENODEV
+    u = bbb.LUTOPT.shipped(256, device=-1)            # host-only handle: algebra works, compute refuses
+    assert lib.bbb_awgn_fill_i8(u._h, C.c_void_p(16), 16, 0) == _lib.BBB_ENODEV
+    cfg = _lib.TrialCfg(31, 10, 1, 0, 1, 16, 0, 100)
+    out = _lib.Ber()
+    assert lib.bbb_ber_trials(u._h, C.byref(cfg), 1, C.byref(out)) == _lib.BBB_ENODEV
+
+
+@pytest.mark.parametrize("k", (7, 9, 11, 15, 20, 23, 31))
+def test_prbs_jump_ahead_host(oracle, k):
+    """bbb_prbs_state_at (GF(2) jump) against the sequential oracle."""
+    p = bbb.PRBS(k)
+    for n in (0, 1, 5, 64, 1000, 123_457):
+        assert p.state_at(n) == oracle.prbs_bits(k, n)[1]
+    a, b = 10**12 + 7, 98_765
+    mid = bbb.PRBS(k, init=p.state_at(a))
+    assert mid.state_at(b) == p.state_at(a + b)
+    assert p.state_at((1 << k) - 1) == 1               # maximal length: period 2^k - 1
+
+
+@pytest.mark.parametrize("n", (16, 32, 64, 128, 256, 512))
+def test_lutopt_jump_ahead_host(oracle, golden_lutopt, n):
+    """bbb_lutopt_state_at on a host-only handle against the oracle and the golden states."""
+    u = bbb.LUTOPT.shipped(n, device=-1)
+    m = oracle.Lutopt(path=oracle.data_path(n))
+    if str(n) in golden_lutopt:
+        for i, h in enumerate(golden_lutopt[str(n)]["states_hex"][:20]):
+            assert u.state_at(i + 1) == int(h, 16)
+    for t in (0, 1, 2, 63, 64, 1000, 20_011):
+        assert u.state_at(t) == m.run_int(1, t)
+    init = (0x0123456789ABCDEF << (n - 64 if n > 64 else 0) | 5) & ((1 << n) - 1)
+    v = bbb.LUTOPT.shipped(n, init=init, device=-1)
+    assert v.state_at(3333) == m.run_int(init, 3333)
+    far = bbb.LUTOPT.shipped(n, init=v.state_at(10**17), device=-1)
+    assert far.state_at(4242) == v.state_at(10**17 + 4242)
+    assert u.specialised == (n == 256)
+
+
+def test_matrix_file_loader(tmp_path):
+    u = bbb.LUTOPT.from_matrix_file(bbb.recurrences.matrix_path(32), device=-1)
+    assert u.packed == bbb.recurrences.n32 and u.k == 32
+    assert np.array_equal(u.a.sum(axis=1), [len(r) for r in bbb.recurrences.n32])
+    bad = tmp_path / "bad.txt"
+    bad.write_text("010\n10\n001\n")
+    with pytest.raises(_lib.BbbError) as e:
+        bbb.LUTOPT.from_matrix_file(bad, device=-1)
+    assert e.value.code == _lib.BBB_EIO
+    with pytest.raises(_lib.BbbError):
+        bbb.LUTOPT.from_matrix_file(tmp_path / "missing.txt", device=-1)
+    with pytest.raises(ValueError):
+        bbb.LUTOPT.from_packed([[0, 1]] * 24, device=-1)
+
+
+def test_shipped_matrices_have_lut_friendly_weights():
+    """Row and column weights 3..4 (what the LUT-optimised search produces: rnghunt.rs:25)."""
+    for n in bbb.recurrences.SIZES:
+        p = bbb.recurrences.load_packed(bbb.recurrences.matrix_path(n))
+        assert len(p) == n and set(map(len, p)) <= {3, 4}
+        col = np.zeros(n, dtype=int)
+        for r in p:
+            col[r] += 1
+        assert set(col.tolist()) <= {3, 4}
+
+
+def test_channel_helpers():
+    from basebandboard_amd import channel
+    assert channel.amp_for_ebn0(0.0, 8) == 91             # 64 * sqrt(2) = 90.5
+    assert abs(channel.ebn0_db(91, 8) - 0.0) < 0.05
+    assert abs(channel.ber_theory(0.0) - 0.0786) < 1e-3
+    assert channel.shard(10, 1, 4) == [1, 5, 9]
+    with pytest.raises(ValueError, match="invalid for PRBS"):
+        bbb.Trial(10, 1, 1, prbs_k=12)

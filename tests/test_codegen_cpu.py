@@ -1,0 +1,100 @@
+"""The generated straight-line LUTOPT/CLT network and the bit-matrix helpers, compiled for the
+HOST with g++ (V_BITOP3 emulated by its truth table) and checked against the oracle.  This
+exercises the exact text the HIP kernels include, without a GPU."""
+import ctypes as C
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+HARNESS = r"""
+#include <cstdint>
+#include <cstring>
+#define __device__
+#define __forceinline__ inline
+static inline uint32_t __builtin_amdgcn_bitop3_b32(uint32_t a, uint32_t b, uint32_t c, unsigned tt) {
+  uint32_t r = 0;
+  for (int i = 0; i < 8; i++) if ((tt >> i) & 1) { uint32_t m = ~0u; m &= (i & 4) ? a : ~a; m &= (i & 2) ? b : ~b; m &= (i & 1) ? c : ~c; r |= m; }
+  return r;
+}
+#include "GEN_INC"
+#include "bitslice_util.hpp"
+extern "C" void step(const uint32_t* a, uint32_t* b, uint32_t* cnt) {
+  uint32_t A[NN], B[NN], Cn[LOGN]; memcpy(A, a, sizeof A); STEPFN(A, B, Cn); memcpy(b, B, sizeof B); memcpy(cnt, Cn, sizeof Cn);
+}
+extern "C" void t32(uint32_t* q) { uint32_t Q[32]; memcpy(Q, q, sizeof Q); bbb::transpose32(Q); memcpy(q, Q, sizeof Q); }
+extern "C" unsigned long long gidx(unsigned long long w, unsigned l, unsigned j) { return bbb::gen_index(w, l, j); }
+"""
+
+
+def build(tmp_path, n):
+    inc = tmp_path / f"lutopt{n}_gen.inc"
+    subprocess.check_call([sys.executable, str(ROOT / "tools" / "gen_lutopt_kernel.py"),
+                           str(ROOT / "basebandboard_amd" / "data" / f"lutopt_{n}.txt"), str(inc)])
+    src = tmp_path / f"h{n}.cpp"
+    src.write_text(HARNESS.replace("GEN_INC", inc.name))
+    so = tmp_path / f"h{n}.so"
+    logn = n.bit_length() - 1
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", f"-DNN={n}", f"-DLOGN={logn}",
+                           f"-DSTEPFN=lutopt{n}_step", f"-I{tmp_path}", f"-I{ROOT / 'basebandboard_amd' / 'csrc'}",
+                           str(src), "-o", str(so)])
+    return C.CDLL(str(so))
+
+
+@pytest.mark.parametrize("n", (32, 256))
+def test_generated_network_matches_oracle(oracle, tmp_path, n):
+    lib = build(tmp_path, n)
+    logn = n.bit_length() - 1
+    m = oracle.Lutopt(path=oracle.data_path(n))
+    rng = np.random.default_rng(n)
+    states = [int.from_bytes(rng.bytes(n // 8), "little") for _ in range(32)]
+    states[0] = 1
+    states[1] = (1 << n) - 1
+    a = np.zeros(n, dtype=np.uint32)
+    for g, s in enumerate(states):
+        for p in range(n):
+            if (s >> p) & 1:
+                a[p] |= np.uint32(1 << g)
+    b = np.zeros(n, dtype=np.uint32)
+    cnt = np.zeros(logn, dtype=np.uint32)
+    P = lambda x: x.ctypes.data_as(C.POINTER(C.c_uint32))  # noqa: E731
+    for _ in range(12):
+        lib.step(P(a), P(b), P(cnt))
+        for g in range(32):
+            states[g] = m.step_int(states[g])
+            got = sum(((int(b[p]) >> g) & 1) << p for p in range(n))
+            assert got == states[g]
+            v = sum(((int(cnt[q]) >> g) & 1) << q for q in range(logn))
+            v = v - n if v >= n // 2 else v
+            assert v == m.clt_wrap(m.clt_tree(states[g]))
+        a, b = b.copy(), a
+
+
+def test_committed_generated_file_is_current(tmp_path):
+    """csrc/gen/lutopt256_gen.inc (built by build()) must be what the generator emits today."""
+    cur = ROOT / "basebandboard_amd" / "csrc" / "gen" / "lutopt256_gen.inc"
+    if not cur.exists():
+        pytest.skip("not built yet")
+    out = tmp_path / "x.inc"
+    subprocess.check_call([sys.executable, str(ROOT / "tools" / "gen_lutopt_kernel.py"),
+                           str(ROOT / "basebandboard_amd" / "data" / "lutopt_256.txt"), str(out)])
+    assert out.read_text() == cur.read_text()
+
+
+def test_transpose32_and_gen_index(tmp_path):
+    lib = build(tmp_path, 32)
+    rng = np.random.default_rng(3)
+    q = rng.integers(0, 2**32, size=32, dtype=np.uint64).astype(np.uint32)
+    orig = q.copy()
+    lib.t32(q.ctypes.data_as(C.POINTER(C.c_uint32)))
+    for i in range(32):
+        for j in range(32):
+            assert (int(q[i]) >> j) & 1 == (int(orig[j]) >> i) & 1
+    lib.gidx.restype = C.c_ulonglong
+    lib.gidx.argtypes = [C.c_ulonglong, C.c_uint, C.c_uint]
+    seen = {lib.gidx(w, l, j) for w in range(3) for l in range(64) for j in range(32)}
+    assert seen == set(range(3 * 2048))
+    assert lib.gidx(2, 5, 7) == (2 * 32 + 7) * 64 + 5

@@ -1,0 +1,152 @@
+"""LUTOPT + CLTGRNG kernels vs the oracle and the golden vectors (through the C ABI).  Bit exact."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def ref_stream(oracle, n, init, first, count, fast=True):
+    m = oracle.Lutopt(path=oracle.data_path(n))
+    return m.awgn(init, first, count, fast=fast and n == 256)
+
+
+def test_n256_golden_prefix(gpu, golden_lutopt):
+    """First 4096 samples from init=1 equal the reference's embedded models (rng.py:134-135,173-181)."""
+    u = gpu.LUTOPT.shipped(256)
+    assert u.specialised
+    g = gpu.CLTGRNG(u)
+    got = g.generate(4096).cpu().numpy()
+    assert got.tolist() == golden_lutopt["256"]["clt_out"]
+    assert u.state_at(1) == int(golden_lutopt["256"]["states_hex"][0], 16)
+    assert u.state_at(4096) == int(golden_lutopt["256"]["state_last_hex"], 16)
+
+
+def test_n256_second_seed(gpu, golden_lutopt):
+    g2 = golden_lutopt["256_seed2"]
+    u = gpu.LUTOPT.shipped(256, init=int(g2["init"], 16))
+    got = gpu.CLTGRNG(u).generate(512).cpu().numpy()
+    assert got.tolist() == g2["clt_out"]
+    assert u.state_at(512) == int(g2["state_last_hex"], 16)
+
+
+@pytest.mark.parametrize("nsamples,first", [(1, 0), (15, 0), (16, 7), (17, 0), (63, 0), (64, 16), (65, 16),
+                                            (4097, 3), (131072, 16), (1_000_003, 16), (3_000_000, 1_234_567)])
+def test_n256_matches_oracle(gpu, oracle, nsamples, first):
+    u = gpu.LUTOPT.shipped(256)
+    got = gpu.CLTGRNG(u).generate(nsamples, first_step=first).cpu().numpy()
+    exp = ref_stream(oracle, 256, 1, first, nsamples)
+    assert np.array_equal(got, exp)
+
+
+def test_n256_far_offset(gpu, oracle):
+    """first_step far beyond what the sequential oracle can reach: jump-ahead composes
+    (state_at(a + b) from a handle seeded with state_at(a)), and the stream from there matches
+    the oracle started at that state."""
+    u = gpu.LUTOPT.shipped(256)
+    far = 10**15 + 12345
+    s_far = u.state_at(far)
+    assert gpu.LUTOPT.shipped(256, init=u.state_at(10**15)).state_at(12345) == s_far
+    m = oracle.Lutopt(path=oracle.data_path(256))
+    assert m.run_int(u.state_at(10**15 + 12000), 345) == s_far
+    got = gpu.CLTGRNG(u).generate(500_000, first_step=far).cpu().numpy()
+    assert np.array_equal(got, m.awgn(s_far, 0, 500_000, fast=True))
+
+
+def test_n256_large_seams_and_checksum(gpu, oracle):
+    """2^28 samples: every generator segment start (seam) and a strided sample of whole segments
+    are compared with the sequential oracle; plus determinism (same call twice, identical bytes)."""
+    n = 1 << 28
+    u = gpu.LUTOPT.shipped(256)
+    g = gpu.CLTGRNG(u)
+    a = g.generate(n, first_step=16)
+    b = g.generate(n, first_step=16).clone()
+    assert torch.equal(a, b)
+    m = oracle.Lutopt(path=oracle.data_path(256))
+    a_np = a.cpu().numpy()
+    head = m.awgn(1, 16, 200_000, fast=True)
+    assert np.array_equal(a_np[:200_000], head)
+    rng = np.random.default_rng(0)
+    for off in list(rng.integers(0, n - 5000, size=40)) + [n - 5000]:
+        exp = m.awgn(u.state_at(16 + int(off)), 0, 5000, fast=True)
+        assert np.array_equal(a_np[off: off + 5000], exp), off
+    # moments of the CLT output (rng.py:63-65 / clt-grng-evaluate.py:18-31): mean 0, variance 64
+    x = a_np[: 1 << 24].astype(np.float64)
+    assert abs(x.mean()) < 0.02 and abs(x.var() - 64.0) < 0.2
+
+
+@pytest.mark.parametrize("n", (16, 32, 64, 128))
+def test_small_matrices_match_golden_and_oracle(gpu, oracle, golden_lutopt, n):
+    """The reference's own test matrices (n16 in test_lutopt, n32 in test_cltgrng) on the GPU's
+    table-driven kernel."""
+    u = gpu.LUTOPT.shipped(n)
+    assert not u.specialised
+    g = gpu.CLTGRNG(u)
+    gold = golden_lutopt[str(n)]
+    got = g.generate(256).cpu().numpy()
+    assert got.tolist() == gold["clt_out"]
+    for i, h in enumerate(gold["states_hex"][:16]):
+        assert u.state_at(i + 1) == int(h, 16)
+    got = g.generate(70_001, first_step=2 * int(np.log2(n))).cpu().numpy()
+    exp = ref_stream(oracle, n, 1, 2 * int(np.log2(n)), 70_001)
+    assert np.array_equal(got, exp)
+
+
+def test_n512_int16(gpu, oracle):
+    u = gpu.LUTOPT.shipped(512)
+    g = gpu.CLTGRNG(u)
+    assert g.dtype == torch.int16
+    got = g.generate(20_000, first_step=18).cpu().numpy()
+    m = oracle.Lutopt(path=oracle.data_path(512))
+    x = u.state_at(18)
+    exp = []
+    for _ in range(300):
+        x = m.step_int(x)
+        exp.append(m.clt_wrap(m.clt_tree(x)))
+    assert got[:300].tolist() == exp
+
+
+def test_n256_generic_path_equals_specialised(gpu, oracle):
+    """A row-permuted copy of n256 is a different matrix (table-driven kernel); the shipped one
+    hits the straight-line kernel.  Both must agree with the oracle on their own matrix."""
+    packed = gpu.recurrences.n256
+    perm = packed[1:] + packed[:1]
+    u = gpu.LUTOPT.from_packed(perm, init=12345)
+    assert not u.specialised
+    got = gpu.CLTGRNG(u).generate(50_000, first_step=3).cpu().numpy()
+    m = oracle.Lutopt(packed=perm)
+    assert np.array_equal(got, m.awgn(12345, 3, 50_000))
+
+
+def test_lutopt_from_matrix_and_errors(gpu):
+    a = gpu.LUTOPT.shipped(16).a
+    u = gpu.LUTOPT(a, init=1)
+    assert u.packed == gpu.recurrences.n16
+    with pytest.raises(ValueError):
+        gpu.LUTOPT.from_packed([[0]] * 24)          # k not a power of two
+    with pytest.raises(ValueError):
+        gpu.LUTOPT.from_packed([[99]] * 16)         # tap out of range
+    with pytest.raises(ValueError):
+        gpu.LUTOPT.from_packed(gpu.recurrences.n16, init=1 << 16)
+
+
+def test_extreme_state_wraps_to_minus_128(gpu, golden_lutopt):
+    """Bits set exactly on the +1 positions: tree value +128, 8-bit signed output -128 (rng.py:78)."""
+    ex = golden_lutopt["256_extreme"]
+    x = int(ex["x_hex"], 16)
+    words = np.array([[(x >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]], dtype=np.uint64).view(np.int64)
+    t = gpu.CLTGRNG.tree(torch.from_numpy(words).cuda(), 256).cpu().numpy()
+    assert t[0] == ex["clt_tree"] == 128
+
+
+def test_clt_tree_random_words(gpu, oracle):
+    """software/clt-grng/clt-grng-evaluate.py's experiment: tree of random 256-bit words; compare
+    each value with the literal tree and the moments with theory (sigma^2 = 64)."""
+    rng = np.random.default_rng(7)
+    w = rng.integers(0, 2**63, size=(100_000, 4), dtype=np.int64) | (rng.integers(0, 2, size=(100_000, 4)).astype(np.int64) << 63)
+    t = gpu.CLTGRNG.tree(torch.from_numpy(w).cuda(), 256).cpu().numpy()
+    m = oracle.Lutopt(path=oracle.data_path(256))
+    for i in range(0, 100_000, 997):
+        x = sum(int(np.uint64(w[i, q])) << (64 * q) for q in range(4))
+        assert t[i] == m.clt_tree(x) == m.clt_popcount(x)
+    assert abs(t.mean()) < 0.1 and abs(t.astype(np.float64).var() - 64.0) < 1.0

@@ -1,0 +1,105 @@
+"""PRBS kernels vs the oracle and the golden vectors (through the C ABI).  Bit exact."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+KS = (7, 9, 11, 15, 20, 23, 31)
+
+
+def unpack(words_i64, nbits):
+    w = words_i64.cpu().numpy().view(np.uint64)
+    bits = np.unpackbits(w.view(np.uint8), bitorder="little")
+    return bits[:nbits]
+
+
+@pytest.mark.parametrize("k", KS)
+def test_prbs_golden_prefix(gpu, golden_prbs, k):
+    """First 4096 bits from state 1 equal the reference model's (prbs.py:112-113)."""
+    got = unpack(gpu.PRBS(k).generate(4096), 4096)
+    assert "".join(map(str, got)) == golden_prbs[str(k)]["bits"]
+    g2 = golden_prbs[f"{k}_seed2"]
+    got = unpack(gpu.PRBS(k, init=g2["init"]).generate(1024), 1024)
+    assert "".join(map(str, got)) == g2["bits"]
+
+
+@pytest.mark.parametrize("k", KS)
+@pytest.mark.parametrize("nbits,first", [(1, 0), (63, 0), (64, 5), (65, 0), (8191, 3), (8193, 0),
+                                         (1_000_003, 0), (300_000, 123_456_789), (5_000_000, 2**40 + 17)])
+def test_prbs_fill_matches_oracle(gpu, oracle, k, nbits, first):
+    p = gpu.PRBS(k)
+    got = p.generate(nbits, first_bit=first).cpu().numpy().view(np.uint64)
+    s0 = p.state_at(first)
+    exp, s_end = oracle.prbs_packed(k, nbits, state=s0, fast=True)
+    assert np.array_equal(got, exp)
+    assert p.state_at(first + nbits) == s_end
+
+
+@pytest.mark.parametrize("k", (7, 20, 31))
+def test_prbs_state_at_small(gpu, oracle, k):
+    p = gpu.PRBS(k)
+    for n in (0, 1, 2, 63, 64, 1000):
+        _, s = oracle.prbs_bits(k, n)
+        assert p.state_at(n) == s
+
+
+@pytest.mark.parametrize("k", KS)
+def test_prbs_loopback_and_injected_errors(gpu, k):
+    """Generator -> checker: 0 errors clean; an XOR mask of known weight is counted exactly."""
+    nbits = 20_000_003
+    p = gpu.PRBS(k)
+    det = gpu.PRBSErrorDetector(k)
+    buf = p.generate(nbits, first_bit=77)
+    assert det.count_errors(buf, nbits, first_bit=77) == 0
+    rng = np.random.default_rng(k)
+    pos = np.unique(rng.integers(0, nbits, size=5000))
+    mask = np.zeros(buf.numel(), dtype=np.uint64)
+    np.bitwise_xor.at(mask, pos // 64, np.uint64(1) << (pos % 64).astype(np.uint64))
+    buf ^= torch.from_numpy(mask.view(np.int64)).to(buf.device)
+    assert det.count_errors(buf, nbits, first_bit=77) == len(pos)
+    # garbage above nbits in the last word must be ignored
+    buf2 = p.generate(1000)
+    buf2[-1] |= torch.tensor(-1 << (1000 % 64), dtype=torch.int64, device=buf2.device)
+    assert det.count_errors(buf2, 1000) == 0
+
+
+def test_prbs_invalid_k(gpu):
+    for k in (0, 8, 10, 32, 63):
+        with pytest.raises(ValueError, match="invalid for PRBS"):
+            gpu.PRBS(k)
+        with pytest.raises(ValueError, match="invalid for PRBS"):
+            gpu.PRBSErrorDetector(k)
+
+
+def test_prbs_empty(gpu):
+    assert gpu.PRBS(31).generate(0).numel() == 0
+
+
+@pytest.mark.parametrize("k", KS)
+def test_prbs_detector_fsm_matches_oracle(gpu, oracle, k):
+    """Cycle-exact FSM, many independent streams at once, random error patterns incl. bursts."""
+    rng = np.random.default_rng(100 + k)
+    nstreams, n = 300, 700
+    tx, _ = oracle.prbs_bits(k, n)
+    bits = np.tile(tx, (nstreams, 1))
+    errs = (rng.random((nstreams, n)) < 0.03).astype(np.uint8)
+    errs[:, : 2 * k] = 0
+    errs[::3, n // 2: n // 2 + 3 * k] = 1
+    bits ^= errs
+    bits[5] = rng.integers(0, 2, n)            # pure noise stream: reload logic exercised hard
+    e, r = gpu.PRBSErrorDetector(k).run(torch.from_numpy(bits).cuda())
+    e, r = e.cpu().numpy(), r.cpu().numpy()
+    for s in range(0, nstreams, 7):
+        eo, ro = oracle.prbs_detector_run(k, bits[s])
+        assert np.array_equal(e[s], eo) and np.array_equal(r[s], ro), s
+
+
+@pytest.mark.parametrize("k", KS)
+@pytest.mark.parametrize("seed", range(4))
+def test_prbs_detector_reference_protocol(gpu, oracle, k, seed):
+    """The reference's own test design (prbs.py:124-163), see tests/detector_protocol.py."""
+    from detector_protocol import make_case, check_case
+    wire, tx_errors = make_case(k, lambda kk, n: oracle.prbs_bits(kk, n)[0], seed)
+    e, r = gpu.PRBSErrorDetector(k).run(torch.from_numpy(wire[None, :]).cuda())
+    check_case(tx_errors, e[0].cpu().numpy(), r[0].cpu().numpy())

@@ -1,0 +1,177 @@
+"""The CPU oracle (oracle/bbb_oracle.c) against the golden vectors derived from the reference's
+embedded models, plus internal consistency (literal tree == closed form, fast == literal)."""
+import numpy as np
+import pytest
+
+KS = (7, 9, 11, 15, 20, 23, 31)
+
+
+@pytest.mark.parametrize("n", (16, 32, 64, 128, 256))
+def test_lutopt_states_and_clt_golden(oracle, golden_lutopt, n):
+    g = golden_lutopt[str(n)]
+    m = oracle.Lutopt(path=oracle.data_path(n))
+    x = 1
+    for h in g["states_hex"]:
+        x = m.step_int(x)
+        assert x == int(h, 16)
+    assert m.run_int(1, len(g["clt_tree"])) == int(g["state_last_hex"], 16)
+    x = 1
+    for tree, outv in zip(g["clt_tree"], g["clt_out"]):
+        x = m.step_int(x)
+        assert m.clt_tree(x) == tree == m.clt_popcount(x)
+        assert m.clt_wrap(tree) == outv
+
+
+def test_survey_appendix_b_pins(oracle):
+    """Literal values quoted in SURVEY.md Appendix B (independently generated there)."""
+    m = oracle.Lutopt(path=oracle.data_path(16))
+    assert [hex(m.run_int(1, t)) for t in (1, 2, 3, 4)] == ["0x2124", "0xbf2a", "0x6474", "0x9ddf"]
+    m = oracle.Lutopt(path=oracle.data_path(32))
+    assert [hex(m.run_int(1, t)) for t in (1, 2, 3, 4)] == ["0x24080", "0x40105234", "0xe64686f3", "0x88264e3a"]
+    m = oracle.Lutopt(path=oracle.data_path(256))
+    assert m.awgn(1, 0, 12).tolist() == [-4, -6, 0, 1, 2, -4, -3, 1, -1, -7, -7, 5]
+    assert [bin(m.run_int(1, t)).count("1") for t in range(1, 8)] == [4, 14, 44, 87, 120, 116, 121]
+
+
+def test_awgn_stream_golden_and_fast_path(oracle, golden_lutopt):
+    m = oracle.Lutopt(path=oracle.data_path(256))
+    gold = np.array(golden_lutopt["256"]["clt_out"], dtype=np.int8)
+    assert np.array_equal(m.awgn(1, 0, len(gold)), gold)
+    assert np.array_equal(m.awgn(1, 0, len(gold), fast=True), gold)
+    assert np.array_equal(m.awgn(1, 100, 3000), gold[100:3100])
+    g2 = golden_lutopt["256_seed2"]
+    assert m.awgn(int(g2["init"], 16), 0, 512, fast=True).tolist() == g2["clt_out"]
+    a = m.awgn(0xFEEDFACE, 5, 50_000)
+    assert np.array_equal(a, m.awgn(0xFEEDFACE, 5, 50_000, fast=True))
+
+
+def test_clt_extreme_wraps(oracle, golden_lutopt):
+    ex = golden_lutopt["256_extreme"]
+    m = oracle.Lutopt(path=oracle.data_path(256))
+    x = int(ex["x_hex"], 16)
+    assert m.clt_tree(x) == 128 and m.clt_wrap(128) == -128 == ex["clt_out"]
+    assert m.clt_tree((1 << 256) - 1 - x) == -128 and m.clt_wrap(-128) == -128
+    assert m.clt_tree(0) == 0 == m.clt_tree((1 << 256) - 1)
+
+
+def test_python_restatement_agrees(oracle):
+    """A second, independent (pure Python) restatement of rng.py:38-40 / clt-grng-evaluate.py:10-15."""
+    for n in (16, 32, 256):
+        m = oracle.Lutopt(path=oracle.data_path(n))
+        x = 0x1234567 & ((1 << n) - 1) | 1
+        for _ in range(20):
+            y = oracle.py_lutopt_step(m.packed, x)
+            assert y == m.step_int(x)
+            assert oracle.py_clt_tree(y, n) == m.clt_tree(y)
+            x = y
+
+
+def test_reference_inline_test_matrices(oracle):
+    """The literal matrices inside the reference's tests equal the shipped n16 / n32
+    (gateware/bbb/rng.py:114-119 and :144-155), quoted here as data."""
+    t16 = [[8, 11, 12, 13], [2, 6, 14], [0, 3, 4, 7], [1, 5, 9, 15], [5, 10, 13], [0, 2, 3, 6], [10, 12, 15],
+           [4, 7, 9, 11], [0, 1, 8, 14], [5, 9, 10, 12], [1, 7, 13, 15], [2, 4, 14], [3, 6, 8], [0, 8, 11, 15],
+           [6, 10, 11, 12], [2, 5, 7, 13]]
+    assert oracle.Lutopt(path=oracle.data_path(16)).packed == t16
+
+
+@pytest.mark.parametrize("k", KS)
+def test_prbs_golden(oracle, golden_prbs, k):
+    g = golden_prbs[str(k)]
+    bits, s = oracle.prbs_bits(k, 4096)
+    assert "".join(map(str, bits)) == g["bits"] and s == g["state_after"]
+    g2 = golden_prbs[f"{k}_seed2"]
+    bits, s = oracle.prbs_bits(k, 1024, state=g2["init"])
+    assert "".join(map(str, bits)) == g2["bits"] and s == g2["state_after"]
+    pb, ps = oracle.py_prbs(k, 300)
+    assert pb == list(bits[:0]) + [int(c) for c in g["bits"][:300]]
+
+
+def test_prbs_matches_rnghunt_strings(oracle, golden_prbs):
+    """The PRBS-9 / PRBS-11 strings in software/rnghunt/src/berlekamp_massey.rs:40,45 are the first
+    bits of gateware PRBS(9) / PRBS(11) from state 1."""
+    b9, _ = oracle.prbs_bits(9, 19)
+    b11, _ = oracle.prbs_bits(11, 23)
+    assert "".join(map(str, b9)) == golden_prbs["rnghunt_bm_prbs9"]
+    assert "".join(map(str, b11)) == golden_prbs["rnghunt_bm_prbs11"]
+
+
+@pytest.mark.parametrize("k", KS)
+def test_prbs_packed_variants(oracle, k):
+    for nbits, st in ((1, 1), (64, 1), (65, 3), (1000, 1), (70_001, (1 << k) - 1)):
+        w, s1 = oracle.prbs_packed(k, nbits, state=st)
+        wf, s2 = oracle.prbs_packed(k, nbits, state=st, fast=True)
+        bits, s3 = oracle.prbs_bits(k, nbits, state=st)
+        assert np.array_equal(w, wf) and s1 == s2 == s3
+        assert np.array_equal(np.unpackbits(w.view(np.uint8), bitorder="little")[:nbits], bits)
+        assert oracle.prbs_check_packed(k, w, nbits, state=st) == 0
+    w, _ = oracle.prbs_packed(k, 5000)
+    w[3] ^= np.uint64(0b1011)
+    w[70] ^= np.uint64(1) << np.uint64(63)
+    assert oracle.prbs_check_packed(k, w, 5000) == 4
+    # maximal length: period 2^k - 1 for the small ones
+    if k <= 15:
+        bits, s = oracle.prbs_bits(k, (1 << k) - 1)
+        assert s == 1 and bits.sum() == 1 << (k - 1)
+
+
+def test_prbs_invalid_k(oracle):
+    for k in (0, 8, 32):
+        with pytest.raises(ValueError, match="invalid for PRBS"):
+            oracle.prbs_bits(k, 10)
+        with pytest.raises(ValueError, match="invalid for PRBS"):
+            oracle.prbs_detector_run(k, np.zeros(4, dtype=np.uint8))
+
+
+@pytest.mark.parametrize("k", KS)
+@pytest.mark.parametrize("seed", range(6))
+def test_detector_reference_protocol(oracle, k, seed):
+    from detector_protocol import make_case, check_case
+    wire, tx_errors = make_case(k, lambda kk, n: oracle.prbs_bits(kk, n)[0], seed)
+    e, r = oracle.prbs_detector_run(k, wire)
+    check_case(tx_errors, e, r)
+
+
+@pytest.mark.parametrize("k", KS)
+def test_detector_structure(oracle, k):
+    """Facts that follow from prbs.py:80,91-97: the all-ones reset of err_sr arms a reload on the
+    very first clock; a clean stream is in lock (err == 0, reload == 0) from some clock on."""
+    tx, _ = oracle.prbs_bits(k, 6 * k + 100)
+    e, r = oracle.prbs_detector_run(k, tx)
+    assert r[0] == 1
+    lock = int(np.max(np.nonzero(r)[0])) + 1
+    assert lock <= 4 * k
+    assert not e[lock + 1:].any() and not r[lock:].any()
+
+
+def test_rnghunt_recur_kat(oracle, golden_gf2):
+    g = golden_gf2["test_recur"]
+    out = oracle.rnghunt_recur(g["nrows"], g["ncols"], [int(w, 16) for w in g["col_words_hex"]], g["x_bits"], g["n"])
+    assert out.tolist() == g["out_bits"]
+
+
+def test_txrx_decide_semantics(oracle):
+    """tx.py:75-81 / rx.py:29 in the no-wrap regime: decision = sign of (+-amp + nv * g)."""
+    for g in (-128, -17, -1, 0, 1, 30, 127):
+        for bit in (0, 1):
+            for amp, nv in ((0, 1), (100, 8), (254, 15), (10, 0)):
+                x = (amp if bit else -amp) + g * nv
+                if -2048 <= x < 2048:
+                    assert oracle.txrx_decide(g, bit, amp, nv) == int(x >= 0)
+                else:                                   # 12-bit register wraps (tx.py:80)
+                    assert oracle.txrx_decide(g, bit, amp, nv) == int(((x + 2048) % 4096) - 2048 >= 0)
+    # 12-bit wrap: 2047 + 127*15 = 3952 -> wraps negative
+    assert oracle.txrx_decide(127, 1, 2047, 15) == 0
+
+
+def test_ber_trial_additive_and_sane(oracle):
+    m = oracle.Lutopt(path=oracle.data_path(256))
+    whole = m.ber_trial(1, 31, 1, 100, 8, 16, 0, 60_000)
+    a = m.ber_trial(1, 31, 1, 100, 8, 16, 0, 25_000)
+    b = m.ber_trial(1, 31, 1, 100, 8, 16, 25_000, 35_000)
+    assert whole[0] == 60_000 and whole[1] == a[1] + b[1]
+    from math import erfc, sqrt
+    ber = whole[1] / whole[0]
+    theory = 0.5 * erfc(sqrt(100 ** 2 / (2 * 64.0 ** 2)))
+    assert abs(ber / theory - 1) < 0.15
+    assert m.ber_trial(1, 31, 1, 2000, 0, 16, 0, 1000)[1] == 0      # no noise, no errors

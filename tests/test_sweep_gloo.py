@@ -1,0 +1,73 @@
+"""The multi-rank sweep (basebandboard_amd.channel.sweep) on CPU: two `gloo` ranks shard the trial
+list round-robin, each runs its share, ONE all-reduce sums the 64-bit counters; the result must
+equal the single-rank counters exactly.  The per-trial compute is injected (the oracle here: this
+file is a test; on GPU ranks it is the HIP kernel via gpu_runner)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _trials():
+    from basebandboard_amd import Trial
+    return [Trial(nbits=3000 + 500 * i, amp=60 + 20 * i, noise_var=8, prbs_k=(7, 9, 31)[i % 3], first_bit=100 * i)
+            for i in range(7)]
+
+
+def _oracle_runner():
+    import sys
+    sys.path.insert(0, str(ROOT))
+    import oracle as O
+    m = O.Lutopt(path=O.data_path(256))
+
+    def run(local_trials, n):
+        out = torch.zeros((n, 2), dtype=torch.int64)
+        for i, t in enumerate(local_trials):
+            b, e = m.ber_trial(1, t.prbs_k, t.prbs_state, t.amp, t.noise_var, t.warmup, t.first_bit, t.nbits)
+            out[i, 0], out[i, 1] = b, e
+        return out
+    return run
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from basebandboard_amd import sweep
+    total = sweep(_trials(), _oracle_runner(), rank=rank, world=world)
+    q.put((rank, total.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sweep_equals_single_rank():
+    from basebandboard_amd import sweep
+    single = sweep(_trials(), _oracle_runner(), rank=0, world=1).tolist()
+    assert all(b > 0 for b, _ in single)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0] == got[1] == single
+
+
+def test_shard_is_a_partition():
+    from basebandboard_amd import shard
+    for n in (0, 1, 7, 88):
+        for world in (1, 2, 8):
+            parts = [shard(n, r, world) for r in range(world)]
+            assert sorted(i for p in parts for i in p) == list(range(n))
+            assert max(map(len, parts)) - min(map(len, parts)) <= 1
