@@ -29,64 +29,93 @@
 namespace bbb {
 
 // ---------------------------------------------------------------------------------------------
-// Start states by doubling.  cols holds, per level d, the COLUMNS of B_d = A^(L*2^d):
-// cols[(d*k + c)*W32 + w]; y = B x is the XOR of the columns c with x[c] = 1.
+// Start states by doubling: level d maps the first 2^d states through B_d = (A^L)^(2^d),
+//     S[2^d + i] = B_d * S[i].
+// y = B x is evaluated four state bits at a time: tabs holds, per level and per nibble position n,
+// the 16 XOR-combinations of columns 4n..4n+3 of B_d ([level][k/4][16][W32] words, built on the
+// host).  A block stages its level's table in LDS (32 KiB for k = 256) and every lane does k/4
+// lookups of W32 words.  States are stored word-major, S[w * stride + g], so that both this kernel
+// and the bit-slicing pass touch consecutive addresses from consecutive lanes.
 // ---------------------------------------------------------------------------------------------
 struct State16 { uint32_t w[16]; };
 
-template <int W32>
-__device__ __forceinline__ void gf2_colmul(const uint32_t *__restrict cols, int k, const uint32_t (&x)[W32],
-                                           uint32_t (&y)[W32]) {
-#pragma unroll
-    for (int w = 0; w < W32; w++) y[w] = 0;
-#pragma unroll
-    for (int cw = 0; cw < W32; cw++) {
-        const uint32_t xw = x[cw];
-        if (cw * 32 >= k) break;
-#pragma unroll 8
-        for (int cb = 0; cb < 32; cb++) {
-            const uint32_t m = (uint32_t)(-(int32_t)((xw >> cb) & 1u));
-            const uint32_t *col = cols + (size_t)(cw * 32 + cb) * W32;   // wave-uniform address
-#pragma unroll
-            for (int w = 0; w < W32; w++) y[w] ^= col[w] & m;
-        }
-    }
-}
-
-// One launch covers levels [d0, d1).  For d1 - d0 > 1 it must be a single block (block-level
-// barriers order the levels); the host uses that for the first, tiny levels.
+// Table layout: a nibble entry of W32 words is cut into chunks of C = min(W32, 4) words (one
+// ds_read_b128 each for C = 4); chunk zc of all 16 entries of nibble n is contiguous:
+//   index(n, v, zc, zz) = ((n * (W32/C) + zc) * 16 + v) * C + zz
+// so the 16 possible 16-byte reads of one (n, zc) cover 256 consecutive bytes = every LDS bank
+// once: lanes reading different entries never conflict, lanes reading the same entry broadcast.
 template <int W32>
 __global__ void __launch_bounds__(256)
-seed_levels_kernel(const uint32_t *__restrict cols, int k, State16 s0, int d0, int d1, unsigned long long G,
-                   uint32_t *__restrict S) {
+seed_levels_kernel(const uint32_t *__restrict tabs, int k, State16 s0, int d0, int d1, unsigned long long G,
+                   unsigned long long stride, uint32_t *__restrict S) {
+    constexpr int C = W32 < 4 ? W32 : 4;
+    constexpr int NC = W32 / C;
+    typedef uint32_t chunk_t __attribute__((ext_vector_type(C)));
+    extern __shared__ __attribute__((aligned(16))) uint32_t tab[];
     const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nnib = (k + 3) / 4;
+    const int nt = nnib * 16 * W32;            // words; a multiple of 4 for every supported k
     if (d0 == 0 && tid == 0) {
 #pragma unroll
-        for (int w = 0; w < W32; w++) S[w] = s0.w[w];
+        for (int w = 0; w < W32; w++) S[w * stride] = s0.w[w];
     }
-    if (d0 == 0) __syncthreads();
     for (int d = d0; d < d1; d++) {
+        __syncthreads();
+        {   // stage this level's table: 16-byte loads, eight in flight per lane
+            typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+            const u4 *src = reinterpret_cast<const u4 *>(tabs + (size_t)d * nt);
+            u4 *dst = reinterpret_cast<u4 *>(tab);
+            const int n4 = nt / 4;
+            for (int base = 0; base < n4; base += 8 * 256) {
+                u4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int i = base + u * 256 + (int)threadIdx.x;
+                    if (i < n4) v[u] = src[i];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int i = base + u * 256 + (int)threadIdx.x;
+                    if (i < n4) dst[i] = v[u];
+                }
+            }
+        }
+        __syncthreads();
         const unsigned long long lo = 1ull << d;
         if (tid < lo && lo + tid < G) {
-            uint32_t x[W32], y[W32];
+            uint32_t x[W32];
+            chunk_t y[NC];
 #pragma unroll
-            for (int w = 0; w < W32; w++) x[w] = S[tid * W32 + w];
-            gf2_colmul<W32>(cols + (size_t)d * k * W32, k, x, y);
+            for (int w = 0; w < W32; w++) x[w] = S[w * stride + tid];
 #pragma unroll
-            for (int w = 0; w < W32; w++) S[(lo + tid) * W32 + w] = y[w];
+            for (int zc = 0; zc < NC; zc++) y[zc] = (chunk_t)(0);
+#pragma unroll
+            for (int w = 0; w < W32; w++) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int n = w * 8 + q;
+                    if (n < nnib) {
+                        const uint32_t v = (x[w] >> (4 * q)) & 15u;
+#pragma unroll
+                        for (int zc = 0; zc < NC; zc++)
+                            y[zc] ^= *reinterpret_cast<const chunk_t *>(tab + ((n * NC + zc) * 16 + v) * C);
+                    }
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < W32; w++) S[w * stride + lo + tid] = y[w / C][w % C];
         }
-        if (d + 1 < d1) __syncthreads();
     }
 }
 
-// [G][W32] packed states -> bit planes.  Thread (LG, wq) gathers word wq of the 32 generators of
+// Word-major packed states -> bit planes.  Thread (LG, wq) gathers word wq of the 32 generators of
 // lane LG and transposes: planes[(32*wq + p) * nlanes + LG] bit j = state bit 32*wq+p of g(LG, j).
 template <int W32>
 __global__ void __launch_bounds__(256)
-bitslice_kernel(const uint32_t *__restrict S, unsigned long long G, unsigned nlanes, int k,
+bitslice_kernel(const uint32_t *__restrict S, unsigned long long G, unsigned long long stride, unsigned nlanes, int k,
                 uint32_t *__restrict planes) {
     const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned long long LG = t % nlanes;       // consecutive threads -> consecutive lanes (coalesced stores)
+    const unsigned long long LG = t % nlanes;       // consecutive threads -> consecutive lanes
     const unsigned wq = (unsigned)(t / nlanes);
     if (wq * 32 >= (unsigned)k) return;
     const unsigned long long wave = LG >> 6;
@@ -95,7 +124,7 @@ bitslice_kernel(const uint32_t *__restrict S, unsigned long long G, unsigned nla
 #pragma unroll
     for (int j = 0; j < 32; j++) {
         const unsigned long long g = gen_index(wave, lane, j);
-        q[j] = g < G ? S[g * W32 + wq] : 0u;
+        q[j] = g < G ? S[wq * stride + g] : 0u;
     }
     transpose32(q);
 #pragma unroll
@@ -108,10 +137,11 @@ bitslice_kernel(const uint32_t *__restrict S, unsigned long long G, unsigned nla
 // update's temporaries need the whole 512-register file).
 //
 // Per round of 16 steps a lane leaves 16 bytes for each of its 32 generators:
-//   step t   -> 8 count planes cnt[b] (bit j = bit b of generator j's sample) -> LDS P[t][b][lane]
-//   round end-> for w = 0..3: Q[8*tt+b] = P[4w+tt][b]; transpose32(Q): Q[j] = the 4 sample
-//               bytes of generator j for steps 4w..4w+3; staged back to LDS, re-read as 16 B
-//               per generator and stored with one global_store_dwordx4.
+//   step t    -> 8 count planes -> planes8_to_bytes (12 shift/BFI butterflies): word i byte q is
+//                the sample of generator 8q+i -> LDS Z[t][i][lane]
+//   round end -> for i = 0..7: the 16 words Z[0..15][i]; four 4x4 byte transposes (V_PERM_B32)
+//                give, per q, the 16 consecutive sample bytes of generator 8q+i -> one
+//                global_store_dwordx4 each.
 // All LDS traffic is lane-private (dword index = row*64 + lane: conflict-free, no barriers).
 // ---------------------------------------------------------------------------------------------
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -119,7 +149,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 awgn256_kernel(const uint32_t *__restrict planes, int8_t *__restrict dst, unsigned long long nsamples,
                unsigned L, unsigned long long G, unsigned nlanes) {
-    __shared__ uint32_t P[16 * 8 * 64];
+    __shared__ uint32_t Z[16 * 8 * 64];
     const unsigned lane = threadIdx.x;
     const unsigned long long wave = blockIdx.x;
     const unsigned long long LG = wave * 64 + lane;
@@ -134,36 +164,38 @@ awgn256_kernel(const uint32_t *__restrict planes, int8_t *__restrict dst, unsign
 #pragma unroll 1
         for (unsigned tt = 0; tt < 8; tt++) {
             lutopt256_step(a, b, cnt);
+            planes8_to_bytes(cnt);
 #pragma unroll
-            for (int q = 0; q < 8; q++) P[((2 * tt) * 8 + q) * 64 + lane] = cnt[q];
+            for (int i = 0; i < 8; i++) Z[((2 * tt) * 8 + i) * 64 + lane] = cnt[i];
             lutopt256_step(b, a, cnt);
+            planes8_to_bytes(cnt);
 #pragma unroll
-            for (int q = 0; q < 8; q++) P[((2 * tt + 1) * 8 + q) * 64 + lane] = cnt[q];
+            for (int i = 0; i < 8; i++) Z[((2 * tt + 1) * 8 + i) * 64 + lane] = cnt[i];
         }
 #pragma unroll 1
-        for (unsigned w = 0; w < 4; w++) {
-            uint32_t q[32];
+        for (unsigned i = 0; i < 8; i++) {
+            uint32_t o[4][4];                 // o[w][q] after the transposes
 #pragma unroll
-            for (int i = 0; i < 32; i++) q[i] = P[(w * 32 + i) * 64 + lane];
-            transpose32(q);
+            for (int w = 0; w < 4; w++) {
+                uint32_t z[4];
 #pragma unroll
-            for (int j = 0; j < 32; j++) P[(w * 32 + j) * 64 + lane] = q[j];
-        }
-#pragma unroll 4
-        for (unsigned j = 0; j < 32; j++) {
-            const unsigned long long g = gen_index(wave, lane, j);
-            const unsigned long long off = g * L + (unsigned long long)r * 16;
-            if (g < G && off < nsamples) {
-                u32x4 v;
-                v.x = P[(0 * 32 + j) * 64 + lane];
-                v.y = P[(1 * 32 + j) * 64 + lane];
-                v.z = P[(2 * 32 + j) * 64 + lane];
-                v.w = P[(3 * 32 + j) * 64 + lane];
-                if (off + 16 <= nsamples) {
-                    *reinterpret_cast<u32x4 *>(dst + off) = v;
-                } else {
-                    const unsigned n = (unsigned)(nsamples - off);
-                    for (unsigned e = 0; e < n; e++) dst[off + e] = (int8_t)((v[e >> 2] >> (8 * (e & 3))) & 0xff);
+                for (int t = 0; t < 4; t++) z[t] = Z[((4 * w + t) * 8 + i) * 64 + lane];
+                transpose4x4_bytes(z);        // z[q] = bytes (t = 4w..4w+3) of generator 8q+i
+#pragma unroll
+                for (int q = 0; q < 4; q++) o[w][q] = z[q];
+            }
+#pragma unroll
+            for (unsigned q = 0; q < 4; q++) {
+                const unsigned long long g = gen_index(wave, lane, 8 * q + i);
+                const unsigned long long off = g * L + (unsigned long long)r * 16;
+                if (g < G && off < nsamples) {
+                    const u32x4 v = {o[0][q], o[1][q], o[2][q], o[3][q]};
+                    if (off + 16 <= nsamples) {
+                        *reinterpret_cast<u32x4 *>(dst + off) = v;
+                    } else {
+                        const unsigned n = (unsigned)(nsamples - off);
+                        for (unsigned e = 0; e < n; e++) dst[off + e] = (int8_t)((o[e >> 2][q] >> (8 * (e & 3))) & 0xff);
+                    }
                 }
             }
         }
@@ -240,36 +272,43 @@ clt_tree_kernel(int nwords, const unsigned long long *__restrict states, unsigne
 // host launchers
 // ---------------------------------------------------------------------------------------------
 template <int W32>
-static int seed_and_slice(int k, const uint32_t *d_cols, const uint32_t *s0, uint64_t G, uint32_t *d_states,
-                          unsigned nlanes, uint32_t *d_planes, hipStream_t st) {
+static int seed_and_slice(int k, const uint32_t *d_tabs, const uint32_t *s0, uint64_t G, uint32_t *d_states,
+                          uint64_t stride, unsigned nlanes, uint32_t *d_planes, hipStream_t st) {
     State16 s;
     for (int w = 0; w < 16; w++) s.w[w] = w < W32 ? s0[w] : 0u;
     int levels = 0;
     while ((1ull << levels) < G) levels++;
     const int first = levels < 8 ? levels : 8;
-    // levels [0, first): one block of 256 threads (at most 128 sources per level)
-    hipLaunchKernelGGL((seed_levels_kernel<W32>), dim3(1), dim3(256), 0, st, d_cols, k, s, 0, first,
-                       (unsigned long long)G, d_states);
+    const size_t lds = (size_t)((k + 3) / 4) * 16 * W32 * sizeof(uint32_t);
+    static bool attr_set = false;
+    if (!attr_set && lds > 48 * 1024) {
+        BBB_HIP(hipFuncSetAttribute((const void *)seed_levels_kernel<W32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    // levels [0, first): one block of 256 threads (at most 128 sources per level); always launched
+    // (it also stores S[0])
+    hipLaunchKernelGGL((seed_levels_kernel<W32>), dim3(1), dim3(256), lds, st, d_tabs, k, s, 0, first,
+                       (unsigned long long)G, (unsigned long long)stride, d_states);
     for (int d = first; d < levels; d++) {
         const uint64_t n = 1ull << d;
-        hipLaunchKernelGGL((seed_levels_kernel<W32>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_cols, k, s,
-                           d, d + 1, (unsigned long long)G, d_states);
+        hipLaunchKernelGGL((seed_levels_kernel<W32>), dim3((unsigned)((n + 255) / 256)), dim3(256), lds, st, d_tabs, k,
+                           s, d, d + 1, (unsigned long long)G, (unsigned long long)stride, d_states);
     }
     const uint64_t threads = (uint64_t)nlanes * (uint64_t)((k + 31) / 32);
     hipLaunchKernelGGL((bitslice_kernel<W32>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, d_states,
-                       (unsigned long long)G, nlanes, k, d_planes);
+                       (unsigned long long)G, (unsigned long long)stride, nlanes, k, d_planes);
     BBB_HIP(hipGetLastError());
     return BBB_OK;
 }
 
-int awgn_seed_launch(int k, const uint32_t *d_cols, const uint32_t *s0, uint64_t G, uint32_t *d_states,
-                     unsigned nlanes, uint32_t *d_planes, hipStream_t st) {
+int awgn_seed_launch(int k, const uint32_t *d_tabs, const uint32_t *s0, uint64_t G, uint32_t *d_states,
+                     uint64_t stride, unsigned nlanes, uint32_t *d_planes, hipStream_t st) {
     switch ((k + 31) / 32) {
-    case 1: return seed_and_slice<1>(k, d_cols, s0, G, d_states, nlanes, d_planes, st);
-    case 2: return seed_and_slice<2>(k, d_cols, s0, G, d_states, nlanes, d_planes, st);
-    case 4: return seed_and_slice<4>(k, d_cols, s0, G, d_states, nlanes, d_planes, st);
-    case 8: return seed_and_slice<8>(k, d_cols, s0, G, d_states, nlanes, d_planes, st);
-    case 16: return seed_and_slice<16>(k, d_cols, s0, G, d_states, nlanes, d_planes, st);
+    case 1: return seed_and_slice<1>(k, d_tabs, s0, G, d_states, stride, nlanes, d_planes, st);
+    case 2: return seed_and_slice<2>(k, d_tabs, s0, G, d_states, stride, nlanes, d_planes, st);
+    case 4: return seed_and_slice<4>(k, d_tabs, s0, G, d_states, stride, nlanes, d_planes, st);
+    case 8: return seed_and_slice<8>(k, d_tabs, s0, G, d_states, stride, nlanes, d_planes, st);
+    case 16: return seed_and_slice<16>(k, d_tabs, s0, G, d_states, stride, nlanes, d_planes, st);
     default: return fail(BBB_EINVAL, "k must be a power of two in [16, 512]");
     }
 }

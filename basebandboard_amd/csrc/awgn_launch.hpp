@@ -4,9 +4,10 @@
 
 namespace bbb {
 
-// start states S[g] = B^g s0 (B given per doubling level as column lists) and their bit planes
-int awgn_seed_launch(int k, const uint32_t *d_cols, const uint32_t *s0, uint64_t G, uint32_t *d_states,
-                     unsigned nlanes, uint32_t *d_planes, hipStream_t st);
+// start states S[g] = B^g s0 (B given per doubling level as nibble-combination tables
+// [level][k/4][16][W32]) stored word-major with `stride` words per state word, and their bit planes
+int awgn_seed_launch(int k, const uint32_t *d_tabs, const uint32_t *s0, uint64_t G, uint32_t *d_states,
+                     uint64_t stride, unsigned nlanes, uint32_t *d_planes, hipStream_t st);
 int awgn256_fill_launch(const uint32_t *d_planes, int8_t *dst, uint64_t nsamples, unsigned L, uint64_t G,
                         unsigned nlanes, hipStream_t st);
 int awgn_generic_fill_launch(int k, const uint16_t *d_taps, const uint32_t *d_row_off, uint32_t *d_planes2,

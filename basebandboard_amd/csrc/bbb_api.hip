@@ -31,7 +31,7 @@ int use_device(int device) {
 
 // device copy of the doubling matrices for one segment length L
 struct JumpPlan {
-    uint32_t *d_cols = nullptr;   // [levels][k][W32]
+    uint32_t *d_cols = nullptr;   // [levels][k/4][16][W32] nibble tables
     int levels = 0;
 };
 
@@ -50,7 +50,7 @@ struct bbb_lutopt {
     std::map<uint64_t, JumpPlan> plans;            // keyed by L
     std::map<uint64_t, JumpPlan> prbs_plans;       // keyed by (k << 48 | L)
     // workspace
-    uint32_t *d_states = nullptr; size_t states_cap = 0;      // [G][W32]
+    uint32_t *d_states = nullptr; size_t states_cap = 0;      // [W32][G] word-major
     uint32_t *d_planes = nullptr; size_t planes_cap = 0;      // [2][k][nlanes] (second half: generic kernel)
     uint32_t *d_pstates = nullptr; size_t pstates_cap = 0;    // PRBS [G]
     uint32_t *d_pplanes = nullptr; size_t pplanes_cap = 0;    // PRBS [32][nlanes]
@@ -81,16 +81,42 @@ int grow(uint32_t **p, size_t *cap, size_t need_words) {
     return BBB_OK;
 }
 
-// columns of (M^(2^d)) for d < levels, packed [d][c][W32], uploaded to the device
+// For d < levels: the 16 XOR-combinations of every group of four columns of M^(2^d), packed
+// [d][k/4][16][W32], uploaded to the device (y = M x then needs k/4 table lookups).
 int build_plan(const GF2Mat &M, int levels, JumpPlan *plan) {
-    const int k = M.n, W32 = (k + 31) / 32;
-    std::vector<uint32_t> host((size_t)levels * k * W32, 0);
+    const int k = M.n, W32 = (k + 31) / 32, nnib = (k + 3) / 4;
+    std::vector<uint32_t> host((size_t)levels * nnib * 16 * W32, 0);
+    std::vector<uint32_t> cols((size_t)k * W32);
     GF2Mat cur = M;
     for (int d = 0; d < levels; d++) {
         if (d) cur = cur.mul(cur);
-        for (int c = 0; c < k; c++)
-            for (int r = 0; r < k; r++)
-                if (cur.get(r, c)) host[((size_t)d * k + c) * W32 + (r >> 5)] |= 1u << (r & 31);
+        std::fill(cols.begin(), cols.end(), 0u);
+        for (int r = 0; r < k; r++) {
+            const uint64_t *row = cur.row(r);
+            for (int w = 0; w < cur.W; w++) {
+                uint64_t bits = row[w];
+                while (bits) {
+                    const int c = (w << 6) + __builtin_ctzll(bits);
+                    bits &= bits - 1;
+                    cols[(size_t)c * W32 + (r >> 5)] |= 1u << (r & 31);
+                }
+            }
+        }
+        // entry (n, v) = XOR of the columns 4n+i with bit i of v set; stored chunked (see the
+        // layout comment at seed_levels_kernel): index ((n*NC + zc)*16 + v)*C + zz
+        const int C = W32 < 4 ? W32 : 4, NC = W32 / C;
+        std::vector<uint32_t> ent(16 * (size_t)W32);
+        for (int n = 0; n < nnib; n++) {
+            std::fill(ent.begin(), ent.end(), 0u);
+            for (int v = 1; v < 16; v++) {
+                const int c = 4 * n + __builtin_ctz((unsigned)v);
+                for (int z = 0; z < W32; z++)
+                    ent[(size_t)v * W32 + z] = ent[(size_t)(v & (v - 1)) * W32 + z] ^ (c < k ? cols[(size_t)c * W32 + z] : 0u);
+            }
+            for (int v = 0; v < 16; v++)
+                for (int z = 0; z < W32; z++)
+                    host[(size_t)d * nnib * 16 * W32 + (((size_t)n * NC + z / C) * 16 + v) * C + z % C] = ent[(size_t)v * W32 + z];
+        }
     }
     BBB_HIP(hipMalloc((void **)&plan->d_cols, host.size() * sizeof(uint32_t)));
     BBB_HIP(hipMemcpy(plan->d_cols, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -152,7 +178,7 @@ int prepare_planes(bbb_lutopt *h, uint64_t first, uint64_t L, uint64_t G, unsign
     uint32_t s32[16] = {0};
     for (int w = 0; w < h->W32; w++) s32[w] = (uint32_t)(s0[w >> 1] >> (32 * (w & 1)));
     h->planes_valid = false;
-    rc = awgn_seed_launch(h->k, plan->d_cols, s32, G, h->d_states, nlanes, h->d_planes, h->stream);
+    rc = awgn_seed_launch(h->k, plan->d_cols, s32, G, h->d_states, G, nlanes, h->d_planes, h->stream);
     if (rc) return rc;
     h->planes_valid = true;
     h->planes_first = first; h->planes_L = L; h->planes_G = G;
@@ -244,7 +270,7 @@ int ber_run(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, unsigned long lo
         uint64_t ps0 = 0;
         if ((rc = prbs_state_at_host(c.prbs_k, c.prbs_state, c.first_bit, &ps0))) return rc;
         uint32_t ps32[16] = {(uint32_t)ps0};
-        if ((rc = awgn_seed_launch(c.prbs_k, pp->d_cols, ps32, G, h->d_pstates, nlanes, h->d_pplanes, h->stream))) return rc;
+        if ((rc = awgn_seed_launch(c.prbs_k, pp->d_cols, ps32, G, h->d_pstates, G, nlanes, h->d_pplanes, h->stream))) return rc;
         if ((rc = ber256_launch(h->d_planes, h->d_pplanes, t, nlanes, counters_dev + 2 * (size_t)i, h->stream))) return rc;
     }
     return BBB_OK;

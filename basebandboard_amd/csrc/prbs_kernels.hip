@@ -107,12 +107,17 @@ prbs_stream_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwords,
     const PrbsPowTable &pw = d_prbs_pow[ki];
 
     // 1. LFSR state at the first bit of this region: s = T^(t0) * init (lane r evaluates row r).
+    //    All 64 candidate rows are fetched up front (one memory round trip, not one per set bit).
     const u64 t0 = first_bit + word0 * 64;
     uint32_t s = (uint32_t)init_state;
-    for (int i = 0; i < 64; i++) {
-        if (!((t0 >> i) & 1)) continue;
-        const uint32_t row = lane < K ? pw.rows[i][lane] : 0u;
-        s = (uint32_t)__ballot(__builtin_popcount(row & s) & 1);
+    {
+        uint32_t myrow[64];
+#pragma unroll
+        for (int i = 0; i < 64; i++) myrow[i] = pw.rows[i][lane & 31];
+#pragma unroll
+        for (int i = 0; i < 64; i++) {
+            if ((t0 >> i) & 1) s = (uint32_t)__ballot(lane < K && (__builtin_popcount(myrow[i] & s) & 1));
+        }
     }
     // 2. lane i < K forms word i of the region: jump a further 64*i bits, then clock 64 times.
     if (lane < K) {
@@ -160,33 +165,53 @@ prbs_stream_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwords,
     u64 errs = 0;
 
     for (u64 q0 = 0; q0 < nrows; q0 += K) {
-        u64x2 D[K];
-        if (CHECK) {
+        const u64 wbase = word0 + q0 * 128 + 2 * (u64)lane;
+        // fast path: all K rows of this pass lie strictly below the stream's last word --
+        // no bounds or tail-mask logic, K independent 16-byte accesses per lane
+        if (q0 + K <= nrows && word0 + (q0 + K) * 128 <= last_word) {
+            if (CHECK) {
+                u64x2 D[K];
 #pragma unroll
-            for (int i = 0; i < K; i++) {
-                const u64 w = word0 + (q0 + i) * 128 + 2 * (u64)lane;
-                D[i] = (u64x2){0, 0};
-                if (q0 + i < nrows) {
-                    if (w + 1 <= last_word) D[i] = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(buf + w));
-                    else if (w <= last_word) D[i].x = buf[w];
+                for (int i = 0; i < K; i++) D[i] = *reinterpret_cast<const u64x2 *>(buf + wbase + (u64)i * 128);
+                if (q0 > 0) {
+#pragma unroll
+                    for (int i = 0; i < K; i++) V[i] ^= V[(i - TAP + K) % K];
                 }
+                uint32_t e32 = 0;
+#pragma unroll
+                for (int i = 0; i < K; i++) {
+                    const u64x2 d = D[i] ^ V[i];
+                    e32 += (uint32_t)(__builtin_popcountll(d.x) + __builtin_popcountll(d.y));
+                }
+                errs += e32;
+            } else {
+                if (q0 > 0) {
+#pragma unroll
+                    for (int i = 0; i < K; i++) V[i] ^= V[(i - TAP + K) % K];   // row[q] = row[q-K] ^ row[q-TAP]
+                }
+#pragma unroll
+                for (int i = 0; i < K; i++) *reinterpret_cast<u64x2 *>(buf + wbase + (u64)i * 128) = V[i];
             }
+            continue;
         }
+        // tail pass: per-word bounds and the mask of the final partial word
         if (q0 > 0) {
 #pragma unroll
-            for (int i = 0; i < K; i++) V[i] ^= V[(i - TAP + K) % K];   // row[q] = row[q-K] ^ row[q-TAP]
+            for (int i = 0; i < K; i++) V[i] ^= V[(i - TAP + K) % K];
         }
-#pragma unroll
+#pragma unroll 1
         for (int i = 0; i < K; i++) {
             if (q0 + i >= nrows) break;
-            const u64 w = word0 + (q0 + i) * 128 + 2 * (u64)lane;
-            u64x2 v = V[i];
+            const u64 w = wbase + (u64)i * 128;
+            u64x2 v = V[0];
+#pragma unroll
+            for (int j = 1; j < K; j++) if (j == i) v = V[j];
             if (w == last_word) v.x &= last_mask;
             if (w + 1 == last_word) v.y &= last_mask;
             if (CHECK) {
-                u64x2 d = D[i] ^ v;
-                if (w > last_word) d.x = 0;
-                if (w + 1 > last_word) d.y = 0;
+                u64x2 d = {0, 0};
+                if (w <= last_word) d.x = buf[w] ^ v.x;
+                if (w + 1 <= last_word) d.y = buf[w + 1] ^ v.y;
                 if (w == last_word) d.x &= last_mask;
                 if (w + 1 == last_word) d.y &= last_mask;
                 errs += (u64)(__builtin_popcountll(d.x) + __builtin_popcountll(d.y));
