@@ -24,7 +24,9 @@ struct TrialDev {            // one trial as the kernel sees it
     uint32_t L;              // bits per generator
     uint64_t G, nbits;
 };
-int ber256_launch(const uint32_t *d_planes, const uint32_t *d_prbs_planes, const TrialDev &t, unsigned nlanes,
+#define BBB_BER_MAX_GROUP 12
+// one launch for `ncfg` channel settings that share one noise / PRBS stream (same geometry in t[0..ncfg))
+int ber256_launch(const uint32_t *d_planes, const uint32_t *d_prbs_planes, const TrialDev *t, int ncfg, unsigned nlanes,
                   unsigned long long *d_counters, hipStream_t st);
 int prbs_state_at_host(int k, uint64_t init_state, uint64_t nbits, uint64_t *state);
 

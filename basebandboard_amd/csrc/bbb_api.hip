@@ -8,6 +8,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 namespace bbb {
@@ -244,6 +245,7 @@ int channel_thresholds(int amp, int noise_var, TrialDev *t) {
 
 int ber_run(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, unsigned long long *counters_dev) {
     if (!h->specialised) return fail(BBB_EUNSUP, "BER trials need the n256 generator");
+    std::vector<TrialDev> td((size_t)ncfg);
     for (int i = 0; i < ncfg; i++) {
         const bbb_trial_cfg &c = cfgs[i];
         const int tap = prbs_tap(c.prbs_k);
@@ -251,16 +253,32 @@ int ber_run(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, unsigned long lo
         if (c.prbs_state == 0 || (c.prbs_state >> c.prbs_k)) return fail(BBB_EINVAL, "PRBS state must be in [1, 2^k)");
         if (c.amp < 0 || c.amp > 2047 || c.noise_var < 0 || c.noise_var > 15)
             return fail(BBB_EINVAL, "amp must be 0..2047 and noise_var 0..15");
-        if (c.nbits == 0) continue;
-        TrialDev t{};
-        t.prbs_k = c.prbs_k;
-        t.prbs_tap = tap;
-        int rc = channel_thresholds(c.amp, c.noise_var, &t);
+        if (c.warmup + c.first_bit < c.warmup || c.warmup + c.first_bit + c.nbits < c.nbits)
+            return fail(BBB_EINVAL, "warmup + first_bit + nbits overflows");
+        td[(size_t)i].prbs_k = c.prbs_k;
+        td[(size_t)i].prbs_tap = tap;
+        int rc = channel_thresholds(c.amp, c.noise_var, &td[(size_t)i]);
         if (rc) return rc;
+    }
+    // Consecutive trials that read the SAME noise and PRBS streams (same seeds, offsets, length)
+    // differ only in the channel thresholds: they are evaluated together, on one pass over the
+    // streams.  The counters are identical to running them one by one.
+    for (int i = 0; i < ncfg;) {
+        const bbb_trial_cfg &c = cfgs[i];
+        int n = 1;
+        while (i + n < ncfg && n < BBB_BER_MAX_GROUP) {
+            const bbb_trial_cfg &d = cfgs[i + n];
+            if (d.prbs_k != c.prbs_k || d.prbs_state != c.prbs_state || d.warmup != c.warmup ||
+                d.first_bit != c.first_bit || d.nbits != c.nbits)
+                break;
+            n++;
+        }
+        if (c.nbits == 0) { i += n; continue; }
         uint64_t L, G;
         unsigned nlanes;
         partition(h, c.nbits, 2, &L, &G, &nlanes);
-        t.L = (uint32_t)L; t.G = G; t.nbits = c.nbits;
+        for (int j = 0; j < n; j++) { td[(size_t)(i + j)].L = (uint32_t)L; td[(size_t)(i + j)].G = G; td[(size_t)(i + j)].nbits = c.nbits; }
+        int rc;
         if ((rc = prepare_planes(h, c.warmup + c.first_bit, L, G, nlanes))) return rc;
         // PRBS start states: the same doubling machinery with the k x k LFSR companion matrix
         JumpPlan *pp;
@@ -271,7 +289,8 @@ int ber_run(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, unsigned long lo
         if ((rc = prbs_state_at_host(c.prbs_k, c.prbs_state, c.first_bit, &ps0))) return rc;
         uint32_t ps32[16] = {(uint32_t)ps0};
         if ((rc = awgn_seed_launch(c.prbs_k, pp->d_cols, ps32, G, h->d_pstates, G, nlanes, h->d_pplanes, h->stream))) return rc;
-        if ((rc = ber256_launch(h->d_planes, h->d_pplanes, t, nlanes, counters_dev + 2 * (size_t)i, h->stream))) return rc;
+        if ((rc = ber256_launch(h->d_planes, h->d_pplanes, &td[(size_t)i], n, nlanes, counters_dev + 2 * (size_t)i, h->stream))) return rc;
+        i += n;
     }
     return BBB_OK;
 }
@@ -486,15 +505,23 @@ int bbb_prbs_check(int k, uint64_t init_state, uint64_t first_bit, uint64_t nbit
     int rc = use_device(device);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)hip_stream;
+    // one 8-byte device counter per device, allocated once (a malloc/free pair per call would cost
+    // as much as checking a gigabyte)
+    static std::mutex mu;
+    static uint64_t *slots[64] = {nullptr};
     uint64_t *d = nullptr;
-    BBB_HIP(hipMalloc((void **)&d, sizeof(uint64_t)));
-    rc = BBB_OK;
-    if (hipMemsetAsync(d, 0, sizeof(uint64_t), st) != hipSuccess) rc = fail(BBB_EHIP, "hipMemsetAsync");
-    if (!rc) rc = bbb_prbs_check_dev(k, init_state, first_bit, nbits, src_packed_dev, d, device, hip_stream);
-    if (!rc && hipMemcpyAsync(nerr, d, sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess) rc = fail(BBB_EHIP, "hipMemcpyAsync");
-    if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = fail(BBB_EHIP, "hipStreamSynchronize");
-    (void)hipFree(d);
-    return rc;
+    {
+        std::lock_guard<std::mutex> g(mu);
+        if (device >= 64) return fail(BBB_EINVAL, "device index too large");
+        if (!slots[device]) BBB_HIP(hipMalloc((void **)&slots[device], sizeof(uint64_t)));
+        d = slots[device];
+    }
+    BBB_HIP(hipMemsetAsync(d, 0, sizeof(uint64_t), st));
+    rc = bbb_prbs_check_dev(k, init_state, first_bit, nbits, src_packed_dev, d, device, hip_stream);
+    if (rc) return rc;
+    BBB_HIP(hipMemcpyAsync(nerr, d, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    BBB_HIP(hipStreamSynchronize(st));
+    return BBB_OK;
 }
 
 int bbb_prbs_state_at(int k, uint64_t init_state, uint64_t nbits, uint64_t *state) {

@@ -24,21 +24,27 @@
 
 namespace bbb {
 
-struct TrialK {              // kernel-argument form of TrialDev (uniform -> SGPRs)
-    int32_t k, tap;
-    int32_t nthr0, nthr1, inv0, inv1;
-    uint32_t thrmask0[4][8];   // thrmask[i][q] = all-ones when bit q of threshold i is 1
-    uint32_t thrmask1[4][8];
+constexpr int kMaxCfg = BBB_BER_MAX_GROUP;   // channel settings evaluated per launch on ONE noise / PRBS stream
+
+struct TrialK {              // kernel-argument form (uniform -> SGPRs / scalar loads)
+    int32_t k, tap, ncfg;
     uint32_t L, last_len;
     unsigned long long G;
+    int8_t nthr[kMaxCfg][2];     // thresholds in use for bit = 0 / 1
+    int8_t inv[kMaxCfg][2];      // constant term of the parity
+    int16_t thr[kMaxCfg][2][4];  // each in 1..255
 };
 
-// [T >= thr] for 32 samples: scan from the LSB; where the threshold bit is 1 the running
-// result must AND with T's bit, where it is 0 it ORs (tm = 0 / ~0 selects).
-__device__ __forceinline__ uint32_t ge_thr(const uint32_t (&T)[8], const uint32_t (&tm)[8]) {
+// [T >= thr] for 32 samples: scan from the LSB; where the threshold bit is 1 the running result
+// ANDs with T's bit, where it is 0 it ORs.  The per-bit mask is a scalar (SALU) value, the
+// update one V_BITOP3 with a scalar operand.
+__device__ __forceinline__ uint32_t ge_thr(const uint32_t (&T)[8], int thr) {
     uint32_t ge = ~0u;
 #pragma unroll
-    for (int q = 0; q < 8; q++) ge = (tm[q] & (T[q] & ge)) | (~tm[q] & (T[q] | ge));
+    for (int q = 0; q < 8; q++) {
+        const uint32_t tm = (uint32_t)(((int32_t)((uint32_t)thr << (31 - q))) >> 31);
+        ge = (tm & (T[q] & ge)) | (~tm & (T[q] | ge));
+    }
     return ge;
 }
 
@@ -62,7 +68,10 @@ ber256_kernel(const uint32_t *__restrict planes, const uint32_t *__restrict prbs
         if (g < tk.G) vm_all |= 1u << j;
         if (g + 1 == tk.G) vm_last |= 1u << j;
     }
-    uint32_t nerr = 0, nbit = 0;
+    uint32_t nerr[kMaxCfg];
+#pragma unroll
+    for (int c = 0; c < kMaxCfg; c++) nerr[c] = 0;
+    uint32_t nbit = 0;
     int head = 0;
 
     auto consume = [&](unsigned t) {
@@ -77,13 +86,17 @@ ber256_kernel(const uint32_t *__restrict planes, const uint32_t *__restrict prbs
 #pragma unroll
         for (int q = 0; q < 7; q++) T[q] = cnt[q];
         T[7] = ~cnt[7];
-        uint32_t e0 = tk.inv0 ? ~0u : 0u, e1 = tk.inv1 ? ~0u : 0u;
-        for (int i = 0; i < tk.nthr0; i++) e0 ^= ge_thr(T, tk.thrmask0[i]);
-        for (int i = 0; i < tk.nthr1; i++) e1 ^= ge_thr(T, tk.thrmask1[i]);
         const uint32_t valid = t < tk.last_len ? vm_all : (vm_all & ~vm_last);
-        const uint32_t e = ((pb & e1) | (~pb & e0)) & valid;
-        nerr += __builtin_popcount(e);
         nbit += __builtin_popcount(valid);
+#pragma unroll
+        for (int c = 0; c < kMaxCfg; c++) {
+            if (c < tk.ncfg) {
+                uint32_t e0 = tk.inv[c][0] ? ~0u : 0u, e1 = tk.inv[c][1] ? ~0u : 0u;
+                for (int i = 0; i < tk.nthr[c][0]; i++) e0 ^= ge_thr(T, tk.thr[c][0][i]);
+                for (int i = 0; i < tk.nthr[c][1]; i++) e1 ^= ge_thr(T, tk.thr[c][1][i]);
+                nerr[c] += __builtin_popcount(((pb & e1) | (~pb & e0)) & valid);
+            }
+        }
     };
 
     const unsigned pairs = (tk.L + 1) / 2;
@@ -94,39 +107,46 @@ ber256_kernel(const uint32_t *__restrict planes, const uint32_t *__restrict prbs
         lutopt256_step(b, a, cnt);
         if (2 * it + 1 < tk.L) consume(2 * it + 1);
     }
-    unsigned long long e64 = nerr, b64 = nbit;
+    unsigned long long b64 = nbit;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        e64 += __shfl_xor(e64, off, 64);
-        b64 += __shfl_xor(b64, off, 64);
-    }
-    if (lane == 0) {
-        atomicAdd(&counters[0], b64);
-        if (e64) atomicAdd(&counters[1], e64);
+    for (int off = 32; off > 0; off >>= 1) b64 += __shfl_xor(b64, off, 64);
+#pragma unroll
+    for (int c = 0; c < kMaxCfg; c++) {
+        if (c < tk.ncfg) {
+            unsigned long long e64 = nerr[c];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) e64 += __shfl_xor(e64, off, 64);
+            if (lane == 0) {
+                atomicAdd(&counters[2 * c], b64);
+                if (e64) atomicAdd(&counters[2 * c + 1], e64);
+            }
+        }
     }
 }
 
-int ber256_launch(const uint32_t *d_planes, const uint32_t *d_prbs_planes, const TrialDev &t, unsigned nlanes,
+// counters: [ncfg][2] contiguous.  All trials of the group share t[0]'s stream geometry.
+int ber256_launch(const uint32_t *d_planes, const uint32_t *d_prbs_planes, const TrialDev *t, int ncfg, unsigned nlanes,
                   unsigned long long *d_counters, hipStream_t st) {
+    if (ncfg < 1 || ncfg > kMaxCfg) return fail(BBB_EINVAL, "bad trial group size");
     TrialK tk{};
-    tk.k = t.prbs_k;
-    tk.tap = t.prbs_tap;
-    tk.L = t.L;
-    tk.G = t.G;
-    tk.last_len = (uint32_t)(t.nbits - (t.G - 1) * (uint64_t)t.L);
-    int nth[2] = {0, 0}, inv[2] = {0, 0};
-    for (int bv = 0; bv < 2; bv++) {
-        for (int i = 0; i < t.nthr[bv]; i++) {
-            const int th = t.thr[bv][i];
-            if (th <= 0) { inv[bv] ^= 1; continue; }     // [T >= 0] is always true
-            if (th >= 256) continue;                     // [T >= 256] never
-            uint32_t(*dst)[8] = bv ? tk.thrmask1 : tk.thrmask0;
-            for (int q = 0; q < 8; q++) dst[nth[bv]][q] = ((th >> q) & 1) ? ~0u : 0u;
-            nth[bv]++;
+    tk.k = t[0].prbs_k;
+    tk.tap = t[0].prbs_tap;
+    tk.ncfg = ncfg;
+    tk.L = t[0].L;
+    tk.G = t[0].G;
+    tk.last_len = (uint32_t)(t[0].nbits - (t[0].G - 1) * (uint64_t)t[0].L);
+    for (int c = 0; c < ncfg; c++)
+        for (int bv = 0; bv < 2; bv++) {
+            int n = 0, inv = 0;
+            for (int i = 0; i < t[c].nthr[bv]; i++) {
+                const int th = t[c].thr[bv][i];
+                if (th <= 0) { inv ^= 1; continue; }     // [T >= 0] is always true
+                if (th >= 256) continue;                 // [T >= 256] never
+                tk.thr[c][bv][n++] = (int16_t)th;
+            }
+            tk.nthr[c][bv] = (int8_t)n;
+            tk.inv[c][bv] = (int8_t)inv;
         }
-    }
-    tk.nthr0 = nth[0]; tk.nthr1 = nth[1];
-    tk.inv0 = inv[0];  tk.inv1 = inv[1];
     hipLaunchKernelGGL(ber256_kernel, dim3(nlanes / 64), dim3(64), 0, st, d_planes, d_prbs_planes, tk, nlanes,
                        d_counters);
     BBB_HIP(hipGetLastError());

@@ -20,6 +20,7 @@
 #include "bbb_common.hpp"
 #include "gf2.hpp"
 
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -84,6 +85,8 @@ int prbs_state_at_host(int k, uint64_t init_state, uint64_t nbits, uint64_t *sta
 
 // ---------------------------------------------------------------------------------------------
 // Streaming generator / checker.  One wave per block; block b owns rows [b*rpw, (b+1)*rpw).
+// A row is RW = 64*WPL words; lane l owns words WPL*l .. WPL*l+WPL-1 of every row (8- or 16-byte
+// accesses).  Row lag identity: row[q] = row[q-K] ^ row[q-TAP]  (bit lags K*RW*64, TAP*RW*64).
 // ---------------------------------------------------------------------------------------------
 template <int K>
 __device__ __forceinline__ uint32_t lfsr_matvec(const uint32_t *__restrict rows, uint32_t s) {
@@ -93,30 +96,57 @@ __device__ __forceinline__ uint32_t lfsr_matvec(const uint32_t *__restrict rows,
     return ns;
 }
 
-template <int K, bool CHECK>
-__global__ void __launch_bounds__(64)
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <int WPL> struct LaneWords;
+template <> struct LaneWords<1> { typedef u32x2 type; };
+template <> struct LaneWords<2> { typedef u32x4 type; };
+__device__ __forceinline__ uint32_t popc_words(u32x2 v) { return (uint32_t)(__builtin_popcount(v.x) + __builtin_popcount(v.y)); }
+__device__ __forceinline__ uint32_t popc_words(u32x4 v) {
+    return (uint32_t)(__builtin_popcount(v.x) + __builtin_popcount(v.y) + __builtin_popcount(v.z) + __builtin_popcount(v.w));
+}
+// a ^= b, in place: the tied operand stops the compiler from double-buffering the K-row window
+// (which would need 2 x 4K registers and spill)
+__device__ __forceinline__ void xor_inplace(u32x2 &a, const u32x2 &b) {
+    asm("v_xor_b32 %0, %0, %1" : "+v"(a.x) : "v"(b.x));
+    asm("v_xor_b32 %0, %0, %1" : "+v"(a.y) : "v"(b.y));
+}
+__device__ __forceinline__ void xor_inplace(u32x4 &a, const u32x4 &b) {
+    asm("v_xor_b32 %0, %0, %1" : "+v"(a.x) : "v"(b.x));
+    asm("v_xor_b32 %0, %0, %1" : "+v"(a.y) : "v"(b.y));
+    asm("v_xor_b32 %0, %0, %1" : "+v"(a.z) : "v"(b.z));
+    asm("v_xor_b32 %0, %0, %1" : "+v"(a.w) : "v"(b.w));
+}
+
+template <int K, bool CHECK, int WPL>
+__global__ void __launch_bounds__(64, 2)   // >= 2 waves per SIMD: at most 256 registers
 prbs_stream_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwords, u64 rows_per_wave,
                    u64 *__restrict buf, u64 *__restrict nerr) {
+    typedef typename LaneWords<WPL>::type lw_t;
     constexpr int TAP = tap_of(K);
+    constexpr int RW = 64 * WPL;                 // words per row
+    constexpr int LEVELS = WPL == 2 ? 7 : 6;     // RW = 2^LEVELS
     constexpr uint32_t SMASK = (uint32_t)((1ull << K) - 1ull);
-    __shared__ __attribute__((aligned(16))) u64 X[K * 128];
+    __shared__ __attribute__((aligned(16))) u64 X[K * RW];
     const int lane = threadIdx.x;
     const u64 row0 = (u64)blockIdx.x * rows_per_wave;
-    const u64 word0 = row0 * 128;
+    const u64 word0 = row0 * RW;
     if (word0 >= nwords) return;
     const PrbsPowTable &pw = d_prbs_pow[ki];
 
     // 1. LFSR state at the first bit of this region: s = T^(t0) * init (lane r evaluates row r).
-    //    All 64 candidate rows are fetched up front (one memory round trip, not one per set bit).
+    //    The candidate rows are fetched 16 at a time (four memory round trips, not one per set bit).
     const u64 t0 = first_bit + word0 * 64;
     uint32_t s = (uint32_t)init_state;
-    {
-        uint32_t myrow[64];
+#pragma unroll 1
+    for (int i0 = 0; i0 < 64; i0 += 16) {
+        if (((t0 >> i0) & 0xffffull) == 0) continue;
+        uint32_t myrow[16];
 #pragma unroll
-        for (int i = 0; i < 64; i++) myrow[i] = pw.rows[i][lane & 31];
+        for (int i = 0; i < 16; i++) myrow[i] = pw.rows[i0 + i][lane & 31];
 #pragma unroll
-        for (int i = 0; i < 64; i++) {
-            if ((t0 >> i) & 1) s = (uint32_t)__ballot(lane < K && (__builtin_popcount(myrow[i] & s) & 1));
+        for (int i = 0; i < 16; i++) {
+            if ((t0 >> (i0 + i)) & 1) s = (uint32_t)__ballot(lane < K && (__builtin_popcount(myrow[i] & s) & 1));
         }
     }
     // 2. lane i < K forms word i of the region: jump a further 64*i bits, then clock 64 times.
@@ -136,11 +166,11 @@ prbs_stream_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwords,
         X[lane] = w;
     }
     __syncthreads();
-    // 3. grow the known prefix K -> 128K words: level j uses word lags K*2^j and TAP*2^j.
+    // 3. grow the known prefix K -> K*RW words: level j uses word lags K*2^j and TAP*2^j.
     {
         int known = K;
 #pragma unroll 1
-        for (int j = 0; j < 7; j++) {
+        for (int j = 0; j < LEVELS; j++) {
             const int lagk = K << j, lagt = TAP << j, target = K << (j + 1);
             while (known < target) {
                 const int cnt = min(lagt, target - known);
@@ -153,71 +183,68 @@ prbs_stream_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwords,
             }
         }
     }
-    // 4. register window: V[q] = words (2*lane, 2*lane+1) of row q, q < K.
-    u64x2 V[K];
+    // 4. register window: V[q] = this lane's words of row q, q < K.
+    lw_t V[K];
 #pragma unroll
-    for (int q = 0; q < K; q++) V[q] = *reinterpret_cast<const u64x2 *>(&X[q * 128 + 2 * lane]);
+    for (int q = 0; q < K; q++) V[q] = *reinterpret_cast<const lw_t *>(&X[q * RW + WPL * lane]);
 
-    const u64 rows_total = (nwords - word0 + 127) / 128;
+    const u64 rows_total = (nwords - word0 + RW - 1) / RW;
     const u64 nrows = rows_total < rows_per_wave ? rows_total : rows_per_wave;
     const u64 last_word = nwords - 1;
     const u64 last_mask = (nbits & 63) ? ((1ull << (nbits & 63)) - 1ull) : ~0ull;
     u64 errs = 0;
 
     for (u64 q0 = 0; q0 < nrows; q0 += K) {
-        const u64 wbase = word0 + q0 * 128 + 2 * (u64)lane;
+        const u64 wbase = word0 + q0 * RW + (u64)(WPL * lane);
+        u64 *rowp = buf + (word0 + q0 * RW);      // wave-uniform row base: scalar base + lane offset addressing
         // fast path: all K rows of this pass lie strictly below the stream's last word --
-        // no bounds or tail-mask logic, K independent 16-byte accesses per lane
-        if (q0 + K <= nrows && word0 + (q0 + K) * 128 <= last_word) {
+        // no bounds or tail-mask logic, K independent accesses per lane
+        if (q0 + K <= nrows && word0 + (q0 + K) * RW <= last_word) {
             if (CHECK) {
-                u64x2 D[K];
+                lw_t D[K];
 #pragma unroll
-                for (int i = 0; i < K; i++) D[i] = *reinterpret_cast<const u64x2 *>(buf + wbase + (u64)i * 128);
+                for (int i = 0; i < K; i++) D[i] = reinterpret_cast<const lw_t *>(rowp + (u64)i * RW)[lane];
                 if (q0 > 0) {
 #pragma unroll
-                    for (int i = 0; i < K; i++) V[i] ^= V[(i - TAP + K) % K];
+                    for (int i = 0; i < K; i++) xor_inplace(V[i], V[(i - TAP + K) % K]);
                 }
                 uint32_t e32 = 0;
 #pragma unroll
-                for (int i = 0; i < K; i++) {
-                    const u64x2 d = D[i] ^ V[i];
-                    e32 += (uint32_t)(__builtin_popcountll(d.x) + __builtin_popcountll(d.y));
-                }
+                for (int i = 0; i < K; i++) e32 += popc_words(D[i] ^ V[i]);
                 errs += e32;
             } else {
                 if (q0 > 0) {
 #pragma unroll
-                    for (int i = 0; i < K; i++) V[i] ^= V[(i - TAP + K) % K];   // row[q] = row[q-K] ^ row[q-TAP]
+                    for (int i = 0; i < K; i++) xor_inplace(V[i], V[(i - TAP + K) % K]);   // row[q] = row[q-K] ^ row[q-TAP]
                 }
 #pragma unroll
-                for (int i = 0; i < K; i++) *reinterpret_cast<u64x2 *>(buf + wbase + (u64)i * 128) = V[i];
+                for (int i = 0; i < K; i++) reinterpret_cast<lw_t *>(rowp + (u64)i * RW)[lane] = V[i];
             }
             continue;
         }
-        // tail pass: per-word bounds and the mask of the final partial word
+        // tail pass: per-word bounds and the mask of the final partial word; the window goes back
+        // to LDS so that rows can be indexed at run time
         if (q0 > 0) {
 #pragma unroll
-            for (int i = 0; i < K; i++) V[i] ^= V[(i - TAP + K) % K];
+            for (int i = 0; i < K; i++) xor_inplace(V[i], V[(i - TAP + K) % K]);
         }
-#pragma unroll 1
-        for (int i = 0; i < K; i++) {
-            if (q0 + i >= nrows) break;
-            const u64 w = wbase + (u64)i * 128;
-            u64x2 v = V[0];
 #pragma unroll
-            for (int j = 1; j < K; j++) if (j == i) v = V[j];
-            if (w == last_word) v.x &= last_mask;
-            if (w + 1 == last_word) v.y &= last_mask;
-            if (CHECK) {
-                u64x2 d = {0, 0};
-                if (w <= last_word) d.x = buf[w] ^ v.x;
-                if (w + 1 <= last_word) d.y = buf[w + 1] ^ v.y;
-                if (w == last_word) d.x &= last_mask;
-                if (w + 1 == last_word) d.y &= last_mask;
-                errs += (u64)(__builtin_popcountll(d.x) + __builtin_popcountll(d.y));
-            } else {
-                if (w + 1 <= last_word) *reinterpret_cast<u64x2 *>(buf + w) = v;
-                else if (w <= last_word) buf[w] = v.x;
+        for (int q = 0; q < K; q++) *reinterpret_cast<lw_t *>(&X[q * RW + WPL * lane]) = V[q];
+#pragma unroll 1
+        for (int i = 0; i < K && q0 + i < nrows; i++) {
+#pragma unroll
+            for (int e = 0; e < WPL; e++) {
+                const u64 w = wbase + (u64)i * RW + e;
+                if (w > last_word) continue;
+                u64 v = X[i * RW + WPL * lane + e];
+                if (w == last_word) v &= last_mask;
+                if (CHECK) {
+                    u64 d = buf[w] ^ v;
+                    if (w == last_word) d &= last_mask;
+                    errs += (u64)__builtin_popcountll(d);
+                } else {
+                    buf[w] = v;
+                }
             }
         }
     }
@@ -227,6 +254,53 @@ prbs_stream_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwords,
         for (int off = 32; off > 0; off >>= 1) errs += __shfl_xor(errs, off, 64);
         if (lane == 0 && errs) atomicAdd(nerr, errs);
     }
+}
+
+// words per lane: 1 (8-byte accesses, a 2K-register window, 15.5 KiB of LDS for K = 31) measured
+// faster than 2 for both directions (profiles/r01_prbs_sweep.log); overridable for experiments
+static int prbs_wpl(bool check) {
+    static const int fill = std::getenv("BBB_PRBS_FILL_WPL") ? std::atoi(std::getenv("BBB_PRBS_FILL_WPL")) : 1;
+    static const int chk = std::getenv("BBB_PRBS_CHECK_WPL") ? std::atoi(std::getenv("BBB_PRBS_CHECK_WPL")) : 1;
+    const int v = check ? chk : fill;
+    return v == 1 ? 1 : 2;
+}
+
+template <bool CHECK, int WPL>
+static int launch_stream_w(int k, int ki, u64 init_state, u64 first_bit, u64 nbits, u64 *buf, u64 *nerr, hipStream_t st) {
+    const u64 nwords = (nbits + 63) / 64;
+    const u64 RW = 64 * WPL;
+    const u64 rows = (nwords + RW - 1) / RW;
+    // exactly one resident generation of waves: every wave pays the bootstrap once, and a second,
+    // partially filled generation would double the run time
+    int dev = 0, ncu = 256, per_cu = 4;
+    BBB_HIP(hipGetDevice(&dev));
+    BBB_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    const void *fn = nullptr;
+#define BBB_PRBS_FN(KK) case KK: fn = (const void *)prbs_stream_kernel<KK, CHECK, WPL>; break;
+    switch (k) { BBB_PRBS_FN(7) BBB_PRBS_FN(9) BBB_PRBS_FN(11) BBB_PRBS_FN(15) BBB_PRBS_FN(20) BBB_PRBS_FN(23) BBB_PRBS_FN(31) }
+#undef BBB_PRBS_FN
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    static const int cap = std::getenv("BBB_PRBS_WAVES_PER_CU") ? std::atoi(std::getenv("BBB_PRBS_WAVES_PER_CU")) : 0;
+    if (cap > 0 && per_cu > cap) per_cu = cap;
+    const u64 target_waves = (u64)ncu * (u64)per_cu;
+    u64 rpw = (rows + target_waves - 1) / target_waves;
+    const u64 min_rpw = 8 * (u64)k;
+    if (rpw < min_rpw) rpw = min_rpw;
+    const u64 nblocks = (rows + rpw - 1) / rpw;
+    if (nblocks > 0x7fffffffull) return fail(BBB_EINVAL, "nbits too large");
+    dim3 grid((unsigned)nblocks), block(64);
+#define BBB_PRBS_CASE(KK)                                                                                       \
+    case KK:                                                                                                    \
+        hipLaunchKernelGGL((prbs_stream_kernel<KK, CHECK, WPL>), grid, block, 0, st, ki, init_state, first_bit, \
+                           nbits, nwords, rpw, buf, nerr);                                                      \
+        break;
+    switch (k) {
+        BBB_PRBS_CASE(7) BBB_PRBS_CASE(9) BBB_PRBS_CASE(11) BBB_PRBS_CASE(15)
+        BBB_PRBS_CASE(20) BBB_PRBS_CASE(23) BBB_PRBS_CASE(31)
+    }
+#undef BBB_PRBS_CASE
+    BBB_HIP(hipGetLastError());
+    return BBB_OK;
 }
 
 template <bool CHECK>
@@ -239,27 +313,8 @@ static int launch_stream(int k, u64 init_state, u64 first_bit, u64 nbits, u64 *b
     if (first_bit + nbits < first_bit) return fail(BBB_EINVAL, "first_bit + nbits overflows");
     int rc = upload_pow_table(k);
     if (rc) return rc;
-    const u64 nwords = (nbits + 63) / 64;
-    const u64 rows = (nwords + 127) / 128;
-    const u64 target_waves = 256 * 5;
-    u64 rpw = (rows + target_waves - 1) / target_waves;
-    const u64 min_rpw = 8 * (u64)k;
-    if (rpw < min_rpw) rpw = min_rpw;
-    const u64 nblocks = (rows + rpw - 1) / rpw;
-    if (nblocks > 0x7fffffffull) return fail(BBB_EINVAL, "nbits too large");
-    dim3 grid((unsigned)nblocks), block(64);
-#define BBB_PRBS_CASE(KK)                                                                                    \
-    case KK:                                                                                                 \
-        hipLaunchKernelGGL((prbs_stream_kernel<KK, CHECK>), grid, block, 0, st, ki, init_state, first_bit,   \
-                           nbits, nwords, rpw, buf, nerr);                                                   \
-        break;
-    switch (k) {
-        BBB_PRBS_CASE(7) BBB_PRBS_CASE(9) BBB_PRBS_CASE(11) BBB_PRBS_CASE(15)
-        BBB_PRBS_CASE(20) BBB_PRBS_CASE(23) BBB_PRBS_CASE(31)
-    }
-#undef BBB_PRBS_CASE
-    BBB_HIP(hipGetLastError());
-    return BBB_OK;
+    return prbs_wpl(CHECK) == 1 ? launch_stream_w<CHECK, 1>(k, ki, init_state, first_bit, nbits, buf, nerr, st)
+                                : launch_stream_w<CHECK, 2>(k, ki, init_state, first_bit, nbits, buf, nerr, st);
 }
 
 int prbs_fill_launch(int k, uint64_t init_state, uint64_t first_bit, uint64_t nbits, uint64_t *dst, hipStream_t st) {

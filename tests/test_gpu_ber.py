@@ -39,6 +39,25 @@ def test_trial_offsets_and_sizes(gpu, oracle, nbits, first, warm):
     assert (bits, errs) == oracle_trial(oracle, t, init=0xABCDEF0123456789)
 
 
+def test_grouped_trials_equal_individual_trials(gpu, oracle):
+    """Trials that share one noise/PRBS stream are evaluated in one pass (up to 12 per launch); the
+    counters must equal those of the same trials run one at a time, and the oracle's."""
+    u = gpu.LUTOPT.shipped(256)
+    chan = [(0, 15), (64, 8), (91, 8), (300, 9), (2047, 15), (1900, 15), (500, 0), (1, 1), (181, 15), (128, 8),
+            (143, 8), (161, 8), (203, 8), (286, 8)]                       # 14 -> one group of 12 and one of 2
+    ts = [gpu.Trial(nbits=120_001, amp=a, noise_var=nv, prbs_k=15, first_bit=777) for a, nv in chan]
+    grouped = gpu.run_trials(u, ts)
+    single = [gpu.run_trials(u, [t])[0] for t in ts]
+    assert grouped == single
+    for i in (0, 4, 5, 13):
+        assert grouped[i] == oracle_trial(oracle, ts[i])
+    # a different stream in the middle splits the groups but changes nothing else
+    mixed = ts[:3] + [gpu.Trial(nbits=5000, amp=90, noise_var=8, prbs_k=7)] + ts[3:6]
+    res = gpu.run_trials(u, mixed)
+    assert res[:3] == grouped[:3] and res[4:] == grouped[3:6]
+    assert res[3] == oracle_trial(oracle, mixed[3])
+
+
 def test_split_trial_sums_to_whole(gpu):
     """Counters are additive over disjoint bit ranges: what sharding across GPUs relies on."""
     u = gpu.LUTOPT.shipped(256)
