@@ -265,11 +265,22 @@ int ber_run(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, unsigned long lo
     // streams.  The counters are identical to running them one by one.
     for (int i = 0; i < ncfg;) {
         const bbb_trial_cfg &c = cfgs[i];
+        // only settings with one decision threshold per bit value can share a launch (the
+        // straight-line kernel); 12-bit wrap-around settings run alone on the general kernel
+        auto single = [&](int idx) {
+            const TrialDev &t = td[(size_t)idx];
+            for (int bv = 0; bv < 2; bv++) {
+                int real = 0;                       // thresholds strictly inside (0, 256)
+                for (int j = 0; j < t.nthr[bv]; j++) real += t.thr[bv][j] > 0 && t.thr[bv][j] < 256;
+                if (real != 1) return false;
+            }
+            return true;
+        };
         int n = 1;
-        while (i + n < ncfg && n < BBB_BER_MAX_GROUP) {
+        while (single(i) && i + n < ncfg && n < BBB_BER_MAX_GROUP) {
             const bbb_trial_cfg &d = cfgs[i + n];
             if (d.prbs_k != c.prbs_k || d.prbs_state != c.prbs_state || d.warmup != c.warmup ||
-                d.first_bit != c.first_bit || d.nbits != c.nbits)
+                d.first_bit != c.first_bit || d.nbits != c.nbits || !single(i + n))
                 break;
             n++;
         }

@@ -48,9 +48,16 @@ __device__ __forceinline__ uint32_t ge_thr(const uint32_t (&T)[8], int thr) {
     return ge;
 }
 
+// GENERAL = true : one channel setting per launch, any number (<= 4) of thresholds per bit value
+//                  (12-bit wrap-around cases).
+// GENERAL = false: up to kMaxCfg settings per launch, each with exactly ONE threshold per bit value
+//                  plus an optional complement (every non-wrapping channel: bit 0 errs when
+//                  T >= thr0, bit 1 when T < thr1): straight-line code, ~36 issue slots each.
+template <bool GENERAL>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 ber256_kernel(const uint32_t *__restrict planes, const uint32_t *__restrict prbs_planes, TrialK tk, unsigned nlanes,
               unsigned long long *__restrict counters) {
+    constexpr int NC = GENERAL ? 1 : kMaxCfg;
     __shared__ uint32_t PR[32 * 64];          // PRBS state planes, circular: slot (head + i) % k = state bit i
     const unsigned lane = threadIdx.x;
     const unsigned long long wave = blockIdx.x;
@@ -68,11 +75,19 @@ ber256_kernel(const uint32_t *__restrict planes, const uint32_t *__restrict prbs
         if (g < tk.G) vm_all |= 1u << j;
         if (g + 1 == tk.G) vm_last |= 1u << j;
     }
-    uint32_t nerr[kMaxCfg];
+    uint32_t nerr[NC];
 #pragma unroll
-    for (int c = 0; c < kMaxCfg; c++) nerr[c] = 0;
+    for (int c = 0; c < NC; c++) nerr[c] = 0;
     uint32_t nbit = 0;
     int head = 0;
+    // thresholds of the simple path, as scalars
+    int thr0[NC], thr1[NC];
+    uint32_t inv0[NC], inv1[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        thr0[c] = tk.thr[c][0][0]; thr1[c] = tk.thr[c][1][0];
+        inv0[c] = tk.inv[c][0] ? ~0u : 0u; inv1[c] = tk.inv[c][1] ? ~0u : 0u;
+    }
 
     auto consume = [&](unsigned t) {
         // PRBS: bit = s[k-1] ^ s[tap-1]; shift in at position 0 (prbs.py:34-35)
@@ -88,13 +103,19 @@ ber256_kernel(const uint32_t *__restrict planes, const uint32_t *__restrict prbs
         T[7] = ~cnt[7];
         const uint32_t valid = t < tk.last_len ? vm_all : (vm_all & ~vm_last);
         nbit += __builtin_popcount(valid);
+        if (GENERAL) {
+            uint32_t e0 = tk.inv[0][0] ? ~0u : 0u, e1 = tk.inv[0][1] ? ~0u : 0u;
+            for (int i = 0; i < tk.nthr[0][0]; i++) e0 ^= ge_thr(T, tk.thr[0][0][i]);
+            for (int i = 0; i < tk.nthr[0][1]; i++) e1 ^= ge_thr(T, tk.thr[0][1][i]);
+            nerr[0] += __builtin_popcount(((pb & e1) | (~pb & e0)) & valid);
+        } else {
+            const uint32_t pv1 = pb & valid, pv0 = ~pb & valid;
 #pragma unroll
-        for (int c = 0; c < kMaxCfg; c++) {
-            if (c < tk.ncfg) {
-                uint32_t e0 = tk.inv[c][0] ? ~0u : 0u, e1 = tk.inv[c][1] ? ~0u : 0u;
-                for (int i = 0; i < tk.nthr[c][0]; i++) e0 ^= ge_thr(T, tk.thr[c][0][i]);
-                for (int i = 0; i < tk.nthr[c][1]; i++) e1 ^= ge_thr(T, tk.thr[c][1][i]);
-                nerr[c] += __builtin_popcount(((pb & e1) | (~pb & e0)) & valid);
+            for (int c = 0; c < NC; c++) {
+                if (c < tk.ncfg) {
+                    const uint32_t e0 = ge_thr(T, thr0[c]) ^ inv0[c], e1 = ge_thr(T, thr1[c]) ^ inv1[c];
+                    nerr[c] += __builtin_popcount((pv1 & e1) | (pv0 & e0));
+                }
             }
         }
     };
@@ -111,7 +132,7 @@ ber256_kernel(const uint32_t *__restrict planes, const uint32_t *__restrict prbs
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) b64 += __shfl_xor(b64, off, 64);
 #pragma unroll
-    for (int c = 0; c < kMaxCfg; c++) {
+    for (int c = 0; c < NC; c++) {
         if (c < tk.ncfg) {
             unsigned long long e64 = nerr[c];
 #pragma unroll
@@ -147,8 +168,18 @@ int ber256_launch(const uint32_t *d_planes, const uint32_t *d_prbs_planes, const
             tk.nthr[c][bv] = (int8_t)n;
             tk.inv[c][bv] = (int8_t)inv;
         }
-    hipLaunchKernelGGL(ber256_kernel, dim3(nlanes / 64), dim3(64), 0, st, d_planes, d_prbs_planes, tk, nlanes,
-                       d_counters);
+    // the straight-line multi-setting kernel needs exactly one threshold per bit value
+    bool simple = true;
+    for (int c = 0; c < ncfg; c++)
+        for (int bv = 0; bv < 2; bv++) simple = simple && tk.nthr[c][bv] == 1;
+    if (simple)
+        hipLaunchKernelGGL(ber256_kernel<false>, dim3(nlanes / 64), dim3(64), 0, st, d_planes, d_prbs_planes, tk, nlanes,
+                           d_counters);
+    else if (ncfg == 1)
+        hipLaunchKernelGGL(ber256_kernel<true>, dim3(nlanes / 64), dim3(64), 0, st, d_planes, d_prbs_planes, tk, nlanes,
+                           d_counters);
+    else
+        return fail(BBB_EINVAL, "grouped trials must be single-threshold");
     BBB_HIP(hipGetLastError());
     return BBB_OK;
 }

@@ -118,7 +118,9 @@ __device__ __forceinline__ void xor_inplace(u32x4 &a, const u32x4 &b) {
     asm("v_xor_b32 %0, %0, %1" : "+v"(a.w) : "v"(b.w));
 }
 
-template <int K, bool CHECK, int WPL>
+// LW = true keeps the K-row window in (lane-private) LDS instead of registers: the checker then
+// only holds its in-flight loads in registers and can use 16-byte accesses without spilling.
+template <int K, bool CHECK, int WPL, bool LW>
 __global__ void __launch_bounds__(64, 2)   // >= 2 waves per SIMD: at most 256 registers
 prbs_stream_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwords, u64 rows_per_wave,
                    u64 *__restrict buf, u64 *__restrict nerr) {
@@ -134,9 +136,15 @@ prbs_stream_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwords,
     if (word0 >= nwords) return;
     const PrbsPowTable &pw = d_prbs_pow[ki];
 
-    // 1. LFSR state at the first bit of this region: s = T^(t0) * init (lane r evaluates row r).
-    //    The candidate rows are fetched 16 at a time (four memory round trips, not one per set bit).
-    const u64 t0 = first_bit + word0 * 64;
+    // 1. LFSR state at the first bit of the K rows that PRECEDE this region (so that every pass of
+    //    the main loop, including the first, is "advance the window by K rows, then emit").  The
+    //    sequence has period 2^K - 1 (maximal length), which extends it to negative positions.
+    //    s = T^(t0) * init, lane r evaluating row r; the candidate rows of T^(2^i) are fetched 16 at
+    //    a time (four memory round trips, not one per set bit).
+    constexpr u64 PERIOD = (1ull << K) - 1ull;
+    constexpr u64 BACK = (u64)K * RW * 64;                       // bits in K rows
+    constexpr u64 WRAP = ((BACK + PERIOD - 1) / PERIOD) * PERIOD;  // multiple of the period >= BACK
+    const u64 t0 = (first_bit % PERIOD) + (word0 * 64) % PERIOD + (WRAP - BACK);
     uint32_t s = (uint32_t)init_state;
 #pragma unroll 1
     for (int i0 = 0; i0 < 64; i0 += 16) {
@@ -183,10 +191,14 @@ prbs_stream_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwords,
             }
         }
     }
-    // 4. register window: V[q] = this lane's words of row q, q < K.
-    lw_t V[K];
+    // 4. register window: V[q] = this lane's words of row q, q < K (LW: stays in LDS, row q of
+    //    this lane at Xv[q*64 + lane]).
+    lw_t *Xv = reinterpret_cast<lw_t *>(X);
+    lw_t V[LW ? 1 : K];
+    if (!LW) {
 #pragma unroll
-    for (int q = 0; q < K; q++) V[q] = *reinterpret_cast<const lw_t *>(&X[q * RW + WPL * lane]);
+        for (int q = 0; q < K; q++) V[q] = Xv[q * 64 + lane];
+    }
 
     const u64 rows_total = (nwords - word0 + RW - 1) / RW;
     const u64 nrows = rows_total < rows_per_wave ? rows_total : rows_per_wave;
@@ -194,29 +206,63 @@ prbs_stream_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwords,
     const u64 last_mask = (nbits & 63) ? ((1ull << (nbits & 63)) - 1ull) : ~0ull;
     u64 errs = 0;
 
+    constexpr int DB = WPL == 2 ? 4 : 16;               // rows per batch of loads (checker)
+    constexpr int NB = (K + DB - 1) / DB;
     for (u64 q0 = 0; q0 < nrows; q0 += K) {
         const u64 wbase = word0 + q0 * RW + (u64)(WPL * lane);
         u64 *rowp = buf + (word0 + q0 * RW);      // wave-uniform row base: scalar base + lane offset addressing
         // fast path: all K rows of this pass lie strictly below the stream's last word --
-        // no bounds or tail-mask logic, K independent accesses per lane
+        // no bounds or tail-mask logic
         if (q0 + K <= nrows && word0 + (q0 + K) * RW <= last_word) {
             if (CHECK) {
-                lw_t D[K];
+                // loads run one batch ahead of the compares (two register batches, static indices)
+                lw_t D[2][DB];
 #pragma unroll
-                for (int i = 0; i < K; i++) D[i] = reinterpret_cast<const lw_t *>(rowp + (u64)i * RW)[lane];
-                if (q0 > 0) {
+                for (int i = 0; i < DB && i < K; i++) D[0][i] = reinterpret_cast<const lw_t *>(rowp + (u64)i * RW)[lane];
+                // LW: the window makes one LDS round trip per pass (K reads issued back to back, the
+                // in-place recurrence in registers, K writes) so that no register state is carried
+                // around the loop
+                lw_t W[LW ? K : 1];
+                if (LW) {
 #pragma unroll
-                    for (int i = 0; i < K; i++) xor_inplace(V[i], V[(i - TAP + K) % K]);
-                }
-                uint32_t e32 = 0;
+                    for (int i = 0; i < K; i++) W[i] = Xv[i * 64 + lane];
 #pragma unroll
-                for (int i = 0; i < K; i++) e32 += popc_words(D[i] ^ V[i]);
-                errs += e32;
-            } else {
-                if (q0 > 0) {
+                    for (int i = 0; i < K; i++) W[i] ^= W[(i - TAP + K) % K];
+#pragma unroll
+                    for (int i = 0; i < K; i++) Xv[i * 64 + lane] = W[i];
+                } else {
 #pragma unroll
                     for (int i = 0; i < K; i++) xor_inplace(V[i], V[(i - TAP + K) % K]);   // row[q] = row[q-K] ^ row[q-TAP]
                 }
+                uint32_t e32 = 0;
+#pragma unroll
+                for (int bidx = 0; bidx < NB; bidx++) {
+                    if (bidx + 1 < NB) {
+#pragma unroll
+                        for (int i = 0; i < DB; i++)
+                            if ((bidx + 1) * DB + i < K)
+                                D[(bidx + 1) & 1][i] = reinterpret_cast<const lw_t *>(rowp + (u64)((bidx + 1) * DB + i) * RW)[lane];
+                    }
+#pragma unroll
+                    for (int i = 0; i < DB; i++) {
+                        const int r = bidx * DB + i;
+                        if (r < K) e32 += popc_words(D[bidx & 1][i] ^ (LW ? W[r] : V[r]));
+                    }
+                }
+                errs += e32;
+            } else if (LW) {
+                lw_t W[K];
+#pragma unroll
+                for (int i = 0; i < K; i++) W[i] = Xv[i * 64 + lane];
+#pragma unroll
+                for (int i = 0; i < K; i++) W[i] ^= W[(i - TAP + K) % K];
+#pragma unroll
+                for (int i = 0; i < K; i++) Xv[i * 64 + lane] = W[i];
+#pragma unroll
+                for (int i = 0; i < K; i++) reinterpret_cast<lw_t *>(rowp + (u64)i * RW)[lane] = W[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < K; i++) xor_inplace(V[i], V[(i - TAP + K) % K]);
 #pragma unroll
                 for (int i = 0; i < K; i++) reinterpret_cast<lw_t *>(rowp + (u64)i * RW)[lane] = V[i];
             }
@@ -224,12 +270,15 @@ prbs_stream_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwords,
         }
         // tail pass: per-word bounds and the mask of the final partial word; the window goes back
         // to LDS so that rows can be indexed at run time
-        if (q0 > 0) {
+        if (LW) {
+#pragma unroll
+            for (int i = 0; i < K; i++) Xv[i * 64 + lane] = Xv[i * 64 + lane] ^ Xv[((i - TAP + K) % K) * 64 + lane];
+        } else {
 #pragma unroll
             for (int i = 0; i < K; i++) xor_inplace(V[i], V[(i - TAP + K) % K]);
-        }
 #pragma unroll
-        for (int q = 0; q < K; q++) *reinterpret_cast<lw_t *>(&X[q * RW + WPL * lane]) = V[q];
+            for (int q = 0; q < K; q++) Xv[q * 64 + lane] = V[q];
+        }
 #pragma unroll 1
         for (int i = 0; i < K && q0 + i < nrows; i++) {
 #pragma unroll
@@ -265,7 +314,7 @@ static int prbs_wpl(bool check) {
     return v == 1 ? 1 : 2;
 }
 
-template <bool CHECK, int WPL>
+template <bool CHECK, int WPL, bool LW>
 static int launch_stream_w(int k, int ki, u64 init_state, u64 first_bit, u64 nbits, u64 *buf, u64 *nerr, hipStream_t st) {
     const u64 nwords = (nbits + 63) / 64;
     const u64 RW = 64 * WPL;
@@ -276,11 +325,14 @@ static int launch_stream_w(int k, int ki, u64 init_state, u64 first_bit, u64 nbi
     BBB_HIP(hipGetDevice(&dev));
     BBB_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
     const void *fn = nullptr;
-#define BBB_PRBS_FN(KK) case KK: fn = (const void *)prbs_stream_kernel<KK, CHECK, WPL>; break;
+#define BBB_PRBS_FN(KK) case KK: fn = (const void *)prbs_stream_kernel<KK, CHECK, WPL, LW>; break;
     switch (k) { BBB_PRBS_FN(7) BBB_PRBS_FN(9) BBB_PRBS_FN(11) BBB_PRBS_FN(15) BBB_PRBS_FN(20) BBB_PRBS_FN(23) BBB_PRBS_FN(31) }
 #undef BBB_PRBS_FN
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, 0) != hipSuccess || per_cu < 1) per_cu = 4;
-    static const int cap = std::getenv("BBB_PRBS_WAVES_PER_CU") ? std::atoi(std::getenv("BBB_PRBS_WAVES_PER_CU")) : 0;
+    // the generator is fastest with 4 waves per CU (stores need little latency hiding and fewer,
+    // longer regions amortise the bootstrap); the checker takes every wave it can get
+    static const int cap_env = std::getenv("BBB_PRBS_WAVES_PER_CU") ? std::atoi(std::getenv("BBB_PRBS_WAVES_PER_CU")) : -1;
+    const int cap = cap_env >= 0 ? cap_env : (CHECK ? 0 : 4);
     if (cap > 0 && per_cu > cap) per_cu = cap;
     const u64 target_waves = (u64)ncu * (u64)per_cu;
     u64 rpw = (rows + target_waves - 1) / target_waves;
@@ -291,7 +343,7 @@ static int launch_stream_w(int k, int ki, u64 init_state, u64 first_bit, u64 nbi
     dim3 grid((unsigned)nblocks), block(64);
 #define BBB_PRBS_CASE(KK)                                                                                       \
     case KK:                                                                                                    \
-        hipLaunchKernelGGL((prbs_stream_kernel<KK, CHECK, WPL>), grid, block, 0, st, ki, init_state, first_bit, \
+        hipLaunchKernelGGL((prbs_stream_kernel<KK, CHECK, WPL, LW>), grid, block, 0, st, ki, init_state, first_bit, \
                            nbits, nwords, rpw, buf, nerr);                                                      \
         break;
     switch (k) {
@@ -313,8 +365,16 @@ static int launch_stream(int k, u64 init_state, u64 first_bit, u64 nbits, u64 *b
     if (first_bit + nbits < first_bit) return fail(BBB_EINVAL, "first_bit + nbits overflows");
     int rc = upload_pow_table(k);
     if (rc) return rc;
-    return prbs_wpl(CHECK) == 1 ? launch_stream_w<CHECK, 1>(k, ki, init_state, first_bit, nbits, buf, nerr, st)
-                                : launch_stream_w<CHECK, 2>(k, ki, init_state, first_bit, nbits, buf, nerr, st);
+    // generator: register window; checker: window parked in LDS between passes; 8-byte accesses
+    // (both measured: profiles/r01_prbs_sweep.log)
+    static const int lw_fill = std::getenv("BBB_PRBS_FILL_LW") ? std::atoi(std::getenv("BBB_PRBS_FILL_LW")) : 0;
+    static const int lw_chk = std::getenv("BBB_PRBS_CHECK_LW") ? std::atoi(std::getenv("BBB_PRBS_CHECK_LW")) : 1;
+    const bool lw = CHECK ? lw_chk != 0 : lw_fill != 0;
+    if (prbs_wpl(CHECK) == 1)
+        return lw ? launch_stream_w<CHECK, 1, true>(k, ki, init_state, first_bit, nbits, buf, nerr, st)
+                  : launch_stream_w<CHECK, 1, false>(k, ki, init_state, first_bit, nbits, buf, nerr, st);
+    return lw ? launch_stream_w<CHECK, 2, true>(k, ki, init_state, first_bit, nbits, buf, nerr, st)
+              : launch_stream_w<CHECK, 2, false>(k, ki, init_state, first_bit, nbits, buf, nerr, st);
 }
 
 int prbs_fill_launch(int k, uint64_t init_state, uint64_t first_bit, uint64_t nbits, uint64_t *dst, hipStream_t st) {

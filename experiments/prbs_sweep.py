@@ -16,8 +16,13 @@ if len(sys.argv) > 1:
         torch.cuda.synchronize(); g += e[0].elapsed_time(e[1]); c += e[1].elapsed_time(e[2])
     print(json.dumps({"cfg": sys.argv[1], "errors": n0, "gen_TBs": nbits/8*5/g/1e9, "chk_TBs": nbits/8*5/c/1e9}))
 else:
-    for fw in (1, 2):
-        for cw in (1, 2):
-            for cap in (0, 4, 6, 8):
-                env = dict(os.environ, BBB_PRBS_FILL_WPL=str(fw), BBB_PRBS_CHECK_WPL=str(cw), BBB_PRBS_WAVES_PER_CU=str(cap))
-                subprocess.run([sys.executable, __file__, f"fill_wpl={fw} check_wpl={cw} cap={cap}"], env=env)
+    def run(tag, **kv):
+        env = dict(os.environ, **{k: str(v) for k, v in kv.items()})
+        subprocess.run([sys.executable, __file__, tag + " " + " ".join(f"{k[9:]}={v}" for k, v in kv.items())], env=env)
+    for cap in (0, 4, 8):
+        for wpl in (1, 2):
+            for lw in (0, 1):
+                if wpl == 2 and lw == 0:
+                    continue            # spills to scratch: known slow
+                run("FILL ", BBB_PRBS_FILL_WPL=wpl, BBB_PRBS_FILL_LW=lw, BBB_PRBS_WAVES_PER_CU=cap)
+                run("CHECK", BBB_PRBS_CHECK_WPL=wpl, BBB_PRBS_CHECK_LW=lw, BBB_PRBS_WAVES_PER_CU=cap)

@@ -65,7 +65,42 @@ def row_order(n, taps):
     return order
 
 
-def generate(n, taps):
+def plan_parking(n, taps, order, npark, lookahead):
+    """Choose `npark` groups of 4 consecutively computed rows whose planes are parked in LDS between
+    their birth (step s) and shortly before their first use (step s+1).
+
+    Returns (groups, reload_at, store_at): groups[g] = 4 plane indices; reload_at[pos] / store_at[pos]
+    = group ids whose ds_read_b128 is emitted before / whose ds_write_b128 is emitted after the row
+    at schedule position pos.  A group is only eligible if its reload precedes its store within a
+    step (one LDS slot per group, no double buffering)."""
+    pos = {r: i for i, r in enumerate(order)}
+    first_use = [n] * n
+    for r in range(n):
+        for c in taps[r]:
+            first_use[c] = min(first_use[c], pos[r])
+    cands = []
+    for j in range(n // 4):
+        members = order[4 * j: 4 * j + 4]
+        f = min(first_use[p] for p in members)
+        reload_pos = max(0, f - lookahead)
+        store_pos = 4 * j + 3
+        if reload_pos > store_pos:
+            continue
+        # register-time saved: from the store to the end of the step, plus from the start of the
+        # next step to the reload, for each of the four planes
+        saved = 4 * ((n - store_pos) + reload_pos)
+        cands.append((saved, j, members, reload_pos, store_pos))
+    cands.sort(reverse=True)
+    chosen = cands[:npark]
+    groups, reload_at, store_at = [], {}, {}
+    for g, (_, j, members, rp, sp) in enumerate(chosen):
+        groups.append(members)
+        reload_at.setdefault(rp, []).append(g)
+        store_at.setdefault(sp, []).append(g)
+    return groups, reload_at, store_at
+
+
+def generate(n, taps, npark=0, lookahead=6):
     logn = n.bit_length() - 1
     assert 1 << logn == n and n >= 16
     out = []
@@ -100,12 +135,29 @@ def generate(n, taps):
             levels[level].append((s, 0))
 
     emit(f"// GENERATED by tools/gen_lutopt_kernel.py from lutopt_{n}.txt -- do not edit.")
-    emit(f"// matrix crc32 of the packed taps: see LUTOPT{n}_TAPS_CRC")
     flat = ",".join(",".join(map(str, t)) for t in taps)
-    emit(f"#define LUTOPT{n}_TAPS_CRC 0x{zlib.crc32(flat.encode()) & 0xffffffff:08x}u")
-    emit(f"static __device__ __forceinline__ void lutopt{n}_step(const uint32_t (&a)[{n}], uint32_t (&b)[{n}], uint32_t (&cnt)[{logn}])")
+    if not npark:
+        emit(f"#define LUTOPT{n}_TAPS_CRC 0x{zlib.crc32(flat.encode()) & 0xffffffff:08x}u")
+    order = row_order(n, taps)
+    groups, reload_at, store_at = plan_parking(n, taps, order, npark, lookahead) if npark else ([], {}, {})
+    fn = f"lutopt{n}p" if npark else f"lutopt{n}"
+    if npark:
+        emit(f"#define LUTOPT{n}_NPARK {len(groups)}")
+        emit(f"typedef uint32_t lutopt{n}_v4 __attribute__((ext_vector_type(4)));")
+        emit(f"// park[g*64 + lane] holds planes {{p0,p1,p2,p3}} of group g between a step and the next")
+        emit(f"static __device__ __forceinline__ void {fn}_park_init(const uint32_t (&a)[{n}], lutopt{n}_v4 *park, unsigned lane)")
+        emit("{")
+        for g, m in enumerate(groups):
+            emit(f"  park[{g} * 64 + lane] = (lutopt{n}_v4){{a[{m[0]}], a[{m[1]}], a[{m[2]}], a[{m[3]}]}};")
+        emit("}")
+        emit(f"static __device__ __forceinline__ void {fn}_step(uint32_t (&a)[{n}], uint32_t (&b)[{n}], uint32_t (&cnt)[{logn}], lutopt{n}_v4 *park, unsigned lane)")
+    else:
+        emit(f"static __device__ __forceinline__ void lutopt{n}_step(const uint32_t (&a)[{n}], uint32_t (&b)[{n}], uint32_t (&cnt)[{logn}])")
     emit("{")
-    for r in row_order(n, taps):
+    for position, r in enumerate(order):
+        for g in reload_at.get(position, []):
+            m = groups[g]
+            emit(f"  {{ const lutopt{n}_v4 pk = park[{g} * 64 + lane]; a[{m[0]}] = pk.x; a[{m[1]}] = pk.y; a[{m[2]}] = pk.z; a[{m[3]}] = pk.w; }}")
         t = taps[r]
         assert 1 <= len(t) <= 8
         # XOR the taps three at a time (V_BITOP3 0x96), then pairs
@@ -131,6 +183,9 @@ def generate(n, taps):
             emit(f"  b[{r}] = {terms[0]};")
         inv = bin(r).count("1") & 1     # weight -1 positions enter the counter complemented
         push(0, (f"b[{r}]", inv))
+        for g in store_at.get(position, []):
+            m = groups[g]
+            emit(f"  park[{g} * 64 + lane] = (lutopt{n}_v4){{b[{m[0]}], b[{m[1]}], b[{m[2]}], b[{m[3]}]}};")
     # ---- finish the counter: ripple the leftovers up ------------------------------------
     for lev in range(nlev):
         while len(levels[lev]) > 1:
@@ -155,17 +210,20 @@ def generate(n, taps):
             emit(f"  cnt[{lev}] = {x};")
     emit("}")
     emit(f"// {nops} VALU ops per step for 32 samples per lane")
-    # packed taps for the host-side identity check
-    emit(f"static const uint16_t LUTOPT{n}_NTAPS[{n}] = {{{','.join(str(len(t)) for t in taps)}}};")
-    emit(f"static const uint16_t LUTOPT{n}_TAPS[{sum(len(t) for t in taps)}] = {{{flat}}};")
+    if not npark:
+        # packed taps for the host-side identity check
+        emit(f"static const uint16_t LUTOPT{n}_NTAPS[{n}] = {{{','.join(str(len(t)) for t in taps)}}};")
+        emit(f"static const uint16_t LUTOPT{n}_TAPS[{sum(len(t) for t in taps)}] = {{{flat}}};")
     return "\n".join(out) + "\n", nops
 
 
 def main():
     n, taps = load(sys.argv[1])
-    text, nops = generate(n, taps)
+    npark = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    lookahead = int(sys.argv[4]) if len(sys.argv) > 4 else 6
+    text, nops = generate(n, taps, npark, lookahead)
     open(sys.argv[2], "w").write(text)
-    print(f"n={n}: {nops} ops/step -> {sys.argv[2]}")
+    print(f"n={n}: {nops} ops/step, {npark} parked groups -> {sys.argv[2]}")
 
 
 if __name__ == "__main__":
