@@ -13,7 +13,7 @@
 // instructions (tools/gen_lutopt_kernel.py emits the straight-line network for the matrix).
 //
 // Kernels
-//   seed_levels_kernel   start states by doubling: S[2^d + i] = (A^L)^(2^d) * S[i]
+//   seed_first/level_kernel  start states, radix 4: S[j*4^e + i] = (A^L)^(j*4^e) * S[i]
 //   bitslice_kernel      [G][k bits] -> planes [k][lanes] (32x32 bit transposes)
 //   awgn256_kernel       the hot kernel (n256 matrix of gateware/bbb/rng_recurrences.py:172-259)
 //   awgn_generic_kernel  any k <= 512 / any taps, table driven, planes in global scratch
@@ -29,82 +29,103 @@
 namespace bbb {
 
 // ---------------------------------------------------------------------------------------------
-// Start states by doubling: level d maps the first 2^d states through B_d = (A^L)^(2^d),
-//     S[2^d + i] = B_d * S[i].
-// y = B x is evaluated four state bits at a time: tabs holds, per level and per nibble position n,
-// the 16 XOR-combinations of columns 4n..4n+3 of B_d ([level][k/4][16][W32] words, built on the
-// host).  A block stages its level's table in LDS (32 KiB for k = 256) and every lane does k/4
-// lookups of W32 words.  States are stored word-major, S[w * stride + g], so that both this kernel
-// and the bit-slicing pass touch consecutive addresses from consecutive lanes.
-// ---------------------------------------------------------------------------------------------
-struct State16 { uint32_t w[16]; };
-
-// Table layout: a nibble entry of W32 words is cut into chunks of C = min(W32, 4) words (one
-// ds_read_b128 each for C = 4); chunk zc of all 16 entries of nibble n is contiguous:
+// Start states: S[g] = B^g * s0 with B = A^L, built radix 4.  Level e maps the first 4^e states
+// through B^(j*4^e), j = 1..3:   S[j*4^e + i] = B^(j*4^e) * S[i].
+// y = M x is evaluated four state bits at a time: a table holds, per nibble position n, the 16
+// XOR-combinations of columns 4n..4n+3 of M ([k/4][chunks][16][C] words, built on the host, one
+// table per (level, j)).  The big levels stage their table in LDS (32 KiB for k = 256) and every
+// lane does k/4 lookups of W32 words; the first 256 states are produced by one block straight from
+// the tables in global memory (each lane composes up to four jumps from the base-4 digits of its
+// index).  States are stored word-major, S[w * stride + g], so that this kernel and the
+// bit-slicing pass touch consecutive addresses from consecutive lanes.
+//
+// Table layout: an entry of W32 words is cut into chunks of C = min(W32, 4) words (one 16-byte
+// access each for C = 4); chunk zc of all 16 entries of nibble n is contiguous:
 //   index(n, v, zc, zz) = ((n * (W32/C) + zc) * 16 + v) * C + zz
-// so the 16 possible 16-byte reads of one (n, zc) cover 256 consecutive bytes = every LDS bank
-// once: lanes reading different entries never conflict, lanes reading the same entry broadcast.
-template <int W32>
-__global__ void __launch_bounds__(256)
-seed_levels_kernel(const uint32_t *__restrict tabs, int k, State16 s0, int d0, int d1, unsigned long long G,
-                   unsigned long long stride, uint32_t *__restrict S) {
+// so the 16 possible 16-byte LDS reads of one (n, zc) cover 256 consecutive bytes = every bank once:
+// lanes reading different entries never conflict, lanes reading the same entry broadcast.
+// ---------------------------------------------------------------------------------------------
+
+template <int W32, typename TabPtr>
+__device__ __forceinline__ void nibble_matvec(TabPtr tab, int nnib, const uint32_t (&x)[W32], uint32_t (&out)[W32]) {
     constexpr int C = W32 < 4 ? W32 : 4;
     constexpr int NC = W32 / C;
     typedef uint32_t chunk_t __attribute__((ext_vector_type(C)));
-    extern __shared__ __attribute__((aligned(16))) uint32_t tab[];
-    const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int nnib = (k + 3) / 4;
-    const int nt = nnib * 16 * W32;            // words; a multiple of 4 for every supported k
-    if (d0 == 0 && tid == 0) {
+    chunk_t y[NC];
 #pragma unroll
-        for (int w = 0; w < W32; w++) S[w * stride] = s0.w[w];
+    for (int zc = 0; zc < NC; zc++) y[zc] = (chunk_t)(0);
+#pragma unroll
+    for (int w = 0; w < W32; w++) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int n = w * 8 + q;
+            if (n < nnib) {
+                const uint32_t v = (x[w] >> (4 * q)) & 15u;
+#pragma unroll
+                for (int zc = 0; zc < NC; zc++)
+                    y[zc] ^= *reinterpret_cast<const chunk_t *>(tab + ((n * NC + zc) * 16 + v) * C);
+            }
+        }
     }
-    for (int d = d0; d < d1; d++) {
-        __syncthreads();
-        {   // stage this level's table: 16-byte loads, eight in flight per lane
-            typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-            const u4 *src = reinterpret_cast<const u4 *>(tabs + (size_t)d * nt);
-            u4 *dst = reinterpret_cast<u4 *>(tab);
-            const int n4 = nt / 4;
-            for (int base = 0; base < n4; base += 8 * 256) {
-                u4 v[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int i = base + u * 256 + (int)threadIdx.x;
-                    if (i < n4) v[u] = src[i];
-                }
+    for (int w = 0; w < W32; w++) out[w] = y[w / C][w % C];
+}
+
+// states 0..15 come from the host (15 sequential products with B: microseconds, overlapped with
+// the previous launch); this kernel only stores them
+struct Seed16 { uint32_t w[16][16]; };     // [state][word]; only the first W32 words of each are used
+template <int W32>
+__global__ void __launch_bounds__(64)
+seed_store16_kernel(Seed16 s, unsigned long long G, unsigned long long stride, uint32_t *__restrict S) {
+    const unsigned i = threadIdx.x;
+    if (i >= 16 || i >= G) return;
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int i = base + u * 256 + (int)threadIdx.x;
-                    if (i < n4) dst[i] = v[u];
-                }
+    for (int w = 0; w < W32; w++) S[w * stride + i] = s.w[i][w];
+}
+
+// level e: blockIdx.y = j - 1
+template <int W32>
+__global__ void __launch_bounds__(256)
+seed_level_kernel(const uint32_t *__restrict tabs, int k, int e, unsigned long long G, unsigned long long stride,
+                  uint32_t *__restrict S) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t tab[];
+    const unsigned long long lo = 1ull << (2 * e);
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned j = blockIdx.y + 1;
+    const unsigned long long dst = (unsigned long long)j * lo + i;
+    const unsigned long long blk0 = (unsigned long long)j * lo + (unsigned long long)blockIdx.x * blockDim.x;
+    if (blk0 >= G) return;                       // whole block beyond the last generator
+    const int nnib = (k + 3) / 4;
+    const int nt = nnib * 16 * W32;              // words; a multiple of 4 for every supported k
+    const bool active = i < lo && dst < G;
+    uint32_t x[W32];
+#pragma unroll
+    for (int w = 0; w < W32; w++) x[w] = active ? S[w * stride + i] : 0u;   // in flight while the table is staged
+    {
+        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+        const u4 *src = reinterpret_cast<const u4 *>(tabs + ((size_t)e * 3 + (j - 1)) * nt);
+        u4 *dstp = reinterpret_cast<u4 *>(tab);
+        const int n4 = nt / 4;
+        for (int base = 0; base < n4; base += 8 * 256) {
+            u4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int q = base + u * 256 + (int)threadIdx.x;
+                if (q < n4) v[u] = src[q];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int q = base + u * 256 + (int)threadIdx.x;
+                if (q < n4) dstp[q] = v[u];
             }
         }
-        __syncthreads();
-        const unsigned long long lo = 1ull << d;
-        if (tid < lo && lo + tid < G) {
-            uint32_t x[W32];
-            chunk_t y[NC];
+    }
+    __syncthreads();
+    if (active) {
+        uint32_t y[W32];
+        nibble_matvec<W32>(tab, nnib, x, y);
 #pragma unroll
-            for (int w = 0; w < W32; w++) x[w] = S[w * stride + tid];
-#pragma unroll
-            for (int zc = 0; zc < NC; zc++) y[zc] = (chunk_t)(0);
-#pragma unroll
-            for (int w = 0; w < W32; w++) {
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const int n = w * 8 + q;
-                    if (n < nnib) {
-                        const uint32_t v = (x[w] >> (4 * q)) & 15u;
-#pragma unroll
-                        for (int zc = 0; zc < NC; zc++)
-                            y[zc] ^= *reinterpret_cast<const chunk_t *>(tab + ((n * NC + zc) * 16 + v) * C);
-                    }
-                }
-            }
-#pragma unroll
-            for (int w = 0; w < W32; w++) S[w * stride + lo + tid] = y[w / C][w % C];
-        }
+        for (int w = 0; w < W32; w++) S[w * stride + dst] = y[w];
     }
 }
 
@@ -272,27 +293,25 @@ clt_tree_kernel(int nwords, const unsigned long long *__restrict states, unsigne
 // host launchers
 // ---------------------------------------------------------------------------------------------
 template <int W32>
-static int seed_and_slice(int k, const uint32_t *d_tabs, const uint32_t *s0, uint64_t G, uint32_t *d_states,
+static int seed_and_slice(int k, const uint32_t *d_tabs, const uint32_t *s16, uint64_t G, uint32_t *d_states,
                           uint64_t stride, unsigned nlanes, uint32_t *d_planes, hipStream_t st) {
-    State16 s;
-    for (int w = 0; w < 16; w++) s.w[w] = w < W32 ? s0[w] : 0u;
-    int levels = 0;
-    while ((1ull << levels) < G) levels++;
-    const int first = levels < 8 ? levels : 8;
+    Seed16 s;
+    for (int i = 0; i < 16; i++)
+        for (int w = 0; w < 16; w++) s.w[i][w] = w < W32 ? s16[i * 16 + w] : 0u;
+    int levels = 0;                                   // radix-4 levels needed: 4^levels >= G
+    while ((1ull << (2 * levels)) < G) levels++;
     const size_t lds = (size_t)((k + 3) / 4) * 16 * W32 * sizeof(uint32_t);
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
-        BBB_HIP(hipFuncSetAttribute((const void *)seed_levels_kernel<W32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        BBB_HIP(hipFuncSetAttribute((const void *)seed_level_kernel<W32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    // levels [0, first): one block of 256 threads (at most 128 sources per level); always launched
-    // (it also stores S[0])
-    hipLaunchKernelGGL((seed_levels_kernel<W32>), dim3(1), dim3(256), lds, st, d_tabs, k, s, 0, first,
-                       (unsigned long long)G, (unsigned long long)stride, d_states);
-    for (int d = first; d < levels; d++) {
-        const uint64_t n = 1ull << d;
-        hipLaunchKernelGGL((seed_levels_kernel<W32>), dim3((unsigned)((n + 255) / 256)), dim3(256), lds, st, d_tabs, k,
-                           s, d, d + 1, (unsigned long long)G, (unsigned long long)stride, d_states);
+    hipLaunchKernelGGL((seed_store16_kernel<W32>), dim3(1), dim3(64), 0, st, s, (unsigned long long)G,
+                       (unsigned long long)stride, d_states);
+    for (int e = 2; e < levels; e++) {               // levels 0 and 1 (states 1..15) were done on the host
+        const uint64_t n = 1ull << (2 * e);
+        hipLaunchKernelGGL((seed_level_kernel<W32>), dim3((unsigned)((n + 255) / 256), 3), dim3(256), lds, st, d_tabs, k, e,
+                           (unsigned long long)G, (unsigned long long)stride, d_states);
     }
     const uint64_t threads = (uint64_t)nlanes * (uint64_t)((k + 31) / 32);
     hipLaunchKernelGGL((bitslice_kernel<W32>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, d_states,
@@ -301,14 +320,14 @@ static int seed_and_slice(int k, const uint32_t *d_tabs, const uint32_t *s0, uin
     return BBB_OK;
 }
 
-int awgn_seed_launch(int k, const uint32_t *d_tabs, const uint32_t *s0, uint64_t G, uint32_t *d_states,
+int awgn_seed_launch(int k, const uint32_t *d_tabs, const uint32_t *s16, uint64_t G, uint32_t *d_states,
                      uint64_t stride, unsigned nlanes, uint32_t *d_planes, hipStream_t st) {
     switch ((k + 31) / 32) {
-    case 1: return seed_and_slice<1>(k, d_tabs, s0, G, d_states, stride, nlanes, d_planes, st);
-    case 2: return seed_and_slice<2>(k, d_tabs, s0, G, d_states, stride, nlanes, d_planes, st);
-    case 4: return seed_and_slice<4>(k, d_tabs, s0, G, d_states, stride, nlanes, d_planes, st);
-    case 8: return seed_and_slice<8>(k, d_tabs, s0, G, d_states, stride, nlanes, d_planes, st);
-    case 16: return seed_and_slice<16>(k, d_tabs, s0, G, d_states, stride, nlanes, d_planes, st);
+    case 1: return seed_and_slice<1>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st);
+    case 2: return seed_and_slice<2>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st);
+    case 4: return seed_and_slice<4>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st);
+    case 8: return seed_and_slice<8>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st);
+    case 16: return seed_and_slice<16>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st);
     default: return fail(BBB_EINVAL, "k must be a power of two in [16, 512]");
     }
 }

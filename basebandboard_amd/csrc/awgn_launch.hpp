@@ -4,9 +4,11 @@
 
 namespace bbb {
 
-// start states S[g] = B^g s0 (B given per doubling level as nibble-combination tables
-// [level][k/4][16][W32]) stored word-major with `stride` words per state word, and their bit planes
-int awgn_seed_launch(int k, const uint32_t *d_tabs, const uint32_t *s0, uint64_t G, uint32_t *d_states,
+// start states S[g] = B^g s0 (per radix-4 level e and digit j = 1..3 a nibble-combination table of
+// B^(j*4^e): [e][j-1][k/4 * 16 * W32]) stored word-major with `stride` words per state word, and
+// their bit planes
+// s16: the first 16 start states, [16][16] words (host computed)
+int awgn_seed_launch(int k, const uint32_t *d_tabs, const uint32_t *s16, uint64_t G, uint32_t *d_states,
                      uint64_t stride, unsigned nlanes, uint32_t *d_planes, hipStream_t st);
 int awgn256_fill_launch(const uint32_t *d_planes, int8_t *dst, uint64_t nsamples, unsigned L, uint64_t G,
                         unsigned nlanes, hipStream_t st);

@@ -32,7 +32,8 @@ int use_device(int device) {
 
 // device copy of the doubling matrices for one segment length L
 struct JumpPlan {
-    uint32_t *d_cols = nullptr;   // [levels][k/4][16][W32] nibble tables
+    GF2Mat B;                     // the per-generator jump itself (host copy, for the first 16 states)
+    uint32_t *d_cols = nullptr;   // [levels][3][k/4 * 16 * W32] nibble tables of M^(j*4^e)
     int levels = 0;
 };
 
@@ -82,50 +83,70 @@ int grow(uint32_t **p, size_t *cap, size_t need_words) {
     return BBB_OK;
 }
 
-// For d < levels: the 16 XOR-combinations of every group of four columns of M^(2^d), packed
-// [d][k/4][16][W32], uploaded to the device (y = M x then needs k/4 table lookups).
+// Nibble-combination table of one matrix (layout: see seed kernels in awgn_kernels.hip).
+void nibble_table(const GF2Mat &M, uint32_t *out) {
+    const int k = M.n, W32 = (k + 31) / 32, nnib = (k + 3) / 4;
+    const int C = W32 < 4 ? W32 : 4, NC = W32 / C;
+    std::vector<uint32_t> cols((size_t)k * W32, 0u);
+    for (int r = 0; r < k; r++) {
+        const uint64_t *row = M.row(r);
+        for (int w = 0; w < M.W; w++) {
+            uint64_t bits = row[w];
+            while (bits) {
+                const int c = (w << 6) + __builtin_ctzll(bits);
+                bits &= bits - 1;
+                cols[(size_t)c * W32 + (r >> 5)] |= 1u << (r & 31);
+            }
+        }
+    }
+    std::vector<uint32_t> ent(16 * (size_t)W32);
+    for (int n = 0; n < nnib; n++) {
+        std::fill(ent.begin(), ent.end(), 0u);
+        for (int v = 1; v < 16; v++) {
+            const int c = 4 * n + __builtin_ctz((unsigned)v);
+            for (int z = 0; z < W32; z++)
+                ent[(size_t)v * W32 + z] = ent[(size_t)(v & (v - 1)) * W32 + z] ^ (c < k ? cols[(size_t)c * W32 + z] : 0u);
+        }
+        for (int v = 0; v < 16; v++)
+            for (int z = 0; z < W32; z++)
+                out[(((size_t)n * NC + z / C) * 16 + v) * C + z % C] = ent[(size_t)v * W32 + z];
+    }
+}
+
+// Radix-4 jump plan of M: for e < levels and j = 1..3 the table of M^(j*4^e), packed
+// [e][j-1][table], uploaded to the device.
 int build_plan(const GF2Mat &M, int levels, JumpPlan *plan) {
     const int k = M.n, W32 = (k + 31) / 32, nnib = (k + 3) / 4;
-    std::vector<uint32_t> host((size_t)levels * nnib * 16 * W32, 0);
-    std::vector<uint32_t> cols((size_t)k * W32);
-    GF2Mat cur = M;
-    for (int d = 0; d < levels; d++) {
-        if (d) cur = cur.mul(cur);
-        std::fill(cols.begin(), cols.end(), 0u);
-        for (int r = 0; r < k; r++) {
-            const uint64_t *row = cur.row(r);
-            for (int w = 0; w < cur.W; w++) {
-                uint64_t bits = row[w];
-                while (bits) {
-                    const int c = (w << 6) + __builtin_ctzll(bits);
-                    bits &= bits - 1;
-                    cols[(size_t)c * W32 + (r >> 5)] |= 1u << (r & 31);
-                }
-            }
-        }
-        // entry (n, v) = XOR of the columns 4n+i with bit i of v set; stored chunked (see the
-        // layout comment at seed_levels_kernel): index ((n*NC + zc)*16 + v)*C + zz
-        const int C = W32 < 4 ? W32 : 4, NC = W32 / C;
-        std::vector<uint32_t> ent(16 * (size_t)W32);
-        for (int n = 0; n < nnib; n++) {
-            std::fill(ent.begin(), ent.end(), 0u);
-            for (int v = 1; v < 16; v++) {
-                const int c = 4 * n + __builtin_ctz((unsigned)v);
-                for (int z = 0; z < W32; z++)
-                    ent[(size_t)v * W32 + z] = ent[(size_t)(v & (v - 1)) * W32 + z] ^ (c < k ? cols[(size_t)c * W32 + z] : 0u);
-            }
-            for (int v = 0; v < 16; v++)
-                for (int z = 0; z < W32; z++)
-                    host[(size_t)d * nnib * 16 * W32 + (((size_t)n * NC + z / C) * 16 + v) * C + z % C] = ent[(size_t)v * W32 + z];
-        }
+    const size_t nt = (size_t)nnib * 16 * W32;
+    std::vector<uint32_t> host((size_t)levels * 3 * nt, 0);
+    GF2Mat m1 = M;                                   // M^(4^e)
+    for (int e = 0; e < levels; e++) {
+        if (e) { m1 = m1.mul(m1); m1 = m1.mul(m1); }
+        const GF2Mat m2 = m1.mul(m1), m3 = m2.mul(m1);
+        nibble_table(m1, &host[((size_t)e * 3 + 0) * nt]);
+        nibble_table(m2, &host[((size_t)e * 3 + 1) * nt]);
+        nibble_table(m3, &host[((size_t)e * 3 + 2) * nt]);
     }
     BBB_HIP(hipMalloc((void **)&plan->d_cols, host.size() * sizeof(uint32_t)));
     BBB_HIP(hipMemcpy(plan->d_cols, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     plan->levels = levels;
+    plan->B = M;
     return BBB_OK;
 }
 
-constexpr int kPlanLevels = 26;   // up to 2^26 generators
+// the first 16 start states B^i s0, packed [16][16] 32-bit words
+void first16(const JumpPlan &plan, const uint64_t *s0, uint32_t *out) {
+    const int W = plan.B.W;
+    uint64_t x[8];
+    std::memcpy(x, s0, sizeof(uint64_t) * (size_t)W);
+    std::memset(out, 0, sizeof(uint32_t) * 256);
+    for (int i = 0; i < 16; i++) {
+        if (i) plan.B.matvec(x, x);
+        for (int w = 0; w < 2 * W; w++) out[i * 16 + w] = (uint32_t)(x[w >> 1] >> (32 * (w & 1)));
+    }
+}
+
+constexpr int kPlanLevels = 13;   // radix 4: up to 4^13 = 2^26 generators
 
 int get_plan(bbb_lutopt *h, uint64_t L, JumpPlan **out) {
     auto it = h->plans.find(L);
@@ -176,10 +197,10 @@ int prepare_planes(bbb_lutopt *h, uint64_t first, uint64_t L, uint64_t G, unsign
     if ((rc = grow(&h->d_planes, &h->planes_cap, (size_t)2 * h->k * nlanes))) return rc;
     uint64_t s0[8];
     h->pw->apply(first, h->init, s0);
-    uint32_t s32[16] = {0};
-    for (int w = 0; w < h->W32; w++) s32[w] = (uint32_t)(s0[w >> 1] >> (32 * (w & 1)));
+    uint32_t s16[256];
+    first16(*plan, s0, s16);
     h->planes_valid = false;
-    rc = awgn_seed_launch(h->k, plan->d_cols, s32, G, h->d_states, G, nlanes, h->d_planes, h->stream);
+    rc = awgn_seed_launch(h->k, plan->d_cols, s16, G, h->d_states, G, nlanes, h->d_planes, h->stream);
     if (rc) return rc;
     h->planes_valid = true;
     h->planes_first = first; h->planes_L = L; h->planes_G = G;
@@ -298,8 +319,10 @@ int ber_run(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, unsigned long lo
         if ((rc = grow(&h->d_pplanes, &h->pplanes_cap, (size_t)32 * nlanes))) return rc;
         uint64_t ps0 = 0;
         if ((rc = prbs_state_at_host(c.prbs_k, c.prbs_state, c.first_bit, &ps0))) return rc;
-        uint32_t ps32[16] = {(uint32_t)ps0};
-        if ((rc = awgn_seed_launch(c.prbs_k, pp->d_cols, ps32, G, h->d_pstates, G, nlanes, h->d_pplanes, h->stream))) return rc;
+        uint64_t ps64[8] = {ps0};
+        uint32_t ps16[256];
+        first16(*pp, ps64, ps16);
+        if ((rc = awgn_seed_launch(c.prbs_k, pp->d_cols, ps16, G, h->d_pstates, G, nlanes, h->d_pplanes, h->stream))) return rc;
         if ((rc = ber256_launch(h->d_planes, h->d_pplanes, &td[(size_t)i], n, nlanes, counters_dev + 2 * (size_t)i, h->stream))) return rc;
         i += n;
     }
