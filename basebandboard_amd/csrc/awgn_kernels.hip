@@ -24,6 +24,8 @@
 #include "bbb_common.hpp"
 #include "bitslice_util.hpp"
 #include "awgn_launch.hpp"
+
+#include <cstdlib>
 #include "gen/lutopt256_gen.inc"
 
 namespace bbb {
@@ -169,7 +171,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 awgn256_kernel(const uint32_t *__restrict planes, int8_t *__restrict dst, unsigned long long nsamples,
-               unsigned L, unsigned long long G, unsigned nlanes) {
+               unsigned L, unsigned long long G, unsigned nlanes, unsigned long long dbg_mask) {
     __shared__ uint32_t Z[16 * 8 * 64];
     const unsigned lane = threadIdx.x;
     const unsigned long long wave = blockIdx.x;
@@ -212,7 +214,7 @@ awgn256_kernel(const uint32_t *__restrict planes, int8_t *__restrict dst, unsign
                 if (g < G && off < nsamples) {
                     const u32x4 v = {o[0][q], o[1][q], o[2][q], o[3][q]};
                     if (off + 16 <= nsamples) {
-                        *reinterpret_cast<u32x4 *>(dst + off) = v;
+                        *reinterpret_cast<u32x4 *>(dst + (off & dbg_mask)) = v;
                     } else {
                         const unsigned n = (unsigned)(nsamples - off);
                         for (unsigned e = 0; e < n; e++) dst[off + e] = (int8_t)((o[e >> 2][q] >> (8 * (e & 3))) & 0xff);
@@ -335,8 +337,12 @@ int awgn_seed_launch(int k, const uint32_t *d_tabs, const uint32_t *s16, uint64_
 int awgn256_fill_launch(const uint32_t *d_planes, int8_t *dst, uint64_t nsamples, unsigned L, uint64_t G,
                         unsigned nlanes, hipStream_t st) {
     const unsigned nwaves = nlanes / 64;
+    // timing experiment only: BBB_DEBUG_NOSTORE=1 runs the same arithmetic with every store masked off
+    static const bool nostore = std::getenv("BBB_DEBUG_NOSTORE") != nullptr;
+    // BBB_DEBUG_STOREMASK=<hex>: fold every store address into a small window (timing experiment)
+    static const unsigned long long mask = std::getenv("BBB_DEBUG_STOREMASK") ? std::strtoull(std::getenv("BBB_DEBUG_STOREMASK"), nullptr, 16) : ~0ull;
     hipLaunchKernelGGL(awgn256_kernel, dim3(nwaves), dim3(64), 0, st, d_planes, dst, (unsigned long long)nsamples, L,
-                       (unsigned long long)G, nlanes);
+                       (unsigned long long)(nostore ? 0 : G), nlanes, mask);
     BBB_HIP(hipGetLastError());
     return BBB_OK;
 }
