@@ -42,8 +42,9 @@ __device__ __forceinline__ uint32_t ge_thr(const uint32_t (&T)[8], int thr) {
     uint32_t ge = ~0u;
 #pragma unroll
     for (int q = 0; q < 8; q++) {
-        const uint32_t tm = (uint32_t)(((int32_t)((uint32_t)thr << (31 - q))) >> 31);
-        ge = (tm & (T[q] & ge)) | (~tm & (T[q] | ge));
+        const uint32_t tm = (uint32_t)(((int32_t)((uint32_t)thr << (31 - q))) >> 31);   // scalar: 0 or ~0
+        // tm ? (T & ge) : (T | ge)   -- truth table over (a = T, b = ge, c = tm) = 0xD4
+        ge = __builtin_amdgcn_bitop3_b32(T[q], ge, tm, 0xD4);
     }
     return ge;
 }

@@ -135,7 +135,7 @@ def main():
     pmc = ROOT / "profiles" / "r01_awgn256_pmc.json"
     if pmc.exists():
         try:
-            traffic = json.load(open(pmc)).get("awgn256_kernel_hbm_write_bytes_per_launch")
+            traffic = json.load(open(pmc)).get("awgn256_kernel_hbm_bytes_per_launch")
         except Exception:
             traffic = None
     ops_per_step = 1002
