@@ -97,7 +97,12 @@ def sweep(trials, runner, rank=0, world=1, group=None):
     if mine:
         total[torch.tensor(mine, device=local.device)] = local
     if world > 1:
-        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+        if dist.get_backend(group) == "gloo" and total.is_cuda:      # CPU rehearsal of a GPU sweep
+            host = total.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            total.copy_(host)
+        else:
+            dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
     return total
 
 

@@ -206,7 +206,7 @@ prbs_stream_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwords,
     const u64 last_mask = (nbits & 63) ? ((1ull << (nbits & 63)) - 1ull) : ~0ull;
     u64 errs = 0;
 
-    constexpr int DB = WPL == 2 ? 4 : 16;               // rows per batch of loads (checker)
+    constexpr int DB = WPL == 2 ? 8 : 16;               // rows per batch of loads (checker)
     constexpr int NB = (K + DB - 1) / DB;
     for (u64 q0 = 0; q0 < nrows; q0 += K) {
         const u64 wbase = word0 + q0 * RW + (u64)(WPL * lane);
@@ -222,19 +222,22 @@ prbs_stream_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwords,
                 // LW: the window makes one LDS round trip per pass (K reads issued back to back, the
                 // in-place recurrence in registers, K writes) so that no register state is carried
                 // around the loop
-                lw_t W[LW ? K : 1];
-                if (LW) {
-#pragma unroll
-                    for (int i = 0; i < K; i++) W[i] = Xv[i * 64 + lane];
-#pragma unroll
-                    for (int i = 0; i < K; i++) W[i] ^= W[(i - TAP + K) % K];
-#pragma unroll
-                    for (int i = 0; i < K; i++) Xv[i * 64 + lane] = W[i];
-                } else {
+                if (!LW) {
 #pragma unroll
                     for (int i = 0; i < K; i++) xor_inplace(V[i], V[(i - TAP + K) % K]);   // row[q] = row[q-K] ^ row[q-TAP]
                 }
                 uint32_t e32 = 0;
+                // LW: the window streams through registers.  New row i = old row i ^ (i < TAP ? old row
+                // i+K-TAP : new row i-TAP); old row j is fetched from LDS PD iterations before its first
+                // use (iteration j-(K-TAP), or j), new rows are kept while a later row needs them.
+                constexpr int PD = 6;
+                constexpr int LAG = K - TAP;
+                lw_t O[LW ? K : 1], N[LW ? K : 1];
+                if (LW) {
+#pragma unroll
+                    for (int j = 0; j < K; j++)
+                        if ((j >= LAG ? j - LAG : j) < PD) O[j] = Xv[j * 64 + lane];
+                }
 #pragma unroll
                 for (int bidx = 0; bidx < NB; bidx++) {
                     if (bidx + 1 < NB) {
@@ -246,7 +249,18 @@ prbs_stream_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwords,
 #pragma unroll
                     for (int i = 0; i < DB; i++) {
                         const int r = bidx * DB + i;
-                        if (r < K) e32 += popc_words(D[bidx & 1][i] ^ (LW ? W[r] : V[r]));
+                        if (r < K) {
+                            if (LW) {
+#pragma unroll
+                                for (int j = 0; j < K; j++)          // rows whose first use is PD iterations ahead
+                                    if ((j >= LAG ? j - LAG : j) == r + PD) O[j] = Xv[j * 64 + lane];
+                                N[r] = O[r] ^ (r < TAP ? O[(r + LAG) % K] : N[(r - TAP + K) % K]);
+                                Xv[r * 64 + lane] = N[r];
+                                e32 += popc_words(D[bidx & 1][i] ^ N[r]);
+                            } else {
+                                e32 += popc_words(D[bidx & 1][i] ^ V[r]);
+                            }
+                        }
                     }
                 }
                 errs += e32;
@@ -365,10 +379,11 @@ static int launch_stream(int k, u64 init_state, u64 first_bit, u64 nbits, u64 *b
     if (first_bit + nbits < first_bit) return fail(BBB_EINVAL, "first_bit + nbits overflows");
     int rc = upload_pow_table(k);
     if (rc) return rc;
-    // generator: register window; checker: window parked in LDS between passes; 8-byte accesses
+    // both directions: register window, 8-byte accesses (same-box A/B in profiles/README.md); the
+    // LDS-window variants stay selectable for experiments
     // (both measured: profiles/r01_prbs_sweep.log)
     static const int lw_fill = std::getenv("BBB_PRBS_FILL_LW") ? std::atoi(std::getenv("BBB_PRBS_FILL_LW")) : 0;
-    static const int lw_chk = std::getenv("BBB_PRBS_CHECK_LW") ? std::atoi(std::getenv("BBB_PRBS_CHECK_LW")) : 1;
+    static const int lw_chk = std::getenv("BBB_PRBS_CHECK_LW") ? std::atoi(std::getenv("BBB_PRBS_CHECK_LW")) : 0;
     const bool lw = CHECK ? lw_chk != 0 : lw_fill != 0;
     if (prbs_wpl(CHECK) == 1)
         return lw ? launch_stream_w<CHECK, 1, true>(k, ki, init_state, first_bit, nbits, buf, nerr, st)

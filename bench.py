@@ -78,10 +78,17 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         args.gpus = world
+    # BENCH_BACKEND=gloo + BENCH_SHARE_GPU=1 rehearse the multi-rank code path on a one-GPU box
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    if os.environ.get("BENCH_SHARE_GPU"):
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import basebandboard_amd as bbb
     from basebandboard_amd import channel
@@ -91,6 +98,7 @@ def main():
     buf = torch.empty(NSAMP, dtype=torch.int8, device=f"cuda:{local_rank}")
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -122,7 +130,7 @@ def main():
     seed_ms, kern_ms, calls = u.profile_read(reset=True)
     u.profile(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
