@@ -62,7 +62,7 @@ class LUTOPT:
     @classmethod
     def shipped(cls, n=256, init=1, device=0):
         """The maximum-period matrix the reference uses for width n (rng_recurrences.py)."""
-        return cls.from_matrix_file(recurrences.matrix_path(n), init, device)
+        return cls.from_packed(recurrences.load_packed(recurrences.matrix_path(n)), init, device)
 
     def _setup(self, packed, init, device):
         l = _lib.lib()

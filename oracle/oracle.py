@@ -107,10 +107,12 @@ class Lutopt:
     def __init__(self, path=None, packed=None, _lib=None):
         self._l = _lib or lib()
         self._m = _Lutopt()
-        if path is not None:
-            if self._l.bbo_lutopt_load(C.byref(self._m), str(path).encode()):
+        if path is not None and not str(path).endswith(".taps"):
+            if self._l.bbo_lutopt_load(C.byref(self._m), str(path).encode()):      # reference 0/1 text format
                 raise ValueError(f"cannot load matrix {path}")
         else:
+            if path is not None:
+                packed = [[int(x) for x in l.split()] for l in open(path) if l.strip()]
             flat = np.array([c for row in packed for c in row], dtype=np.uint16)
             off = np.zeros(len(packed) + 1, dtype=np.uint32)
             off[1:] = np.cumsum([len(r) for r in packed])
@@ -250,4 +252,4 @@ def py_prbs(k, nbits, lfsr=1):
 
 def data_path(n):
     """Matrix files live with the product package (pure data, shared)."""
-    return _HERE.parent / "basebandboard_amd" / "data" / f"lutopt_{n}.txt"
+    return _HERE.parent / "basebandboard_amd" / "data" / f"lutopt_{n}.taps"

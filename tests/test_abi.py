@@ -100,8 +100,12 @@ def test_lutopt_jump_ahead_host(oracle, golden_lutopt, n):
 
 
 def test_matrix_file_loader(tmp_path):
-    u = bbb.LUTOPT.from_matrix_file(bbb.recurrences.matrix_path(32), device=-1)
+    # the reference's 0/1 text format (software/rnghunt/matrices/N), as rnghunt.rs:51-53 writes it
+    ref_fmt = tmp_path / "32"
+    ref_fmt.write_text("".join("".join("1" if c in row else "0" for c in range(32)) + "\n" for row in bbb.recurrences.n32))
+    u = bbb.LUTOPT.from_matrix_file(ref_fmt, device=-1)
     assert u.packed == bbb.recurrences.n32 and u.k == 32
+    assert bbb.recurrences.load_packed(ref_fmt) == bbb.recurrences.n32
     assert np.array_equal(u.a.sum(axis=1), [len(r) for r in bbb.recurrences.n32])
     bad = tmp_path / "bad.txt"
     bad.write_text("010\n10\n001\n")

@@ -33,7 +33,7 @@ extern "C" unsigned long long gidx(unsigned long long w, unsigned l, unsigned j)
 def build(tmp_path, n):
     inc = tmp_path / f"lutopt{n}_gen.inc"
     subprocess.check_call([sys.executable, str(ROOT / "tools" / "gen_lutopt_kernel.py"),
-                           str(ROOT / "basebandboard_amd" / "data" / f"lutopt_{n}.txt"), str(inc)])
+                           str(ROOT / "basebandboard_amd" / "data" / f"lutopt_{n}.taps"), str(inc)])
     src = tmp_path / f"h{n}.cpp"
     src.write_text(HARNESS.replace("GEN_INC", inc.name))
     so = tmp_path / f"h{n}.so"
@@ -80,7 +80,7 @@ def test_committed_generated_file_is_current(tmp_path):
         pytest.skip("not built yet")
     out = tmp_path / "x.inc"
     subprocess.check_call([sys.executable, str(ROOT / "tools" / "gen_lutopt_kernel.py"),
-                           str(ROOT / "basebandboard_amd" / "data" / "lutopt_256.txt"), str(out)])
+                           str(ROOT / "basebandboard_amd" / "data" / "lutopt_256.taps"), str(out)])
     assert out.read_text() == cur.read_text()
 
 

@@ -66,6 +66,14 @@ def test_python_restatement_agrees(oracle):
             x = y
 
 
+def test_oracle_reads_reference_matrix_format(oracle, tmp_path):
+    """bbo_lutopt_load parses the 0/1 text format of software/rnghunt/matrices/N."""
+    packed = oracle.Lutopt(path=oracle.data_path(64)).packed
+    f = tmp_path / "64"
+    f.write_text("".join("".join("1" if c in row else "0" for c in range(64)) + "\n" for row in packed))
+    assert oracle.Lutopt(path=f).packed == packed
+
+
 def test_reference_inline_test_matrices(oracle):
     """The literal matrices inside the reference's tests equal the shipped n16 / n32
     (gateware/bbb/rng.py:114-119 and :144-155), quoted here as data."""

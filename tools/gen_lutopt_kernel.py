@@ -2,7 +2,7 @@
 """Emit the straight-line bit-sliced LUTOPT step + CLT vertical counter for one matrix.
 
 Input : a recurrence matrix in the reference's text format (software/rnghunt/matrices/N,
-        shipped as basebandboard_amd/data/lutopt_N.txt).
+        shipped as packed tap lists in basebandboard_amd/data/lutopt_N.taps).
 Output: a C++ include for the HIP kernels with
 
   lutoptN_step(a, b, cnt)   b = A*a over GF(2) on 32 generators per lane
@@ -25,10 +25,12 @@ import zlib
 
 
 def load(path):
+    """Packed tap lists (one row per line) or the reference's 0/1 text matrix."""
     rows = [l.strip() for l in open(path) if l.strip()]
     n = len(rows)
-    assert all(len(r) == n for r in rows)
-    return n, [[c for c, ch in enumerate(r) if ch == "1"] for r in rows]
+    if n > 1 and all(set(r) <= {"0", "1"} and len(r) == n for r in rows):
+        return n, [[c for c, ch in enumerate(r) if ch == "1"] for r in rows]
+    return n, [[int(x) for x in r.split()] for r in rows]
 
 
 def tt3(f, inv):
@@ -134,7 +136,7 @@ def generate(n, taps, npark=0, lookahead=6):
                 push(level + 1, (cy, 0))
             levels[level].append((s, 0))
 
-    emit(f"// GENERATED by tools/gen_lutopt_kernel.py from lutopt_{n}.txt -- do not edit.")
+    emit(f"// GENERATED by tools/gen_lutopt_kernel.py from lutopt_{n}.taps -- do not edit.")
     flat = ",".join(",".join(map(str, t)) for t in taps)
     if not npark:
         emit(f"#define LUTOPT{n}_TAPS_CRC 0x{zlib.crc32(flat.encode()) & 0xffffffff:08x}u")

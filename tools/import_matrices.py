@@ -4,7 +4,8 @@
 Reads  /root/reference/software/rnghunt/matrices/N   (N lines of N chars '0'/'1',
        line r char c = A[r][c]; format written by software/rnghunt/src/bin/rnghunt.rs:51-53
        and read by software/rnghunt/util/pack.py:6-18)
-Writes basebandboard_amd/data/lutopt_N.txt           (same text format)
+Writes basebandboard_amd/data/lutopt_N.taps          (packed tap lists: line r = the column indices
+       of the ones of row r, i.e. the `packed` form of gateware/bbb/rng.py:42-55, as plain numbers)
 and cross-checks every N <= 256 against the packed tap lists
 gateware/bbb/rng_recurrences.py (nN), which is what gateware/bbb/tx.py:15,70 feeds
 to LUTOPT.from_packed.  Only runs in the build container (the reference does not
@@ -35,7 +36,7 @@ def main():
         else:
             status = "(no packed twin in rng_recurrences.py)"
         wr = sorted(set(len(p) for p in packed))
-        (OUT / f"lutopt_{n}.txt").write_text("\n".join(rows) + "\n")
+        (OUT / f"lutopt_{n}.taps").write_text("\n".join(" ".join(map(str, t)) for t in packed) + "\n")
         print(f"n={n}: row weights {wr} {status}")
     return 0
 

@@ -12,7 +12,7 @@ exact expressions the reference uses as ITS oracle for the HDL:
   rnghunt     software/rnghunt/src/binary_matrix.rs:183-192 (test_recur KAT, literal)
               software/rnghunt/src/berlekamp_massey.rs:40,45 (PRBS-9 / PRBS-11 strings, literal)
 
-Matrices come from basebandboard_amd/data/lutopt_N.txt (imported from the
+Matrices come from basebandboard_amd/data/lutopt_N.taps (imported from the
 reference by tools/import_matrices.py).  Nothing here is imported from the build's
 own oracle or product code, so the fixtures are independent of both.
 Run in the build container:  python3 tools/make_golden.py
@@ -30,8 +30,11 @@ TAPS = {7: 6, 9: 5, 11: 9, 15: 14, 20: 3, 23: 18, 31: 28}   # prbs.py:14
 
 
 def load_matrix(n):
-    rows = [l.strip() for l in open(DATA / f"lutopt_{n}.txt") if l.strip()]
-    return np.array([[int(c) for c in r] for r in rows], dtype=np.uint8)
+    rows = [[int(x) for x in l.split()] for l in open(DATA / f"lutopt_{n}.taps") if l.strip()]
+    a = np.zeros((len(rows), len(rows)), dtype=np.uint8)
+    for r, taps in enumerate(rows):
+        a[r, taps] = 1                      # rng.py:51-54 from_packed
+    return a
 
 
 def lutopt_states(a, init, nsteps):
