@@ -32,4 +32,9 @@ int ber256_launch(const uint32_t *d_planes, const uint32_t *d_prbs_planes, const
                   unsigned long long *d_counters, hipStream_t st);
 int prbs_state_at_host(int k, uint64_t init_state, uint64_t nbits, uint64_t *state);
 
+// pulse shaper / transmitter output (tx_kernels.hip); d_bits holds data bits m0.. packed LSB first
+int tx_waveform_launch(const int16_t *coeffs, const uint64_t *d_bits, int64_t m0, int source, const int8_t *d_noise,
+                       int noise_var, int bit_en, int noise_en, uint64_t first_sample, uint64_t nsamples,
+                       int16_t *d_out, hipStream_t st);
+
 }  // namespace bbb

@@ -59,6 +59,8 @@ struct bbb_lutopt {
     uint16_t *d_taps = nullptr;
     uint32_t *d_row_off = nullptr;
     unsigned long long *d_counters = nullptr; size_t counters_cap = 0;
+    uint32_t *d_txnoise = nullptr; size_t txnoise_cap = 0;    // TX: int8 noise samples (as words)
+    uint32_t *d_txbits = nullptr; size_t txbits_cap = 0;      // TX: packed data bits (as words)
     // which stream position the planes in d_planes currently describe
     bool planes_valid = false;
     uint64_t planes_first = 0, planes_L = 0, planes_G = 0;
@@ -453,7 +455,8 @@ int bbb_lutopt_destroy(bbb_lutopt *h) {
     for (auto &p : h->plans) (void)hipFree(p.second.d_cols);
     for (auto &p : h->prbs_plans) (void)hipFree(p.second.d_cols);
     for (void *p : {(void *)h->d_states, (void *)h->d_planes, (void *)h->d_pstates, (void *)h->d_pplanes,
-                    (void *)h->d_taps, (void *)h->d_row_off, (void *)h->d_counters})
+                    (void *)h->d_taps, (void *)h->d_row_off, (void *)h->d_counters, (void *)h->d_txnoise,
+                    (void *)h->d_txbits})
         (void)hipFree(p);
     delete h;
     return BBB_OK;
@@ -571,6 +574,73 @@ int bbb_prbs_detector_run(int k, const uint8_t *bits_dev, uint64_t nstreams, uin
     int rc = use_device(device);
     if (rc) return rc;
     return prbs_detector_launch(k, bits_dev, nstreams, n, err_dev, reload_dev, (hipStream_t)hip_stream);
+}
+
+// data bits needed by samples [first, first + n): indices M-7 .. M with M = floor((sample - 17) / 8)
+static void tx_bit_range(uint64_t first, uint64_t n, int64_t *m0, uint64_t *nbits) {
+    const int64_t lo = ((int64_t)first - 17 >= 0 ? ((int64_t)first - 17) / 8 : -1) - 7;
+    const int64_t hi = (int64_t)(first + n - 1) - 17 >= 0 ? ((int64_t)(first + n - 1) - 17) / 8 : -1;
+    *m0 = lo < 0 ? 0 : lo;
+    *nbits = hi >= *m0 ? (uint64_t)(hi - *m0 + 1) : 0;
+}
+
+static int tx_check(const bbb_tx_cfg *cfg) {
+    if (!cfg) return fail(BBB_EINVAL, "null cfg");
+    if (cfg->source != 0 && cfg->source != 1) return fail(BBB_EINVAL, "source must be 0 (PRBS) or 1 (pulse)");
+    if (cfg->source == 0) {
+        if (!prbs_tap(cfg->prbs_k)) return fail(BBB_EINVAL, "k=" + std::to_string(cfg->prbs_k) + " invalid for PRBS");
+        if (cfg->prbs_state == 0 || (cfg->prbs_state >> cfg->prbs_k)) return fail(BBB_EINVAL, "PRBS state must be in [1, 2^k)");
+    }
+    if (cfg->noise_var < 0 || cfg->noise_var > 15) return fail(BBB_EINVAL, "noise_var must be 0..15");
+    for (int i = 0; i < 64; i++)
+        if (cfg->coeffs[i] <= -256 || cfg->coeffs[i] > 255) return fail(BBB_EINVAL, "coefficients must be in (-256, 255]");
+    return BBB_OK;
+}
+
+int bbb_shaper_fill_i16(const bbb_tx_cfg *cfg, int16_t *out_dev, uint64_t nsamples, uint64_t first_sample, int device,
+                        void *hip_stream) {
+    int rc = tx_check(cfg);
+    if (rc) return rc;
+    if (nsamples == 0) return BBB_OK;
+    if (!out_dev || ((uintptr_t)out_dev & 15)) return fail(BBB_EINVAL, "out must be a 16-byte aligned device pointer");
+    if ((rc = use_device(device))) return rc;
+    hipStream_t st = (hipStream_t)hip_stream;
+    int64_t m0;
+    uint64_t nbits;
+    tx_bit_range(first_sample, nsamples, &m0, &nbits);
+    uint64_t *d_bits = nullptr;
+    if (cfg->source == 0 && nbits) {
+        BBB_HIP(hipMallocAsync((void **)&d_bits, ((nbits + 63) / 64 + 2) * sizeof(uint64_t), st));
+        if ((rc = prbs_fill_launch(cfg->prbs_k, cfg->prbs_state, (uint64_t)m0, nbits, d_bits, st))) return rc;
+    }
+    rc = tx_waveform_launch(cfg->coeffs, d_bits, m0, cfg->source, nullptr, 0, 1, 0, first_sample, nsamples, out_dev, st);
+    if (d_bits) BBB_HIP(hipFreeAsync(d_bits, st));
+    return rc;
+}
+
+int bbb_tx_fill_i16(bbb_lutopt *h, const bbb_tx_cfg *cfg, int16_t *out_dev, uint64_t nsamples, uint64_t first_sample) {
+    if (!h) return fail(BBB_EINVAL, "null handle");
+    int rc = tx_check(cfg);
+    if (rc) return rc;
+    if (nsamples == 0) return BBB_OK;
+    if (!out_dev || ((uintptr_t)out_dev & 15)) return fail(BBB_EINVAL, "out must be a 16-byte aligned device pointer");
+    if (h->device < 0) return fail(BBB_ENODEV, "host-only handle (device -1) cannot generate samples");
+    if (cfg->noise_en && (!h->specialised && h->k > 256)) return fail(BBB_EUNSUP, "TX noise needs an 8-bit CLT generator (k <= 256)");
+    BBB_HIP(hipSetDevice(h->device));
+    int64_t m0;
+    uint64_t nbits;
+    tx_bit_range(first_sample, nsamples, &m0, &nbits);
+    if (cfg->source == 0 && nbits && cfg->bit_en) {
+        if ((rc = grow(&h->d_txbits, &h->txbits_cap, (size_t)((nbits + 63) / 64 + 2) * 2))) return rc;
+        if ((rc = prbs_fill_launch(cfg->prbs_k, cfg->prbs_state, (uint64_t)m0, nbits, (uint64_t *)h->d_txbits, h->stream))) return rc;
+    }
+    if (cfg->noise_en) {
+        if ((rc = grow(&h->d_txnoise, &h->txnoise_cap, (size_t)(nsamples + 15) / 4 + 4))) return rc;
+        if ((rc = awgn_fill(h, h->d_txnoise, 1, nsamples, cfg->warmup + first_sample))) return rc;   // tx.py:70-71
+    }
+    return tx_waveform_launch(cfg->coeffs, (const uint64_t *)h->d_txbits, m0, cfg->bit_en ? cfg->source : 1,
+                              (const int8_t *)h->d_txnoise, cfg->noise_var, cfg->bit_en, cfg->noise_en, first_sample,
+                              nsamples, out_dev, h->stream);
 }
 
 int bbb_ber_trials_dev(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, uint64_t *counters_dev) {

@@ -1,0 +1,106 @@
+// tx_kernels.hip -- pulse shaper and transmitter output (first "next" row).
+//
+// Reference semantics (paths relative to the reference checkout):
+//   PRBSShaper  gateware/bbb/bitshaper.py:12-86   8 samples per bit; 8-deep shift register of data
+//               bits; 8 ROMs x 8 phases of +-coefficients (address LSB = the data bit, :52-58,:74);
+//               3-level adder tree to a 12-bit signed sample (:76-86)
+//   TX          gateware/bbb/tx.py:60-81          x = wrap12(bit_en*shaped + noise_en*wrap12(g*noise_var))
+//   test model  bitshaper.py:143-155              +-1 impulses at the middle of each bit period through
+//               the 64-tap pulse, 13 samples of pipeline delay
+//
+// GPU formulation: sample n depends on 8 consecutive data bits and a phase,
+//     shaped[n] = T[ph][q],  ph = (n-17) & 7,  q = bits M-7..M (oldest in bit 0),  M = (n-17) >> 3,
+// with T (8 x 256 int16, 4 KiB) built per block in LDS from the 64 coefficients.  One thread
+// produces 8 consecutive samples (one 16-byte store), reading 8 noise bytes and at most 9 data bits.
+// Roofline: HBM (2 B written + 1 B noise read per sample).
+#include "bbb_common.hpp"
+#include "awgn_launch.hpp"
+
+namespace bbb {
+
+struct Coeffs64 { int16_t c[64]; };
+
+__device__ __forceinline__ int wrap12_dev(int v) { return (int)((unsigned)v << 20) >> 20; }
+
+__global__ void __launch_bounds__(256)
+tx_waveform_kernel(Coeffs64 cf, const unsigned long long *__restrict bits, long long m0, int source,
+                   const int8_t *__restrict noise, int noise_var, int bit_en, int noise_en,
+                   unsigned long long first_sample, unsigned long long nsamples, int16_t *__restrict out) {
+    __shared__ int16_t T[8 * 256];
+    // T[ph][q]: ROM idx contributes +c[8 idx + ph] when data bit M-idx is 1 (q bit 7-idx), else -c
+    for (int e = threadIdx.x; e < 8 * 256; e += blockDim.x) {
+        const int ph = e >> 8, q = e & 255;
+        int s = 0;
+#pragma unroll
+        for (int idx = 0; idx < 8; idx++) {
+            const int c = cf.c[8 * idx + ph];
+            s += ((q >> (7 - idx)) & 1) ? c : -c;
+        }
+        T[e] = (int16_t)wrap12_dev(s);
+    }
+    __syncthreads();
+    const unsigned long long ngroups = (nsamples + 7) / 8;
+    for (unsigned long long g = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups;
+         g += (unsigned long long)gridDim.x * blockDim.x) {
+        const unsigned long long base = g * 8;
+        const long long np0 = (long long)(first_sample + base) - 17;        // n - 17 of the first sample
+        const long long M0 = np0 >> 3;                                      // floor
+        // Q bit j = data bit M0-7+j, j = 0..8 (bits before the first one are 0: the reset shift register)
+        unsigned Q = 0;
+#pragma unroll
+        for (int j = 0; j < 9; j++) {
+            const long long m = M0 - 7 + j;
+            unsigned b = 0;
+            if (m >= 0) {
+                if (source == 0) {
+                    const unsigned long long rel = (unsigned long long)(m - m0);
+                    b = (unsigned)((bits[rel >> 6] >> (rel & 63)) & 1ull);
+                } else {
+                    b = (m & 255) == 0;                                      // Pulser: counter == 0 (tx.py:28-30)
+                }
+            }
+            Q |= b << j;
+        }
+        unsigned long long nz = 0;
+        if (noise_en) {
+            if (base + 8 <= nsamples) nz = *reinterpret_cast<const unsigned long long *>(noise + base);
+            else for (unsigned e = 0; base + e < nsamples; e++) nz |= (unsigned long long)(uint8_t)noise[base + e] << (8 * e);
+        }
+        int16_t v[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const long long np = np0 + e;
+            const int ph = (int)(np & 7);
+            const unsigned q = (unsigned)((np >> 3) == M0 ? Q : Q >> 1) & 255u;
+            const int shaped = bit_en ? (int)T[ph * 256 + q] : 0;                       // tx.py:65-66
+            const int gsample = (int)(int8_t)(nz >> (8 * e));
+            const int nmux = noise_en ? wrap12_dev(gsample * noise_var) : 0;             // tx.py:75-77
+            v[e] = (int16_t)wrap12_dev(shaped + nmux);                                   // tx.py:80-81
+        }
+        if (base + 8 <= nsamples) {
+            typedef short s8 __attribute__((ext_vector_type(8)));
+            s8 pk = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+            *reinterpret_cast<s8 *>(out + base) = pk;
+        } else {
+            for (unsigned e = 0; base + e < nsamples; e++) out[base + e] = v[e];
+        }
+    }
+}
+
+int tx_waveform_launch(const int16_t *coeffs, const uint64_t *d_bits, int64_t m0, int source, const int8_t *d_noise,
+                       int noise_var, int bit_en, int noise_en, uint64_t first_sample, uint64_t nsamples,
+                       int16_t *d_out, hipStream_t st) {
+    if (nsamples == 0) return BBB_OK;
+    Coeffs64 cf;
+    for (int i = 0; i < 64; i++) cf.c[i] = coeffs[i];
+    const uint64_t groups = (nsamples + 7) / 8;
+    uint64_t blocks = (groups + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(tx_waveform_kernel, dim3((unsigned)blocks), dim3(256), 0, st, cf,
+                       (const unsigned long long *)d_bits, (long long)m0, source, d_noise, noise_var, bit_en, noise_en,
+                       (unsigned long long)first_sample, (unsigned long long)nsamples, d_out);
+    BBB_HIP(hipGetLastError());
+    return BBB_OK;
+}
+
+}  // namespace bbb

@@ -1,0 +1,44 @@
+"""Baseband transmitter -- host-side mirror of gateware/bbb/tx.py.
+
+`TX(prbs_k, bit_en, src_sel, shape_sel, noise_en, noise_var)` keeps the reference's arguments
+(tx.py:39-52): shaped PRBS (or pulse) bits plus optional Gaussian noise of controllable power,
+12-bit signed samples, 8 per data bit.  `generate` produces the sample stream on the GPU.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .bitshaper import PRBSShaper, Pulser, _cfg
+from .prbs import PRBS
+from .rng import CLTGRNG, LUTOPT
+
+
+class TX:
+    def __init__(self, prbs_k, bit_en, src_sel, shape_sel, noise_en, noise_var, device=0, init=1, prbs_init=1):
+        self.betas = np.linspace(0, 1, 32).tolist()                      # tx.py:54
+        self.prbs = PRBS(prbs_k, init=prbs_init, device=device)           # tx.py:55 (raises ValueError on a bad k)
+        self.prbs_shaper = PRBSShaper.from_rcf(self.prbs, shape_sel, self.betas)
+        self.pulse = Pulser()
+        self.pulse_shaper = PRBSShaper.from_rcf(self.pulse, shape_sel, self.betas)
+        self.urng = LUTOPT.shipped(256, init=init, device=device)         # tx.py:70: the n256 recurrence
+        self.grng = CLTGRNG(self.urng)
+        if not 0 <= int(noise_var) <= 15:
+            raise ValueError("noise_var is a 4-bit unsigned value")      # tx.py:52
+        self.bit_en, self.src_sel, self.noise_en, self.noise_var = bool(bit_en), int(src_sel), bool(noise_en), int(noise_var)
+        self.device = int(device)
+
+    def generate(self, nsamples, first_sample=0, warmup=16, out=None):
+        """Samples first_sample .. first_sample + nsamples - 1 of `x` (int16, 12-bit signed)."""
+        dev = torch.device("cuda", self.device)
+        if out is None:
+            out = torch.empty(int(nsamples), dtype=torch.int16, device=dev)
+        if out.dtype != torch.int16 or out.numel() < nsamples or not out.is_contiguous() or out.device != dev:
+            raise ValueError(f"out must be a contiguous int16 tensor on {dev} with >= nsamples elements")
+        shaper = self.pulse_shaper if self.src_sel else self.prbs_shaper            # tx.py:65
+        cfg = _cfg(shaper.coefficients[shaper.setsel], shaper.prbs, self.bit_en, self.noise_en, self.noise_var, warmup)
+        self.urng._bind_stream()
+        _lib.check(_lib.lib().bbb_tx_fill_i16(self.urng._h, C.byref(cfg), C.c_void_p(out.data_ptr()), int(nsamples),
+                                              int(first_sample)), "bbb_tx_fill_i16")
+        return out[:nsamples]

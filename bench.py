@@ -180,6 +180,21 @@ def main():
             "hbm_frac_write": round(nbits / 8 * reps / gen_ms / 1e6 / HBM_PEAK_GBS, 4),
             "hbm_frac_read": round(nbits / 8 * reps / chk_ms / 1e6 / HBM_PEAK_GBS, 4)}
         del pbuf
+        # TX output stream: shaped PRBS-31 + scaled CLT noise, int16, 8 samples/bit
+        ntx = 1 << 29
+        tx = bbb.TX(31, 1, 0, 16, 1, 8, device=local_rank)
+        txbuf = torch.empty(ntx, dtype=torch.int16, device=f"cuda:{local_rank}")
+        tx.generate(ntx, out=txbuf)
+        torch.cuda.synchronize()
+        t0e, t1e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0e.record()
+        for i in range(3):
+            tx.generate(ntx, first_sample=(i + 1) * ntx, out=txbuf)
+        t1e.record()
+        torch.cuda.synchronize()
+        extra["tx_waveform"] = {"samples": ntx, "gsample_s": round(3 * ntx / t0e.elapsed_time(t1e) / 1e6, 1),
+                                "note": "bbb_tx_fill_i16: PRBS fill + CLT noise fill + shaper/combine kernel, int16 out"}
+        del txbuf
         # BER sweep (BASELINE configs[3]/[4]): Eb/N0 0..10 dB, 1e9 bits/point, sharded over ranks
         # (point i -> rank i % world), ONE all-reduce (RCCL) of the uint64 counters.
         nv = 8

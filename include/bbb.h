@@ -156,6 +156,34 @@ int bbb_ber_trials(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, bbb_ber *
  * synchronising -- the buffer a multi-GPU host hands to one RCCL all-reduce (ncclUint64, sum). */
 int bbb_ber_trials_dev(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, uint64_t *counters_dev);
 
+/* ---- pulse shaper and transmitter output (8 samples per data bit) -------------------------- */
+
+/* PRBSShaper (gateware/bbb/bitshaper.py:12-86) and TX (gateware/bbb/tx.py:33-81).
+ * Sample n of the shaper is  sum_{idx<8} (bit[M-idx] ? +1 : -1) * coeffs[8*idx + ph]  (12-bit
+ * signed), M = floor((n-17)/8), ph = (n-17) mod 8: the 64-tap pulse applied to +-1 impulses at the
+ * middle of each 8-sample bit period with the 13-sample pipeline delay the reference's own test
+ * compensates (bitshaper.py:143-155); data bits before the first one count as 0 (reset shift
+ * register).  From sample 73 on this equals scipy.signal.lfilter(coeffs, [1], impulses)[n-13].
+ * TX.x = wrap12(bit_en * shaped + noise_en * wrap12(g * noise_var)), g = CLT sample of LUTOPT
+ * state A^(warmup + n + 1) init (tx.py:70-81); the relative alignment of noise and bits is
+ * build-defined. */
+typedef struct {
+    int16_t  coeffs[64];   /* one coefficient set, each in (-256, 255] (bitshaper.py:19-21) */
+    int32_t  source;       /* 0 = PRBS (tx.py src_sel 0), 1 = Pulser: one 1 every 256 bits (tx.py:20-30) */
+    int32_t  prbs_k;
+    uint64_t prbs_state;
+    int32_t  bit_en, noise_en, noise_var, reserved;   /* tx.py:39-52 */
+    uint64_t warmup;       /* LUTOPT clocks before the first noise sample */
+} bbb_tx_cfg;
+
+/* PRBSShaper.x: samples first_sample .. first_sample+nsamples-1 as int16 (only cfg->coeffs,
+ * source, prbs_k, prbs_state are used).  out_dev must be 16-byte aligned. */
+int bbb_shaper_fill_i16(const bbb_tx_cfg *cfg, int16_t *out_dev, uint64_t nsamples, uint64_t first_sample,
+                        int device, void *hip_stream);
+/* TX.x on the handle's generator and stream. */
+int bbb_tx_fill_i16(bbb_lutopt *h, const bbb_tx_cfg *cfg, int16_t *out_dev, uint64_t nsamples,
+                    uint64_t first_sample);
+
 #ifdef __cplusplus
 }
 #endif

@@ -344,6 +344,57 @@ int bbo_ber_trial(const bbo_lutopt *m, const uint64_t *init, const bbo_trial *t,
     return 0;
 }
 
+/* ---- PRBSShaper + TX (bitshaper.py:25-86, tx.py:60-81) ------------------------------------ */
+
+int bbo_shaper_i16(const int16_t coeffs[64], int source, int k, uint64_t prbs_state,
+                   uint64_t first_sample, uint64_t nsamples, int16_t *out)
+{
+    int tap = bbo_prbs_tap(k);
+    if (source == 0 && !tap) return -1;
+    if (nsamples == 0) return 0;
+    /* data bits 0 .. mmax */
+    int64_t last = (int64_t)(first_sample + nsamples - 1) - 17;
+    int64_t mmax = last >= 0 ? last / 8 : -1;
+    uint8_t *bits = (uint8_t *)calloc((size_t)(mmax + 2), 1);
+    if (source == 0) {
+        uint64_t s = prbs_state;
+        for (int64_t m = 0; m <= mmax; m++) bits[m] = (uint8_t)prbs_next(k, tap, &s);
+    } else {
+        for (int64_t m = 0; m <= mmax; m++) bits[m] = (uint8_t)((m & 255) == 0);   /* Pulser: counter == 0 (tx.py:28-30) */
+    }
+    for (uint64_t i = 0; i < nsamples; i++) {
+        int64_t np = (int64_t)(first_sample + i) - 17;
+        int64_t M = np >= 0 ? np / 8 : -((-np + 7) / 8);      /* floor division */
+        int ph = (int)(np - 8 * M);
+        int sum = 0;
+        for (int idx = 0; idx < 8; idx++) {                   /* ROM idx holds c[8 idx .. 8 idx + 7] (:44-58) */
+            int64_t mm = M - idx;
+            int b = mm >= 0 ? bits[mm] : 0;                   /* sr resets to 0 */
+            int c = coeffs[8 * idx + ph];
+            sum += b ? c : -c;                                /* address LSB = data bit, -c stored first (:52-58,:74) */
+        }
+        out[i] = (int16_t)wrap12(sum);
+    }
+    free(bits);
+    return 0;
+}
+
+int bbo_tx_i16(const bbo_lutopt *m, const uint64_t *init, const int16_t coeffs[64], int source, int k,
+               uint64_t prbs_state, int bit_en, int noise_en, int noise_var, uint64_t warmup,
+               uint64_t first_sample, uint64_t nsamples, int16_t *out)
+{
+    if (bbo_shaper_i16(coeffs, source, k, prbs_state, first_sample, nsamples, out)) return -1;
+    int8_t *g = (int8_t *)malloc(nsamples ? nsamples : 1);
+    bbo_awgn_stream_i8(m, init, warmup + first_sample, nsamples, g);
+    for (uint64_t i = 0; i < nsamples; i++) {
+        int bitmux = bit_en ? out[i] : 0;                              /* tx.py:65-66 */
+        int noisemux = noise_en ? wrap12(g[i] * noise_var) : 0;        /* tx.py:75-77 */
+        out[i] = (int16_t)wrap12(bitmux + noisemux);                   /* tx.py:80-81 */
+    }
+    free(g);
+    return 0;
+}
+
 /* ---- rnghunt BinaryMatrix::dot / recur (binary_matrix.rs:53-76) ------------------- */
 
 int bbo_rnghunt_recur(int nrows, int ncols, const uint64_t *col_words, const uint8_t *x_bits,

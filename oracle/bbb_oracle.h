@@ -104,6 +104,23 @@ typedef struct {
 int bbo_ber_trial(const bbo_lutopt *m, const uint64_t *init, const bbo_trial *t,
                   uint64_t *bits_out, uint64_t *errors_out);
 
+/* PRBSShaper (gateware/bbb/bitshaper.py:25-86), 8 samples per bit, for a stream of data bits:
+ * an 8-deep shift register of the most recent bits (sr[0] newest, reset 0), 8 coefficient ROMs of
+ * 8 entries each addressed by the sample phase, ROM idx contributing +c or -c by sr[idx]
+ * (:52-58,:74), summed by a 3-level adder tree into a 12-bit signed output; 13 samples of
+ * pipeline / alignment delay as compensated in the reference's test (:155).  Sample n shows
+ *   sum_idx  (bit[M-idx] ? +1 : -1) * c[8*idx + ph],  M = floor((n-17)/8), ph = (n-17) mod 8,
+ * bits before the first one count as 0 (the reset value of sr).  source: 0 = PRBS-k from
+ * prbs_state, 1 = Pulser (tx.py:20-30: one 1 every 256 bit periods, first at bit 0). */
+int bbo_shaper_i16(const int16_t coeffs[64], int source, int k, uint64_t prbs_state,
+                   uint64_t first_sample, uint64_t nsamples, int16_t *out);
+/* TX.x (gateware/bbb/tx.py:60-81): wrap12( bit_en * shaped + noise_en * wrap12(g * noise_var) ),
+ * g = CLT sample of LUTOPT state A^(warmup + n + 1) init.  The alignment of the noise stream
+ * against the bit stream is build-defined (no vector for it exists in the reference). */
+int bbo_tx_i16(const bbo_lutopt *m, const uint64_t *init, const int16_t coeffs[64], int source, int k,
+               uint64_t prbs_state, int bit_en, int noise_en, int noise_var, uint64_t warmup,
+               uint64_t first_sample, uint64_t nsamples, int16_t *out);
+
 /* rnghunt BinaryMatrix::recur restated (binary_matrix.rs:53-76): column-major u64 words,
  * MSbit = row 0; x given as one bit per byte; emits bit 0 of each successive A x. */
 int bbo_rnghunt_recur(int nrows, int ncols, const uint64_t *col_words, const uint8_t *x_bits,

@@ -79,6 +79,10 @@ def _bind(l):
     l.bbo_txrx_decide.argtypes = [C.c_int] * 4
     l.bbo_ber_trial.argtypes = [LP, u64p, C.POINTER(_Trial), u64p, u64p]
     l.bbo_rnghunt_recur.argtypes = [C.c_int, C.c_int, u64p, u8p, C.c_int, u8p]
+    i16p = C.POINTER(C.c_int16)
+    l.bbo_shaper_i16.argtypes = [i16p, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, i16p]
+    l.bbo_tx_i16.argtypes = [LP, u64p, i16p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_uint64,
+                             C.c_uint64, C.c_uint64, i16p]
     return l
 
 
@@ -203,6 +207,29 @@ def prbs_detector_run(k, bits, _lib=None):
     if l.bbo_prbs_detector_run(k, p(bits), len(bits), p(err), p(rl)):
         raise ValueError("k={} invalid for PRBS".format(k))
     return err, rl
+
+
+def shaper(coeffs, k, nsamples, first_sample=0, prbs_state=1, source=0):
+    """PRBSShaper output samples (gateware/bbb/bitshaper.py:25-86) as int16."""
+    c = np.ascontiguousarray(coeffs, dtype=np.int16)
+    assert c.size == 64
+    out = np.empty(nsamples, dtype=np.int16)
+    p = lambda a: a.ctypes.data_as(C.POINTER(C.c_int16))  # noqa: E731
+    if lib().bbo_shaper_i16(p(c), source, k, prbs_state, first_sample, nsamples, p(out)):
+        raise ValueError("k={} invalid for PRBS".format(k))
+    return out
+
+
+def tx(lut, init, coeffs, k, nsamples, first_sample=0, prbs_state=1, source=0, bit_en=1, noise_en=1, noise_var=8,
+       warmup=16):
+    """TX.x samples (gateware/bbb/tx.py:60-81) as int16; `lut` is an oracle Lutopt."""
+    c = np.ascontiguousarray(coeffs, dtype=np.int16)
+    out = np.empty(nsamples, dtype=np.int16)
+    p = lambda a: a.ctypes.data_as(C.POINTER(C.c_int16))  # noqa: E731
+    if lib().bbo_tx_i16(C.byref(lut._m), _u64(int_to_words(init, lut.k)), p(c), source, k, prbs_state, bit_en, noise_en,
+                        noise_var, warmup, first_sample, nsamples, p(out)):
+        raise ValueError("k={} invalid for PRBS".format(k))
+    return out
 
 
 def txrx_decide(g, bit, amp, noise_var):

@@ -9,6 +9,7 @@ exact expressions the reference uses as ITS oracle for the HDL:
   LUTOPT      gateware/bbb/rng.py:134-135   x = mod(dot(a, x), 2); int from x[::-1]
   CLT tree    gateware/bbb/rng.py:173-181   (same tree as software/clt-grng/clt-grng-evaluate.py:10-15)
   PRBS        gateware/bbb/prbs.py:112-113  two-line integer LFSR model, TAPS prbs.py:14
+  shaper      gateware/bbb/bitshaper.py:97-109 (coefficients), :143-155 (lfilter model of the test)
   rnghunt     software/rnghunt/src/binary_matrix.rs:183-192 (test_recur KAT, literal)
               software/rnghunt/src/berlekamp_massey.rs:40,45 (PRBS-9 / PRBS-11 strings, literal)
 
@@ -136,6 +137,43 @@ def main():
         }
     }
     json.dump(gf2, open(OUT / "gf2.json", "w"), indent=0)
+    # ---- pulse shaper (gateware/bbb/bitshaper.py) ----------------------------------------
+    # coefficient sets exactly as PRBSShaper.from_rcf computes them (bitshaper.py:97-109) for the
+    # 32 roll-offs TX uses (tx.py:54: np.linspace(0, 1, 32)), and the expected waveform from the
+    # model in the reference's own test (bitshaper.py:143-155): +-1 impulses at the midpoint of each
+    # 8-sample bit period, scipy.signal.lfilter with the pulse, 13 samples of pipeline delay:
+    #     shaped[73:] == lfilter(c, [1], y)[60:-13]
+    import scipy.signal
+    T = 8
+
+    def rcf(beta):
+        t = np.arange(-32, 32)
+        if beta != 0.0:
+            replace = np.where(np.abs(t) == T/(2*beta))
+            t[replace] = 0
+        with np.errstate(divide="ignore", invalid="ignore"):
+            c = 1/T * np.sinc(t/T) * np.cos(np.pi * beta * t/T)/(1-(2*beta*t/T)**2)
+        if beta != 0.0:
+            c[replace] = np.pi/(4*T) * np.sinc(1/(2*beta))
+        return (c * T * 254).astype(int).tolist()          # bitshaper.py:107 (np.int == int64)
+
+    def model(c, k, nsamp):
+        bits, _ = prbs_bits(k, nsamp // 8)
+        y = np.zeros(nsamp)
+        y[4::8] = 2*np.array(bits) - 1                      # bitshaper.py:151-153
+        f = scipy.signal.lfilter(np.array(c), [1], y)       # bitshaper.py:154
+        return [int(v) for v in f[60:nsamp-13]]             # == shaped[73:nsamp]   (bitshaper.py:155)
+
+    betas = np.linspace(0, 1, 32).tolist()                  # tx.py:54
+    sets = [rcf(b) for b in betas]
+    rect = [0]*30 + [254]*4 + [0]*30                        # bitshaper.py:108
+    sh = {"betas": betas, "rcf_coeffs": sets, "rect": rect,
+          "test_prbs_shaper": {"k": 9, "beta": 0.5, "coeffs": rcf(0.5), "nsamples": 320,
+                               "shaped_from_73": model(rcf(0.5), 9, 320)},
+          "prbs31_set10": {"k": 31, "set": 10, "nsamples": 4096, "shaped_from_73": model(sets[10], 31, 4096)},
+          "prbs7_set31": {"k": 7, "set": 31, "nsamples": 2048, "shaped_from_73": model(sets[31], 7, 2048)},
+          "prbs15_rect": {"k": 15, "nsamples": 1024, "shaped_from_73": model(rect, 15, 1024)}}
+    json.dump(sh, open(OUT / "shaper.json", "w"))
     print("wrote", sorted(p.name for p in OUT.iterdir()))
 
 
