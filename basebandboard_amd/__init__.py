@@ -8,4 +8,5 @@ from .rng import CLTGRNG, LUTOPT                        # noqa: F401
 from .channel import Trial, run_trials, run_trials_into, sweep, gpu_runner, shard  # noqa: F401
 from .bitshaper import PRBSShaper, Pulser                # noqa: F401
 from .tx import TX                                       # noqa: F401
+from .rx import RX                                       # noqa: F401
 from . import recurrences                                # noqa: F401

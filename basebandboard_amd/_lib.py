@@ -17,7 +17,7 @@ SYMBOLS = [
     "bbb_lutopt_load_matrix_file", "bbb_lutopt_create", "bbb_lutopt_destroy", "bbb_lutopt_set_stream",
     "bbb_lutopt_is_specialised", "bbb_lutopt_profile", "bbb_lutopt_profile_read", "bbb_lutopt_state_at", "bbb_awgn_fill_i8", "bbb_awgn_fill_i16",
     "bbb_clt_tree_i16", "bbb_prbs_fill", "bbb_prbs_check", "bbb_prbs_check_dev", "bbb_prbs_state_at",
-    "bbb_prbs_detector_run", "bbb_ber_trials", "bbb_ber_trials_dev", "bbb_shaper_fill_i16", "bbb_tx_fill_i16",
+    "bbb_prbs_detector_run", "bbb_ber_trials", "bbb_ber_trials_dev", "bbb_shaper_fill_i16", "bbb_tx_fill_i16", "bbb_rx_slice",
 ]
 
 
@@ -89,6 +89,7 @@ def lib():
     l.bbb_ber_trials_dev.argtypes = [vp, C.POINTER(TrialCfg), i32, vp]
     l.bbb_shaper_fill_i16.argtypes = [C.POINTER(TxCfg), vp, u64, u64, i32, vp]
     l.bbb_tx_fill_i16.argtypes = [vp, C.POINTER(TxCfg), vp, u64, u64]
+    l.bbb_rx_slice.argtypes = [vp, u64, u64, u64, i32, vp, u64p, i32, vp]
     for name in SYMBOLS:
         getattr(l, name)          # AttributeError here = header and library out of step
     _lib = l

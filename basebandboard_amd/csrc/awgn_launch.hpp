@@ -37,4 +37,7 @@ int tx_waveform_launch(const int16_t *coeffs, const uint64_t *d_bits, int64_t m0
                        int noise_var, int bit_en, int noise_en, uint64_t first_sample, uint64_t nsamples,
                        int16_t *d_out, hipStream_t st);
 
+int rx_slice_launch(const int16_t *d_samples, uint64_t nbits, uint64_t stride, uint64_t phase, int strict,
+                    uint64_t *d_out, hipStream_t st);
+
 }  // namespace bbb

@@ -643,6 +643,18 @@ int bbb_tx_fill_i16(bbb_lutopt *h, const bbb_tx_cfg *cfg, int16_t *out_dev, uint
                               nsamples, out_dev, h->stream);
 }
 
+int bbb_rx_slice(const int16_t *samples_dev, uint64_t nsamples, uint64_t stride, uint64_t phase, int strict,
+                 uint64_t *bits_packed_dev, uint64_t *nbits_out, int device, void *hip_stream) {
+    if (stride == 0) return fail(BBB_EINVAL, "stride must be >= 1");
+    const uint64_t nbits = phase < nsamples ? (nsamples - phase + stride - 1) / stride : 0;
+    if (nbits_out) *nbits_out = nbits;
+    if (nbits == 0) return BBB_OK;
+    if (!samples_dev || !bits_packed_dev) return fail(BBB_EINVAL, "null device pointer");
+    int rc = use_device(device);
+    if (rc) return rc;
+    return rx_slice_launch(samples_dev, nbits, stride, phase, strict, bits_packed_dev, (hipStream_t)hip_stream);
+}
+
 int bbb_ber_trials_dev(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, uint64_t *counters_dev) {
     if (!h || (ncfg && (!cfgs || !counters_dev)) || ncfg < 0) return fail(BBB_EINVAL, "null argument");
     if (h->device < 0) return fail(BBB_ENODEV, "host-only handle (device -1) cannot run trials");

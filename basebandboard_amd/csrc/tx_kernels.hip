@@ -103,4 +103,44 @@ int tx_waveform_launch(const int16_t *coeffs, const uint64_t *d_bits, int64_t m0
     return BBB_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Receiver front end: sign slicer + sampling phase + clock division.
+//   RX.sliced = ~sample[-1]  (sample >= 0 -> 1)        gateware/bbb/rx.py:29
+//   BitDelayLine picks the sampling phase               gateware/bbb/delayline.py:45-66, rx.py:32-33
+//   one decision per `stride` samples                   rx.py:35-43 (clock division), and
+//   software/memdump/decode.py:15-16: (dat > 0)[::4]    (strict threshold, stride 4)
+// bit j = decide(sample[phase + j*stride]); lane l of a wave takes bit 64w + l and one wave-wide
+// ballot packs the word (LSB first) -- the layout bbb_prbs_check reads.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+rx_slice_kernel(const int16_t *__restrict samples, unsigned long long nbits, unsigned long long stride,
+                unsigned long long phase, int strict, unsigned long long *__restrict out) {
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned long long nwords = (nbits + 63) / 64;
+    const unsigned long long wave0 = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned long long nwaves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
+    for (unsigned long long w = wave0; w < nwords; w += nwaves) {
+        const unsigned long long j = w * 64 + lane;
+        int decision = 0;
+        if (j < nbits) {
+            const int v = samples[phase + j * stride];
+            decision = strict ? v > 0 : v >= 0;
+        }
+        const unsigned long long word = __ballot(decision);
+        if (lane == 0) out[w] = word;
+    }
+}
+
+int rx_slice_launch(const int16_t *d_samples, uint64_t nbits, uint64_t stride, uint64_t phase, int strict,
+                    uint64_t *d_out, hipStream_t st) {
+    if (nbits == 0) return BBB_OK;
+    const uint64_t nwords = (nbits + 63) / 64;
+    uint64_t blocks = (nwords + 3) / 4;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(rx_slice_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_samples, (unsigned long long)nbits,
+                       (unsigned long long)stride, (unsigned long long)phase, strict, (unsigned long long *)d_out);
+    BBB_HIP(hipGetLastError());
+    return BBB_OK;
+}
+
 }  // namespace bbb

@@ -184,6 +184,15 @@ int bbb_shaper_fill_i16(const bbb_tx_cfg *cfg, int16_t *out_dev, uint64_t nsampl
 int bbb_tx_fill_i16(bbb_lutopt *h, const bbb_tx_cfg *cfg, int16_t *out_dev, uint64_t nsamples,
                     uint64_t first_sample);
 
+/* Receiver front end: sign slicer (gateware/bbb/rx.py:29: bit = sample >= 0), sampling phase
+ * (the BitDelayLine of rx.py:32-33, delayline.py:45-66) and clock division (rx.py:35-43); with
+ * strict != 0 the threshold of software/memdump/decode.py:15-16 (sample > 0, there with stride 4).
+ * Bit j = decide(samples_dev[phase + j*stride]) for every j with phase + j*stride < nsamples,
+ * packed LSB first into u64 words (the layout bbb_prbs_check reads); *nbits_out (host, may be
+ * NULL) receives the number of bits.  bits_packed_dev needs ceil(nbits/64) words. */
+int bbb_rx_slice(const int16_t *samples_dev, uint64_t nsamples, uint64_t stride, uint64_t phase, int strict,
+                 uint64_t *bits_packed_dev, uint64_t *nbits_out, int device, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -395,6 +395,17 @@ int bbo_tx_i16(const bbo_lutopt *m, const uint64_t *init, const int16_t coeffs[6
     return 0;
 }
 
+/* ---- RX slicer (rx.py:29; decode.py:15-16) ---------------------------------------------- */
+
+uint64_t bbo_rx_slice(const int16_t *samples, uint64_t nsamples, uint64_t stride, uint64_t phase, int strict,
+                      uint8_t *bits)
+{
+    uint64_t n = 0;
+    for (uint64_t i = phase; i < nsamples; i += stride)
+        bits[n++] = (uint8_t)(strict ? samples[i] > 0 : samples[i] >= 0);   /* sliced = ~sample[-1] */
+    return n;
+}
+
 /* ---- rnghunt BinaryMatrix::dot / recur (binary_matrix.rs:53-76) ------------------- */
 
 int bbo_rnghunt_recur(int nrows, int ncols, const uint64_t *col_words, const uint8_t *x_bits,

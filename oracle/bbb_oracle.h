@@ -121,6 +121,11 @@ int bbo_tx_i16(const bbo_lutopt *m, const uint64_t *init, const int16_t coeffs[6
                uint64_t prbs_state, int bit_en, int noise_en, int noise_var, uint64_t warmup,
                uint64_t first_sample, uint64_t nsamples, int16_t *out);
 
+/* RX front end: bit j = decide(samples[phase + j*stride]); decide = (v >= 0) (rx.py:29) or, strict,
+ * (v > 0) (software/memdump/decode.py:15).  One bit per byte; returns the number of bits. */
+uint64_t bbo_rx_slice(const int16_t *samples, uint64_t nsamples, uint64_t stride, uint64_t phase, int strict,
+                      uint8_t *bits);
+
 /* rnghunt BinaryMatrix::recur restated (binary_matrix.rs:53-76): column-major u64 words,
  * MSbit = row 0; x given as one bit per byte; emits bit 0 of each successive A x. */
 int bbo_rnghunt_recur(int nrows, int ncols, const uint64_t *col_words, const uint8_t *x_bits,

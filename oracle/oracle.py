@@ -232,6 +232,17 @@ def tx(lut, init, coeffs, k, nsamples, first_sample=0, prbs_state=1, source=0, b
     return out
 
 
+def rx_slice(samples, stride, phase, strict=False):
+    """Decided bits (uint8 array) of an int16 sample array -- rx.py:29 / decode.py:15-16."""
+    s = np.ascontiguousarray(samples, dtype=np.int16)
+    out = np.empty(len(s) // max(1, stride) + 2, dtype=np.uint8)
+    f = lib().bbo_rx_slice
+    f.restype = C.c_uint64
+    f.argtypes = [C.POINTER(C.c_int16), C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_uint8)]
+    n = f(s.ctypes.data_as(C.POINTER(C.c_int16)), len(s), stride, phase, int(strict), out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out[:n]
+
+
 def txrx_decide(g, bit, amp, noise_var):
     return lib().bbo_txrx_decide(int(g), int(bit), int(amp), int(noise_var))
 

@@ -85,3 +85,41 @@ def test_tx_errors(gpu):
         gpu.TX(31, 1, 0, 0, 1, 16)
     with pytest.raises(ValueError):
         gpu.TX(31, 1, 0, 40, 1, 8)
+
+
+def test_rx_slice_matches_oracle(gpu, oracle):
+    rng = np.random.default_rng(5)
+    x = rng.integers(-2048, 2048, size=100_003).astype(np.int16)
+    x[::7] = 0                                           # the threshold value itself: >= vs >
+    xt = torch.from_numpy(x).cuda()
+    for spb, delay, stride, strict in ((8, 0, None, False), (8, 5, None, False), (16, 16, 4, False), (4, 1, None, True), (1, 0, None, False)):
+        rx = gpu.RX(31, spb, delay)
+        bits, nbits = rx.slice(xt, stride=stride, strict=strict)
+        exp = oracle.rx_slice(x, stride or spb, delay, strict)
+        assert nbits == len(exp)
+        got = np.unpackbits(bits.cpu().numpy().view(np.uint8), bitorder="little")[:nbits]
+        assert np.array_equal(got, exp)
+    with pytest.raises(ValueError, match="invalid for PRBS"):
+        gpu.RX(10, 8, 0)
+    with pytest.raises(ValueError):
+        gpu.RX(31, 12, 0)
+
+
+def test_tx_rx_loopback(gpu, oracle, golden_shaper):
+    """TX -> slicer at the pulse centre -> PRBS checker.  Noise-free: the decided bits ARE the PRBS
+    (0 errors); with noise the count equals the oracle's count over its own TX samples."""
+    n = 8 * 200_000
+    centre = 17 + 32                                     # impulse of bit m at 8m+4, pulse peak at tap 32, delay 13
+    clean = gpu.TX(31, 1, 0, 16, 0, 0).generate(n)
+    rx = gpu.RX(31, 8, centre % 8)
+    first = centre - centre % 8                          # bit 0 is decided at sample `centre`
+    errs, nbits = rx.count_errors(clean, first_sample=first)
+    assert errs == 0 and nbits >= 199_990
+    noisy_tx = gpu.TX(31, 1, 0, 16, 1, 15)
+    noisy = noisy_tx.generate(n)
+    errs, nbits = rx.count_errors(noisy, first_sample=first)
+    m = oracle.Lutopt(path=oracle.data_path(256))
+    ref = oracle.tx(m, 1, golden_shaper["rcf_coeffs"][16], 31, n, noise_var=15)
+    rbits = oracle.rx_slice(ref, 8, centre)
+    pbits, _ = oracle.prbs_bits(31, len(rbits))
+    assert nbits == len(rbits) and errs == int((rbits != pbits).sum()) and errs > 0
