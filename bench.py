@@ -231,7 +231,11 @@ def main():
                          "algorithmic_bytes_per_launch": NSAMP,
                          "true_bound": "integer VALU (bit-sliced XOR/majority network), not HBM",
                          "valu_lane_ops_per_sample": round(ops_per_step / 32.0, 2),
-                         "valu_net_tlaneops_s": round(ops_per_step / 32.0 * achieved / 1e3, 2)},
+                         "valu_net_tlaneops_s": round(ops_per_step / 32.0 * achieved / 1e3, 2),
+                         # measured V_BITOP3 issue ceiling at ONE wave per SIMD (the kernel needs the whole
+                         # register file): profiles/r01_design_ubench.log, 30.66 T lane-op/s chip-wide
+                         "valu_peak_1wave_tlaneops_s": 30.66,
+                         "valu_frac_net": round(ops_per_step / 32.0 * achieved / 1e3 / 30.66, 3)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
