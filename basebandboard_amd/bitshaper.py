@@ -14,7 +14,7 @@ from .prbs import PRBS
 
 
 class Pulser:
-    """A simple pulse generator: `x` is high for one bit period in every 256 (tx.py:20-30)."""
+    """Alternative data source of TX: a single 1 every 256 bit periods (mirror of tx.py:20-30)."""
     k = 0
     init = 1
 
@@ -54,10 +54,10 @@ def rcf_coefficients(beta):
 
 
 class PRBSShaper:
-    """Runs each data bit through a pulse shaper and outputs the sum of all active pulses.
-
-    `prbs` is a PRBS generator (or a Pulser), `setsel` selects the coefficient set, `coefficients`
-    is a list of up to 32 lists of 64 integers in (-256, 255); each bit lasts 8 coefficients."""
+    """Pulse shaper at 8 samples per data bit: every bit launches a 64-tap pulse (sign by the bit
+    value) and the output is the superposition of the 8 pulses in flight (mirror of
+    bitshaper.py:12-86).  `prbs`: the bit source (PRBS or Pulser); `setsel`: index into
+    `coefficients`, a list of tap sets of 64 integers each, all within (-256, 255)."""
 
     def __init__(self, prbs, setsel, coefficients):
         if not 1 <= len(coefficients) <= 33:
@@ -69,8 +69,8 @@ class PRBSShaper:
 
     @classmethod
     def from_rcf(cls, prbs, setsel, betas):
-        """Raised-cosine pulse shapes for the given roll-offs; with fewer than 32 of them a simple
-        rectangular pulse is appended (bitshaper.py:88-109)."""
+        """One raised-cosine tap set per roll-off in `betas`; when that leaves room (< 32 sets) a
+        4-sample rectangular pulse is added as the last set (bitshaper.py:88-109)."""
         cc = [rcf_coefficients(b) for b in betas]
         if len(cc) < 32:
             cc.append([0] * 30 + [254] * 4 + [0] * 30)

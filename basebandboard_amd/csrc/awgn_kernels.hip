@@ -56,16 +56,22 @@ __device__ __forceinline__ void nibble_matvec(TabPtr tab, int nnib, const uint32
     chunk_t y[NC];
 #pragma unroll
     for (int zc = 0; zc < NC; zc++) y[zc] = (chunk_t)(0);
+    // two lookups are folded per accumulate: y ^= e0 ^ e1 is ONE V_BITOP3 (0x96) per word
 #pragma unroll
     for (int w = 0; w < W32; w++) {
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const int n = w * 8 + q;
-            if (n < nnib) {
-                const uint32_t v = (x[w] >> (4 * q)) & 15u;
+        for (int q = 0; q < 8; q += 2) {
+            const int n0 = w * 8 + q, n1 = n0 + 1;
+            if (n0 >= nnib) continue;
+            const uint32_t v0 = (x[w] >> (4 * q)) & 15u;
+            const uint32_t v1 = (x[w] >> (4 * q + 4)) & 15u;
 #pragma unroll
-                for (int zc = 0; zc < NC; zc++)
-                    y[zc] ^= *reinterpret_cast<const chunk_t *>(tab + ((n * NC + zc) * 16 + v) * C);
+            for (int zc = 0; zc < NC; zc++) {
+                const chunk_t e0 = *reinterpret_cast<const chunk_t *>(tab + ((n0 * NC + zc) * 16 + v0) * C);
+                chunk_t e1 = (chunk_t)(0);
+                if (n1 < nnib) e1 = *reinterpret_cast<const chunk_t *>(tab + ((n1 * NC + zc) * 16 + v1) * C);
+#pragma unroll
+                for (int zz = 0; zz < C; zz++) y[zc][zz] = __builtin_amdgcn_bitop3_b32(y[zc][zz], e0[zz], e1[zz], 0x96);
             }
         }
     }

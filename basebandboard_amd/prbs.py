@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 
-# These are the taps for each PRBS sequence which are not the MSb (prbs.py:12-14).
+# k -> the second feedback tap of x^k + x^tap + 1 (the first is k itself); table of prbs.py:14.
 TAPS = {7: 6, 9: 5, 11: 9, 15: 14, 20: 3, 23: 18, 31: 28}
 
 
@@ -24,7 +24,8 @@ def _check_k(k):
 
 
 class PRBS:
-    """PRBSk generator; `generate` returns the bits the reference's `x` shows on successive clocks."""
+    """PRBS-k source (mirror of prbs.py:17-35); `generate` gives the bits its output `x` takes on
+    successive clocks, packed."""
 
     def __init__(self, k, init=1, device=0):
         _check_k(k)
@@ -50,7 +51,8 @@ class PRBS:
 
 
 class PRBSErrorDetector:
-    """Compares incoming bits to the PRBS they should have been generated by (prbs.py:38-99)."""
+    """Error detector for a received PRBS-k stream (mirror of prbs.py:38-99): exact
+    self-synchronising FSM (`run`) or phase-known bulk comparison (`count_errors`)."""
 
     def __init__(self, k, device=0):
         _check_k(k)

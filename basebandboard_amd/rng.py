@@ -24,7 +24,7 @@ def _int_to_words(v, k):
 
 
 class LUTOPT:
-    """Uniform random integers from a binary linear recurrence x' = A x (rng.py:14-40).
+    """Wide uniform word source: a GF(2) linear recurrence x' = A x with a sparse A (mirror of rng.py:14-40).
 
     `a` is the k x k 0/1 recurrence matrix, `init` the initial state as an integer whose bit i is
     state element i (rng.py:30,135).  `x` after n clocks is `state_at(n)`.
@@ -124,10 +124,9 @@ class LUTOPT:
 
 
 class CLTGRNG:
-    """Gaussian integers by tree-summing the bits of a wide uniform word (rng.py:58-108).
-
-    Mean 0, variance 2**(log2(n) - 2); output width log2(n) bits, signed (rng.py:63-66,78).
-    """
+    """Approximately Gaussian integers: a +-1 weighted sum of the n bits of a uniform word, formed by
+    a log2(n)-level subtractor tree (mirror of rng.py:58-108).  Zero mean, variance n/4, signed
+    log2(n)-bit output (rng.py:63-66,78)."""
 
     def __init__(self, urng):
         n = urng.k

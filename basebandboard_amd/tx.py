@@ -1,8 +1,9 @@
-"""Baseband transmitter -- host-side mirror of gateware/bbb/tx.py.
+"""Transmitter output stream -- host-side mirror of gateware/bbb/tx.py.
 
-`TX(prbs_k, bit_en, src_sel, shape_sel, noise_en, noise_var)` keeps the reference's arguments
-(tx.py:39-52): shaped PRBS (or pulse) bits plus optional Gaussian noise of controllable power,
-12-bit signed samples, 8 per data bit.  `generate` produces the sample stream on the GPU.
+`TX(prbs_k, bit_en, src_sel, shape_sel, noise_en, noise_var)` takes the reference's arguments
+(tx.py:39-52).  Its output is the shaped data bits (PRBS-k or the pulse source) plus the CLT noise
+stream scaled by `noise_var`, each gated by its enable, as 12-bit signed samples at 8 per data bit.
+`generate` fills a tensor with that stream on the GPU.
 """
 import ctypes as C
 
