@@ -9,4 +9,4 @@ from .channel import Trial, run_trials, run_trials_into, sweep, gpu_runner, shar
 from .bitshaper import PRBSShaper, Pulser                # noqa: F401
 from .tx import TX                                       # noqa: F401
 from .rx import RX                                       # noqa: F401
-from . import recurrences                                # noqa: F401
+from . import gf2, recurrences                           # noqa: F401

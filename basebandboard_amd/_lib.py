@@ -17,7 +17,7 @@ SYMBOLS = [
     "bbb_lutopt_load_matrix_file", "bbb_lutopt_create", "bbb_lutopt_destroy", "bbb_lutopt_set_stream",
     "bbb_lutopt_is_specialised", "bbb_lutopt_profile", "bbb_lutopt_profile_read", "bbb_lutopt_state_at", "bbb_awgn_fill_i8", "bbb_awgn_fill_i16",
     "bbb_clt_tree_i16", "bbb_prbs_fill", "bbb_prbs_check", "bbb_prbs_check_dev", "bbb_prbs_state_at",
-    "bbb_prbs_detector_run", "bbb_ber_trials", "bbb_ber_trials_dev", "bbb_shaper_fill_i16", "bbb_tx_fill_i16", "bbb_rx_slice",
+    "bbb_prbs_detector_run", "bbb_ber_trials", "bbb_ber_trials_dev", "bbb_shaper_fill_i16", "bbb_tx_fill_i16", "bbb_rx_slice", "bbb_gf2_berlekamp_massey", "bbb_gf2_recur",
 ]
 
 
@@ -90,6 +90,9 @@ def lib():
     l.bbb_shaper_fill_i16.argtypes = [C.POINTER(TxCfg), vp, u64, u64, i32, vp]
     l.bbb_tx_fill_i16.argtypes = [vp, C.POINTER(TxCfg), vp, u64, u64]
     l.bbb_rx_slice.argtypes = [vp, u64, u64, u64, i32, vp, u64p, i32, vp]
+    u8p = C.POINTER(C.c_uint8)
+    l.bbb_gf2_berlekamp_massey.argtypes = [u8p, u64, u8p, C.POINTER(C.c_int64)]
+    l.bbb_gf2_recur.argtypes = [i32, i32, u64p, u8p, i32, u8p]
     for name in SYMBOLS:
         getattr(l, name)          # AttributeError here = header and library out of step
     _lib = l

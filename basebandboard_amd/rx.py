@@ -46,6 +46,18 @@ class RX:
         assert nb.value == nbits
         return out, nbits
 
+    @staticmethod
+    def decode_capture(raw, stride=4, device=0):
+        """The reference's capture decoder (software/memdump/decode.py:11-18): `raw` holds little-endian
+        int16 ADC samples (it reads 8192 of them from the serial port), every `stride`-th sample is
+        compared against 0 (`dat > 0`) and the bits are returned as a uint8 numpy array."""
+        import numpy as np
+        x = np.frombuffer(bytes(raw), dtype="<i2").astype(np.int16)
+        t = torch.from_numpy(x.copy()).to(torch.device("cuda", device))
+        rx = RX(7, 1, 0, device=device)
+        bits, nbits = rx.slice(t, stride=stride, strict=True)
+        return np.unpackbits(bits.cpu().numpy().view(np.uint8), bitorder="little")[:nbits]
+
     def count_errors(self, samples, first_sample=0, first_bit=0, prbs_init=1, stride=None):
         """Slice, then count the positions that differ from PRBS-k (started `first_bit` bits after `prbs_init`)."""
         bits, nbits = self.slice(samples, first_sample, stride)

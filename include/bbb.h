@@ -193,6 +193,19 @@ int bbb_tx_fill_i16(bbb_lutopt *h, const bbb_tx_cfg *cfg, int16_t *out_dev, uint
 int bbb_rx_slice(const int16_t *samples_dev, uint64_t nsamples, uint64_t stride, uint64_t phase, int strict,
                  uint64_t *bits_packed_dev, uint64_t *nbits_out, int device, void *hip_stream);
 
+/* ---- GF(2) helpers (host only; the pieces of software/rnghunt this path leans on) ------------ */
+
+/* Berlekamp-Massey (software/rnghunt/src/berlekamp_massey.rs:5-31): minimal polynomial of the bit
+ * sequence bits[0..n) (one bit per byte).  coeffs_out[i] (needs n+1 bytes) = coefficient of x^i,
+ * *degree = linear complexity.  E.g. the first 19 bits of PRBS9 give x^9 + x^5 + 1 (its test,
+ * berlekamp_massey.rs:40-42). */
+int bbb_gf2_berlekamp_massey(const uint8_t *bits, uint64_t n, uint8_t *coeffs_out, int64_t *degree);
+/* BinaryMatrix::recur (software/rnghunt/src/binary_matrix.rs:68-76) on rnghunt's matrix storage
+ * (column-major u64 words, first row in the MSbit, binary_matrix.rs:15-19): out_bits[s] = bit 0 of
+ * A^(s+1) x. */
+int bbb_gf2_recur(int nrows, int ncols, const uint64_t *col_words, const uint8_t *x_bits, int nsteps,
+                  uint8_t *out_bits);
+
 #ifdef __cplusplus
 }
 #endif
