@@ -342,7 +342,13 @@ static int launch_stream_w(int k, int ki, u64 init_state, u64 first_bit, u64 nbi
 #define BBB_PRBS_FN(KK) case KK: fn = (const void *)prbs_stream_kernel<KK, CHECK, WPL, LW>; break;
     switch (k) { BBB_PRBS_FN(7) BBB_PRBS_FN(9) BBB_PRBS_FN(11) BBB_PRBS_FN(15) BBB_PRBS_FN(20) BBB_PRBS_FN(23) BBB_PRBS_FN(31) }
 #undef BBB_PRBS_FN
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    static int cached_per_cu[8] = {0};                 // per K (this function is instantiated per CHECK/WPL/LW)
+    int &slot = cached_per_cu[ki];
+    if (slot == 0) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+        slot = per_cu;
+    }
+    per_cu = slot;
     // the generator is fastest with 4 waves per CU (stores need little latency hiding and fewer,
     // longer regions amortise the bootstrap); the checker takes every wave it can get
     static const int cap_env = std::getenv("BBB_PRBS_WAVES_PER_CU") ? std::atoi(std::getenv("BBB_PRBS_WAVES_PER_CU")) : -1;

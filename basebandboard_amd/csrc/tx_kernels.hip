@@ -11,7 +11,8 @@
 // GPU formulation: sample n depends on 8 consecutive data bits and a phase,
 //     shaped[n] = T[ph][q],  ph = (n-17) & 7,  q = bits M-7..M (oldest in bit 0),  M = (n-17) >> 3,
 // with T (8 x 256 int16, 4 KiB) built per block in LDS from the 64 coefficients.  One thread
-// produces 8 consecutive samples (one 16-byte store), reading 8 noise bytes and at most 9 data bits.
+// produces 16 consecutive samples (two 16-byte stores), reading 16 noise bytes and one 10-bit data
+// window.
 // Roofline: HBM (2 B written + 1 B noise read per sample).
 #include "bbb_common.hpp"
 #include "awgn_launch.hpp"
@@ -39,48 +40,61 @@ tx_waveform_kernel(Coeffs64 cf, const unsigned long long *__restrict bits, long 
         T[e] = (int16_t)wrap12_dev(s);
     }
     __syncthreads();
-    const unsigned long long ngroups = (nsamples + 7) / 8;
+    // 16 samples per thread: one 16-byte noise load, two 16-byte stores, one 10-bit data window
+    const unsigned long long ngroups = (nsamples + 15) / 16;
     for (unsigned long long g = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups;
          g += (unsigned long long)gridDim.x * blockDim.x) {
-        const unsigned long long base = g * 8;
+        const unsigned long long base = g * 16;
         const long long np0 = (long long)(first_sample + base) - 17;        // n - 17 of the first sample
         const long long M0 = np0 >> 3;                                      // floor
-        // Q bit j = data bit M0-7+j, j = 0..8 (bits before the first one are 0: the reset shift register)
+        // Q bit j = data bit M0-7+j, j = 0..9 (bits before the first one are 0: the reset shift register)
         unsigned Q = 0;
-#pragma unroll
-        for (int j = 0; j < 9; j++) {
-            const long long m = M0 - 7 + j;
-            unsigned b = 0;
-            if (m >= 0) {
-                if (source == 0) {
-                    const unsigned long long rel = (unsigned long long)(m - m0);
-                    b = (unsigned)((bits[rel >> 6] >> (rel & 63)) & 1ull);
-                } else {
-                    b = (m & 255) == 0;                                      // Pulser: counter == 0 (tx.py:28-30)
+        if (source == 0 && M0 - 7 >= m0) {
+            const unsigned long long rel = (unsigned long long)(M0 - 7 - m0);
+            const unsigned sh = (unsigned)(rel & 63);
+            unsigned long long w = bits[rel >> 6] >> sh;
+            if (sh > 54) w |= bits[(rel >> 6) + 1] << (64 - sh);
+            Q = (unsigned)w & 0x3ffu;
+        } else {
+#pragma unroll 1
+            for (int j = 0; j < 10; j++) {
+                const long long m = M0 - 7 + j;
+                unsigned b = 0;
+                if (m >= 0) {
+                    if (source == 0) {
+                        const unsigned long long rel = (unsigned long long)(m - m0);
+                        b = (unsigned)((bits[rel >> 6] >> (rel & 63)) & 1ull);
+                    } else {
+                        b = (m & 255) == 0;                                  // Pulser: counter == 0 (tx.py:28-30)
+                    }
                 }
+                Q |= b << j;
             }
-            Q |= b << j;
         }
-        unsigned long long nz = 0;
+        const bool full = base + 16 <= nsamples;
+        typedef unsigned long long u2 __attribute__((ext_vector_type(2)));
+        u2 nz = {0, 0};
         if (noise_en) {
-            if (base + 8 <= nsamples) nz = *reinterpret_cast<const unsigned long long *>(noise + base);
-            else for (unsigned e = 0; base + e < nsamples; e++) nz |= (unsigned long long)(uint8_t)noise[base + e] << (8 * e);
+            if (full) nz = *reinterpret_cast<const u2 *>(noise + base);
+            else for (unsigned e = 0; base + e < nsamples; e++) nz[e >> 3] |= (unsigned long long)(uint8_t)noise[base + e] << (8 * (e & 7));
         }
-        int16_t v[8];
+        int16_t v[16];
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
+        for (int e = 0; e < 16; e++) {
             const long long np = np0 + e;
             const int ph = (int)(np & 7);
-            const unsigned q = (unsigned)((np >> 3) == M0 ? Q : Q >> 1) & 255u;
+            const unsigned q = (Q >> (unsigned)((np >> 3) - M0)) & 255u;
             const int shaped = bit_en ? (int)T[ph * 256 + q] : 0;                       // tx.py:65-66
-            const int gsample = (int)(int8_t)(nz >> (8 * e));
+            const int gsample = (int)(int8_t)(nz[e >> 3] >> (8 * (e & 7)));
             const int nmux = noise_en ? wrap12_dev(gsample * noise_var) : 0;             // tx.py:75-77
             v[e] = (int16_t)wrap12_dev(shaped + nmux);                                   // tx.py:80-81
         }
-        if (base + 8 <= nsamples) {
+        if (full) {
             typedef short s8 __attribute__((ext_vector_type(8)));
-            s8 pk = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
-            *reinterpret_cast<s8 *>(out + base) = pk;
+            const s8 lo = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+            const s8 hi = {v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15]};
+            reinterpret_cast<s8 *>(out + base)[0] = lo;
+            reinterpret_cast<s8 *>(out + base)[1] = hi;
         } else {
             for (unsigned e = 0; base + e < nsamples; e++) out[base + e] = v[e];
         }
@@ -93,7 +107,7 @@ int tx_waveform_launch(const int16_t *coeffs, const uint64_t *d_bits, int64_t m0
     if (nsamples == 0) return BBB_OK;
     Coeffs64 cf;
     for (int i = 0; i < 64; i++) cf.c[i] = coeffs[i];
-    const uint64_t groups = (nsamples + 7) / 8;
+    const uint64_t groups = (nsamples + 15) / 16;
     uint64_t blocks = (groups + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(tx_waveform_kernel, dim3((unsigned)blocks), dim3(256), 0, st, cf,

@@ -13,6 +13,15 @@ GOLDEN = ROOT / "tests" / "golden"
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The product library is a build artefact (git-ignored).  If the tests run before build() has
+    # been called, build it now (hipcc cross-compiles without a GPU); the package itself never does
+    # this -- it fails loudly when the library is missing.
+    so = ROOT / "basebandboard_amd" / "libbbb_hip.so"
+    if not so.exists():
+        import shutil
+        import subprocess
+        if shutil.which("hipcc") or pathlib.Path("/opt/rocm/bin/hipcc").exists():
+            subprocess.check_call(["make", "-C", str(ROOT / "basebandboard_amd" / "csrc"), "-j4"])
 
 
 @pytest.fixture(scope="session")
