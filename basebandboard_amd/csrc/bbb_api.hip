@@ -19,13 +19,27 @@ std::string &last_error() {
 }
 
 int use_device(int device) {
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(BBB_ENODEV, "no HIP device visible");
-    if (device < 0 || device >= n) return fail(BBB_ENODEV, "device index out of range");
-    hipDeviceProp_t p;
-    BBB_HIP(hipGetDeviceProperties(&p, device));
-    if (std::strncmp(p.gcnArchName, "gfx950", 6) != 0)
-        return fail(BBB_ENODEV, std::string("device is ") + p.gcnArchName + ", this library is built for gfx950 only");
+    // the architecture check is done once per device (hipGetDeviceProperties is slow)
+    static std::mutex mu;
+    static bool checked[64] = {false};
+    bool known = false;
+    if (device >= 0 && device < 64) {
+        std::lock_guard<std::mutex> g(mu);
+        known = checked[device];
+    }
+    if (!known) {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(BBB_ENODEV, "no HIP device visible");
+        if (device < 0 || device >= n) return fail(BBB_ENODEV, "device index out of range");
+        hipDeviceProp_t p;
+        BBB_HIP(hipGetDeviceProperties(&p, device));
+        if (std::strncmp(p.gcnArchName, "gfx950", 6) != 0)
+            return fail(BBB_ENODEV, std::string("device is ") + p.gcnArchName + ", this library is built for gfx950 only");
+        if (device < 64) {
+            std::lock_guard<std::mutex> g(mu);
+            checked[device] = true;
+        }
+    }
     BBB_HIP(hipSetDevice(device));
     return BBB_OK;
 }
@@ -611,10 +625,10 @@ int bbb_shaper_fill_i16(const bbb_tx_cfg *cfg, int16_t *out_dev, uint64_t nsampl
     uint64_t *d_bits = nullptr;
     if (cfg->source == 0 && nbits) {
         BBB_HIP(hipMallocAsync((void **)&d_bits, ((nbits + 63) / 64 + 2) * sizeof(uint64_t), st));
-        if ((rc = prbs_fill_launch(cfg->prbs_k, cfg->prbs_state, (uint64_t)m0, nbits, d_bits, st))) return rc;
+        rc = prbs_fill_launch(cfg->prbs_k, cfg->prbs_state, (uint64_t)m0, nbits, d_bits, st);
     }
-    rc = tx_waveform_launch(cfg->coeffs, d_bits, m0, cfg->source, nullptr, 0, 1, 0, first_sample, nsamples, out_dev, st);
-    if (d_bits) BBB_HIP(hipFreeAsync(d_bits, st));
+    if (!rc) rc = tx_waveform_launch(cfg->coeffs, d_bits, m0, cfg->source, nullptr, 0, 1, 0, first_sample, nsamples, out_dev, st);
+    if (d_bits) (void)hipFreeAsync(d_bits, st);
     return rc;
 }
 

@@ -150,3 +150,19 @@ def test_clt_tree_random_words(gpu, oracle):
         x = sum(int(np.uint64(w[i, q])) << (64 * q) for q in range(4))
         assert t[i] == m.clt_tree(x) == m.clt_popcount(x)
     assert abs(t.mean()) < 0.1 and abs(t.astype(np.float64).var() - 64.0) < 1.0
+
+
+def test_n256_beyond_4g_samples(gpu, oracle):
+    """More than 2^32 samples in one call (64-bit offsets everywhere): seams and the tail against
+    the oracle started from jump-ahead states."""
+    n = (1 << 32) + 12_345
+    u = gpu.LUTOPT.shipped(256)
+    a = gpu.CLTGRNG(u).generate(n, first_step=16)
+    m = oracle.Lutopt(path=oracle.data_path(256))
+    rng = np.random.default_rng(42)
+    offs = [0, (1 << 32) - 3000, n - 4000] + [int(x) for x in rng.integers(0, n - 4000, size=12)]
+    for off in offs:
+        got = a[off: off + 4000].cpu().numpy()
+        assert np.array_equal(got, m.awgn(u.state_at(16 + off), 0, 4000, fast=True)), off
+    del a
+    torch.cuda.empty_cache()

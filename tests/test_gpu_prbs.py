@@ -103,3 +103,21 @@ def test_prbs_detector_reference_protocol(gpu, oracle, k, seed):
     wire, tx_errors = make_case(k, lambda kk, n: oracle.prbs_bits(kk, n)[0], seed)
     e, r = gpu.PRBSErrorDetector(k).run(torch.from_numpy(wire[None, :]).cuda())
     check_case(tx_errors, e[0].cpu().numpy(), r[0].cpu().numpy())
+
+
+def test_prbs31_beyond_2_pow_35_bits(gpu, oracle):
+    """4 GiB of packed PRBS-31 in one call: loopback is clean, far words match the oracle."""
+    nbits = (1 << 35) + 77
+    p = gpu.PRBS(31)
+    buf = p.generate(nbits, first_bit=5)
+    assert gpu.PRBSErrorDetector(31).count_errors(buf, nbits, first_bit=5) == 0
+    rng = np.random.default_rng(1)
+    for w in [0, (nbits // 64) - 40] + [int(x) for x in rng.integers(0, nbits // 64 - 40, size=10)]:
+        got = buf[w: w + 32].cpu().numpy().view(np.uint64)
+        exp, _ = oracle.prbs_packed(31, 32 * 64, state=p.state_at(5 + 64 * w), fast=True)
+        assert np.array_equal(got, exp), w
+    buf[12345] ^= 0x10
+    buf[-1] ^= 1
+    assert gpu.PRBSErrorDetector(31).count_errors(buf, nbits, first_bit=5) == 2
+    del buf
+    torch.cuda.empty_cache()
