@@ -15,7 +15,7 @@ BBB_OK, BBB_EINVAL, BBB_ENOMEM, BBB_EHIP, BBB_EIO, BBB_ENODEV, BBB_EUNSUP = 0, -
 SYMBOLS = [
     "bbb_abi_version", "bbb_strerror", "bbb_last_error_detail", "bbb_device_count", "bbb_free",
     "bbb_lutopt_load_matrix_file", "bbb_lutopt_create", "bbb_lutopt_destroy", "bbb_lutopt_set_stream",
-    "bbb_lutopt_is_specialised", "bbb_lutopt_profile", "bbb_lutopt_profile_read", "bbb_lutopt_state_at", "bbb_awgn_fill_i8", "bbb_awgn_fill_i16",
+    "bbb_lutopt_is_specialised", "bbb_lutopt_profile", "bbb_lutopt_profile_read", "bbb_lutopt_state_at", "bbb_awgn_fill_i8", "bbb_awgn_fill_i16", "bbb_awgn_prefetch",
     "bbb_clt_tree_i16", "bbb_prbs_fill", "bbb_prbs_check", "bbb_prbs_check_dev", "bbb_prbs_state_at",
     "bbb_prbs_detector_run", "bbb_ber_trials", "bbb_ber_trials_dev", "bbb_shaper_fill_i16", "bbb_tx_fill_i16", "bbb_rx_slice", "bbb_gf2_berlekamp_massey", "bbb_gf2_recur",
 ]
@@ -79,6 +79,7 @@ def lib():
     l.bbb_lutopt_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), u64p, i32]
     l.bbb_awgn_fill_i8.argtypes = [vp, vp, u64, u64]
     l.bbb_awgn_fill_i16.argtypes = [vp, vp, u64, u64]
+    l.bbb_awgn_prefetch.argtypes = [vp, u64, u64]
     l.bbb_clt_tree_i16.argtypes = [i32, vp, u64, vp, i32, vp]
     l.bbb_prbs_fill.argtypes = [i32, u64, u64, u64, vp, i32, vp]
     l.bbb_prbs_check.argtypes = [i32, u64, u64, u64, vp, u64p, i32, vp]

@@ -48,35 +48,36 @@ namespace bbb {
 // lanes reading different entries never conflict, lanes reading the same entry broadcast.
 // ---------------------------------------------------------------------------------------------
 
+// accumulates the nibbles [nlo, nhi) of x into y; `tab` points at the table slice of nibble nlo
 template <int W32, typename TabPtr>
-__device__ __forceinline__ void nibble_matvec(TabPtr tab, int nnib, const uint32_t (&x)[W32], uint32_t (&out)[W32]) {
+__device__ __forceinline__ void nibble_matvec_part(TabPtr tab, int nlo, int nhi, const uint32_t (&x)[W32],
+                                                   uint32_t (&y)[W32]) {
     constexpr int C = W32 < 4 ? W32 : 4;
     constexpr int NC = W32 / C;
     typedef uint32_t chunk_t __attribute__((ext_vector_type(C)));
-    chunk_t y[NC];
-#pragma unroll
-    for (int zc = 0; zc < NC; zc++) y[zc] = (chunk_t)(0);
     // two lookups are folded per accumulate: y ^= e0 ^ e1 is ONE V_BITOP3 (0x96) per word
 #pragma unroll
     for (int w = 0; w < W32; w++) {
+        uint32_t xw = x[w];
+        asm volatile("" : "+v"(xw));            // keeps hipcc from extracting all k/4 nibbles up front (64 live registers)
 #pragma unroll
         for (int q = 0; q < 8; q += 2) {
             const int n0 = w * 8 + q, n1 = n0 + 1;
-            if (n0 >= nnib) continue;
-            const uint32_t v0 = (x[w] >> (4 * q)) & 15u;
-            const uint32_t v1 = (x[w] >> (4 * q + 4)) & 15u;
+            if (n0 < nlo || n0 >= nhi) continue;
+            const uint32_t v0 = (xw >> (4 * q)) & 15u;
+            const uint32_t v1 = (xw >> (4 * q + 4)) & 15u;
 #pragma unroll
             for (int zc = 0; zc < NC; zc++) {
-                const chunk_t e0 = *reinterpret_cast<const chunk_t *>(tab + ((n0 * NC + zc) * 16 + v0) * C);
+                const chunk_t e0 = *reinterpret_cast<const chunk_t *>(tab + (((n0 - nlo) * NC + zc) * 16 + v0) * C);
                 chunk_t e1 = (chunk_t)(0);
-                if (n1 < nnib) e1 = *reinterpret_cast<const chunk_t *>(tab + ((n1 * NC + zc) * 16 + v1) * C);
+                if (n1 < nhi) e1 = *reinterpret_cast<const chunk_t *>(tab + (((n1 - nlo) * NC + zc) * 16 + v1) * C);
 #pragma unroll
-                for (int zz = 0; zz < C; zz++) y[zc][zz] = __builtin_amdgcn_bitop3_b32(y[zc][zz], e0[zz], e1[zz], 0x96);
+                for (int zz = 0; zz < C; zz++)
+                    y[zc * C + zz] = __builtin_amdgcn_bitop3_b32(y[zc * C + zz], e0[zz], e1[zz], 0x96);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);      // keep at most one state word's lookups (16 x 16 B) in flight
     }
-#pragma unroll
-    for (int w = 0; w < W32; w++) out[w] = y[w / C][w % C];
 }
 
 // states 0..15 come from the host (15 sequential products with B: microseconds, overlapped with
@@ -93,7 +94,7 @@ seed_store16_kernel(Seed16 s, unsigned long long G, unsigned long long stride, u
 
 // level e: blockIdx.y = j - 1
 template <int W32>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 5)   // <= 96 registers: a block must fit beside the sample kernel's waves
 seed_level_kernel(const uint32_t *__restrict tabs, int k, int e, unsigned long long G, unsigned long long stride,
                   uint32_t *__restrict S) {
     extern __shared__ __attribute__((aligned(16))) uint32_t tab[];
@@ -106,32 +107,40 @@ seed_level_kernel(const uint32_t *__restrict tabs, int k, int e, unsigned long l
     const int nnib = (k + 3) / 4;
     const int nt = nnib * 16 * W32;              // words; a multiple of 4 for every supported k
     const bool active = i < lo && dst < G;
-    uint32_t x[W32];
+    uint32_t x[W32], y[W32];
 #pragma unroll
-    for (int w = 0; w < W32; w++) x[w] = active ? S[w * stride + i] : 0u;   // in flight while the table is staged
-    {
-        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-        const u4 *src = reinterpret_cast<const u4 *>(tabs + ((size_t)e * 3 + (j - 1)) * nt);
-        u4 *dstp = reinterpret_cast<u4 *>(tab);
-        const int n4 = nt / 4;
-        for (int base = 0; base < n4; base += 8 * 256) {
-            u4 v[8];
+    for (int w = 0; w < W32; w++) { x[w] = active ? S[w * stride + i] : 0u; y[w] = 0u; }   // in flight while the table is staged
+    // The table is staged in two halves (16 KiB each for k = 256): with half the LDS footprint a
+    // block of this kernel fits beside the four resident blocks of the sample kernel on a CU, so
+    // that prefetched seeding (bbb_awgn_prefetch) can overlap the previous fill.
+    const int half = (nnib + 1) / 2 + ((nnib + 1) / 2 & 1);          // even number of nibbles
+    for (int part = 0; part < 2; part++) {
+        const int nlo = part * half, nhi = part ? nnib : (half < nnib ? half : nnib);
+        if (nlo >= nhi) break;
+        if (part) __syncthreads();
+        {
+            typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+            const u4 *src = reinterpret_cast<const u4 *>(tabs + ((size_t)e * 3 + (j - 1)) * nt + (size_t)nlo * 16 * W32);
+            u4 *dstp = reinterpret_cast<u4 *>(tab);
+            const int n4 = (nhi - nlo) * 16 * W32 / 4;
+            for (int base = 0; base < n4; base += 4 * 256) {     // 16 KiB = 4 x 16 B per thread
+                u4 v[4];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int q = base + u * 256 + (int)threadIdx.x;
-                if (q < n4) v[u] = src[q];
-            }
+                for (int u = 0; u < 4; u++) {
+                    const int q = base + u * 256 + (int)threadIdx.x;
+                    if (q < n4) v[u] = src[q];
+                }
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int q = base + u * 256 + (int)threadIdx.x;
-                if (q < n4) dstp[q] = v[u];
+                for (int u = 0; u < 4; u++) {
+                    const int q = base + u * 256 + (int)threadIdx.x;
+                    if (q < n4) dstp[q] = v[u];
+                }
             }
         }
+        __syncthreads();
+        if (active) nibble_matvec_part<W32>(tab, nlo, nhi, x, y);
     }
-    __syncthreads();
     if (active) {
-        uint32_t y[W32];
-        nibble_matvec<W32>(tab, nnib, x, y);
 #pragma unroll
         for (int w = 0; w < W32; w++) S[w * stride + dst] = y[w];
     }
@@ -308,7 +317,8 @@ static int seed_and_slice(int k, const uint32_t *d_tabs, const uint32_t *s16, ui
         for (int w = 0; w < 16; w++) s.w[i][w] = w < W32 ? s16[i * 16 + w] : 0u;
     int levels = 0;                                   // radix-4 levels needed: 4^levels >= G
     while ((1ull << (2 * levels)) < G) levels++;
-    const size_t lds = (size_t)((k + 3) / 4) * 16 * W32 * sizeof(uint32_t);
+    const int nnib_h = (k + 3) / 4, half_h = (nnib_h + 1) / 2 + ((nnib_h + 1) / 2 & 1);
+    const size_t lds = (size_t)half_h * 16 * W32 * sizeof(uint32_t);      // half a table at a time
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
         BBB_HIP(hipFuncSetAttribute((const void *)seed_level_kernel<W32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -9,6 +9,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 namespace bbb {
@@ -79,6 +80,21 @@ struct bbb_lutopt {
     bool planes_valid = false;
     uint64_t planes_first = 0, planes_L = 0, planes_G = 0;
     unsigned max_waves = 1024;
+    // prefetched start states for an announced next fill (bbb_awgn_prefetch): seeded on a side stream
+    // while the previous sample kernel runs, swapped in by the matching bbb_awgn_fill_i8
+    struct Prefetch {
+        bool valid = false;
+        uint64_t first = 0, L = 0, G = 0;
+        unsigned nlanes = 0;
+        uint32_t *d_states = nullptr; size_t states_cap = 0;
+        uint32_t *d_planes = nullptr; size_t planes_cap = 0;
+        hipEvent_t seeded = nullptr;      // recorded on the side stream after seeding
+        hipEvent_t last_read = nullptr;   // recorded on the main stream after the last kernel that read these buffers
+        bool read_pending = false;
+    } pf;
+    hipStream_t side = nullptr;
+    hipEvent_t cur_last_read = nullptr;   // same, for the buffers currently in d_states / d_planes
+    bool cur_read_pending = false;
     // optional per-call device timing of the generator kernels (bbb_lutopt_profile)
     bool profiling = false;
     struct ProfEv { hipEvent_t e0, e1, e2; };
@@ -239,11 +255,28 @@ int awgn_fill(bbb_lutopt *h, void *dst, int elem_size, uint64_t nsamples, uint64
         BBB_HIP(hipEventCreate(&ev.e0)); BBB_HIP(hipEventCreate(&ev.e1)); BBB_HIP(hipEventCreate(&ev.e2));
         BBB_HIP(hipEventRecord(ev.e0, h->stream));
     }
-    int rc = prepare_planes(h, first_step, L, G, nlanes);
+    int rc = BBB_OK;
+    if (h->specialised && elem_size == 1 && h->pf.valid && h->pf.first == first_step && h->pf.L == L && h->pf.G == G) {
+        // the announced fill: its start states were seeded on the side stream -- swap them in
+        BBB_HIP(hipStreamWaitEvent(h->stream, h->pf.seeded, 0));
+        std::swap(h->d_states, h->pf.d_states); std::swap(h->states_cap, h->pf.states_cap);
+        std::swap(h->d_planes, h->pf.d_planes); std::swap(h->planes_cap, h->pf.planes_cap);
+        std::swap(h->cur_last_read, h->pf.last_read); std::swap(h->cur_read_pending, h->pf.read_pending);
+        h->pf.valid = false;
+        h->planes_valid = true;
+        h->planes_first = first_step; h->planes_L = L; h->planes_G = G;
+    } else {
+        rc = prepare_planes(h, first_step, L, G, nlanes);
+    }
     if (rc) return rc;
     if (h->specialised && elem_size == 1) {
         if (h->profiling) BBB_HIP(hipEventRecord(ev.e1, h->stream));
         rc = awgn256_fill_launch(h->d_planes, (int8_t *)dst, nsamples, (unsigned)L, G, nlanes, h->stream);
+        if (!rc) {
+            if (!h->cur_last_read) BBB_HIP(hipEventCreateWithFlags(&h->cur_last_read, hipEventDisableTiming));
+            BBB_HIP(hipEventRecord(h->cur_last_read, h->stream));
+            h->cur_read_pending = true;
+        }
         if (h->profiling) {
             BBB_HIP(hipEventRecord(ev.e2, h->stream));
             h->prof_pending.push_back(ev);
@@ -470,8 +503,11 @@ int bbb_lutopt_destroy(bbb_lutopt *h) {
     for (auto &p : h->prbs_plans) (void)hipFree(p.second.d_cols);
     for (void *p : {(void *)h->d_states, (void *)h->d_planes, (void *)h->d_pstates, (void *)h->d_pplanes,
                     (void *)h->d_taps, (void *)h->d_row_off, (void *)h->d_counters, (void *)h->d_txnoise,
-                    (void *)h->d_txbits})
+                    (void *)h->d_txbits, (void *)h->pf.d_states, (void *)h->pf.d_planes})
         (void)hipFree(p);
+    for (hipEvent_t e : {h->pf.seeded, h->pf.last_read, h->cur_last_read})
+        if (e) (void)hipEventDestroy(e);
+    if (h->side) (void)hipStreamDestroy(h->side);
     delete h;
     return BBB_OK;
 }
@@ -511,6 +547,40 @@ int bbb_lutopt_profile_read(bbb_lutopt *h, double *seed_ms, double *kernel_ms, u
 int bbb_lutopt_state_at(bbb_lutopt *h, uint64_t nsteps, uint64_t *state_words) {
     if (!h || !state_words) return fail(BBB_EINVAL, "null argument");
     h->pw->apply(nsteps, h->init, state_words);
+    return BBB_OK;
+}
+
+int bbb_awgn_prefetch(bbb_lutopt *h, uint64_t nsamples, uint64_t first_step) {
+    if (!h) return fail(BBB_EINVAL, "null handle");
+    if (h->device < 0) return fail(BBB_ENODEV, "host-only handle (device -1)");
+    if (!h->specialised || nsamples == 0) return BBB_OK;          // a hint: nothing to do for the table-driven path
+    BBB_HIP(hipSetDevice(h->device));
+    uint64_t L, G;
+    unsigned nlanes;
+    partition(h, nsamples, 16, &L, &G, &nlanes);
+    JumpPlan *plan;
+    int rc = get_plan(h, L, &plan);
+    if (rc) return rc;
+    bbb_lutopt::Prefetch &pf = h->pf;
+    pf.valid = false;
+    if (!h->side) BBB_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    if (!pf.seeded) BBB_HIP(hipEventCreateWithFlags(&pf.seeded, hipEventDisableTiming));
+    // the buffers may still be read by the sample kernel that used them last (main stream)
+    if (pf.read_pending) BBB_HIP(hipStreamWaitEvent(h->side, pf.last_read, 0));
+    if (pf.states_cap < (size_t)G * h->W32 || pf.planes_cap < (size_t)2 * h->k * nlanes) {
+        if (pf.read_pending) BBB_HIP(hipEventSynchronize(pf.last_read));     // growing frees the old buffers
+        if ((rc = grow(&pf.d_states, &pf.states_cap, (size_t)G * h->W32))) return rc;
+        if ((rc = grow(&pf.d_planes, &pf.planes_cap, (size_t)2 * h->k * nlanes))) return rc;
+    }
+    pf.read_pending = false;
+    uint64_t s0[8] = {0};
+    h->pw->apply(first_step, h->init, s0);
+    uint32_t s16[256];
+    first16(*plan, s0, s16);
+    if ((rc = awgn_seed_launch(h->k, plan->d_cols, s16, G, pf.d_states, G, nlanes, pf.d_planes, h->side))) return rc;
+    BBB_HIP(hipEventRecord(pf.seeded, h->side));
+    pf.valid = true;
+    pf.first = first_step; pf.L = L; pf.G = G; pf.nlanes = nlanes;
     return BBB_OK;
 }
 

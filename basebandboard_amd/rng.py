@@ -153,6 +153,11 @@ class CLTGRNG:
         _lib.check(fn(u._h, C.c_void_p(out.data_ptr()), int(nsamples), int(first_step)), "bbb_awgn_fill")
         return out[:nsamples]
 
+    def prefetch(self, nsamples, first_step=0):
+        """Announce the next `generate(nsamples, first_step)`: its start states are derived now, on a
+        side stream, beside whatever the GPU is running.  Purely a performance hint."""
+        _lib.check(_lib.lib().bbb_awgn_prefetch(self.urng._h, int(nsamples), int(first_step)), "bbb_awgn_prefetch")
+
     @staticmethod
     def tree(states, n):
         """Adder-tree value (un-truncated) of caller-supplied uniform words: `states` is an int64 CUDA

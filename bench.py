@@ -10,7 +10,8 @@ xorshift32" generator) written to HBM.  Step s of rank 
 stream positions [16 + (s*world + r)*1e9, +1e9): a different part of the SAME sequential stream
 every step and every rank, so nothing is cached between steps and ranks are independent shards
 (weak scaling, no data-path collective).  Seeding (GF(2) jump-ahead on the GPU) is inside the
-timed region.
+timed region; the seeding of step s+1 is announced with bbb_awgn_prefetch right after step s is
+launched, so that it runs beside step s's sample kernel (BENCH_NO_PREFETCH=1 turns that off).
 
 The JSON line also carries
   roofline     achieved HBM-write GB/s of the sample kernel (algorithmic 1 B/sample / its mean
@@ -117,14 +118,19 @@ def main():
         tail0 = NSAMP - 4096
         verified = verified and bool(np.array_equal(buf[tail0:].cpu().numpy(),
                                                     m.awgn(u.state_at(WARM_STATE + tail0), 0, 4096, fast=True)))
+    prefetch = not os.environ.get("BENCH_NO_PREFETCH")
     for s in range(1, args.warmup + 1):
         g.generate(NSAMP, first_step=first_step(s), out=buf)
+        if prefetch:
+            g.prefetch(NSAMP, first_step=first_step(s + 1))
     u.profile(True)
     u.profile_read(reset=True)
     barrier()
     t0 = time.perf_counter()
     for s in range(args.steps):
         g.generate(NSAMP, first_step=first_step(args.warmup + 1 + s), out=buf)
+        if prefetch:      # seeding of the following step, issued now so that it runs beside this step's kernel
+            g.prefetch(NSAMP, first_step=first_step(args.warmup + 2 + s))
     barrier()
     dt = time.perf_counter() - t0
     seed_ms, kern_ms, calls = u.profile_read(reset=True)
@@ -223,6 +229,7 @@ def main():
                                    "warm-up 16, sequential reference stream (BASELINE configs[1]; reference-faithful "
                                    "generator, no xorshift/CLT-12 exists in the reference)",
                        "samples_per_step_per_gpu": NSAMP, "seeding_in_timed_region": True,
+                       "seeding_overlapped_by_prefetch_hint": bool(prefetch),
                        "verified_vs_oracle": verified},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

@@ -91,6 +91,12 @@ int bbb_lutopt_state_at(bbb_lutopt *h, uint64_t nsteps, uint64_t *state_words);
  * Output is int8 (for k = 256: -128..127, +128 wraps to -128 as the 8-bit Signal does).
  * dst_dev must be 16-byte aligned.  Asynchronous on the handle's stream. */
 int bbb_awgn_fill_i8(bbb_lutopt *h, int8_t *dst_dev, uint64_t nsamples, uint64_t first_step);
+/* Optional hint: the NEXT bbb_awgn_fill_i8 on this handle will ask for exactly (nsamples, first_step).
+ * The start states of that fill are then derived right away on an internal side stream -- the small
+ * seeding kernels fit beside the running sample kernel (which leaves ~110 registers per SIMD and
+ * 32 KiB of LDS per CU unused) -- and the matching fill only waits for them.  A fill with other
+ * arguments ignores the hint.  Results are identical with or without it. */
+int bbb_awgn_prefetch(bbb_lutopt *h, uint64_t nsamples, uint64_t first_step);
 /* Same stream as int16 (needed for k = 512, whose CLTGRNG output is 9 bits: rng.py:78). */
 int bbb_awgn_fill_i16(bbb_lutopt *h, int16_t *dst_dev, uint64_t nsamples, uint64_t first_step);
 

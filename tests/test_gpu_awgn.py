@@ -166,3 +166,31 @@ def test_n256_beyond_4g_samples(gpu, oracle):
         assert np.array_equal(got, m.awgn(u.state_at(16 + off), 0, 4000, fast=True)), off
     del a
     torch.cuda.empty_cache()
+
+
+def test_prefetch_hint_changes_nothing_but_timing(gpu, oracle):
+    """bbb_awgn_prefetch seeds the announced fill on a side stream; results must be identical, a
+    mismatching fill must ignore the hint, and hints may be chained."""
+    u = gpu.LUTOPT.shipped(256)
+    g = gpu.CLTGRNG(u)
+    m = oracle.Lutopt(path=oracle.data_path(256))
+    n = 3_000_000
+    ref = [m.awgn(u.state_at(16 + i * n), 0, 50_000, fast=True) for i in range(4)]
+    g.prefetch(n, first_step=16)
+    outs = []
+    for i in range(4):
+        x = g.generate(n, first_step=16 + i * n)
+        if i < 3:
+            g.prefetch(n, first_step=16 + (i + 1) * n)
+        outs.append(x[:50_000].cpu().numpy())
+    for a, b in zip(outs, ref):
+        assert np.array_equal(a, b)
+    g.prefetch(n, first_step=999)                      # announced but something else is asked for
+    x = g.generate(1000, first_step=5).cpu().numpy()
+    assert np.array_equal(x, m.awgn(1, 5, 1000, fast=True))
+    y = g.generate(n, first_step=999)[:1000].cpu().numpy()
+    assert np.array_equal(y, m.awgn(u.state_at(999), 0, 1000, fast=True))
+    # BER trials after a prefetch still see the right planes
+    g.prefetch(n, first_step=16)
+    t = gpu.Trial(nbits=50_000, amp=100, noise_var=8)
+    assert gpu.run_trials(u, [t])[0] == m.ber_trial(1, 31, 1, 100, 8, 16, 0, 50_000)
