@@ -192,20 +192,26 @@ awgn256_kernel(const uint32_t *__restrict planes, int8_t *__restrict dst, unsign
     const unsigned long long wave = blockIdx.x;
     const unsigned long long LG = wave * 64 + lane;
 
-    uint32_t a[256], b[256], cnt[8];
+    // lutopt256_step yields the sample of the state it is GIVEN (and its successor): the planes hold
+    // the state before the first sample, so advance once
+    uint32_t a[256], b[256], pa[256], pb[256], cnt[8];
 #pragma unroll
-    for (int p = 0; p < 256; p++) a[p] = planes[(size_t)p * nlanes + LG];
+    for (int p = 0; p < 256; p++) b[p] = planes[(size_t)p * nlanes + LG];
+    lutopt256_advance(b, a);
+#define BBB_PARK(p) BBB_ACC_WRITE(pa[p], a[p]);
+    LUTOPT256_FOR_PARKED(BBB_PARK)
+#undef BBB_PARK
 
     const unsigned rounds = L / 16;
 #pragma unroll 1
     for (unsigned r = 0; r < rounds; r++) {
 #pragma unroll 1
         for (unsigned tt = 0; tt < 8; tt++) {
-            lutopt256_step(a, b, cnt);
+            lutopt256_step_parked(a, pa, b, pb, cnt);
             planes8_to_bytes(cnt);
 #pragma unroll
             for (int i = 0; i < 8; i++) Z[((2 * tt) * 8 + i) * 64 + lane] = cnt[i];
-            lutopt256_step(b, a, cnt);
+            lutopt256_step_parked(b, pb, a, pa, cnt);
             planes8_to_bytes(cnt);
 #pragma unroll
             for (int i = 0; i < 8; i++) Z[((2 * tt + 1) * 8 + i) * 64 + lane] = cnt[i];

@@ -124,9 +124,9 @@ ber256_kernel(const uint32_t *__restrict planes, const uint32_t *__restrict prbs
     const unsigned pairs = (tk.L + 1) / 2;
 #pragma unroll 1
     for (unsigned it = 0; it < pairs; it++) {
-        lutopt256_step(a, b, cnt);
+        lutopt256_step_new(a, b, cnt);       // (the form hipcc allocates best next to the comparators)
         consume(2 * it);
-        lutopt256_step(b, a, cnt);
+        lutopt256_step_new(b, a, cnt);
         if (2 * it + 1 < tk.L) consume(2 * it + 1);
     }
     unsigned long long b64 = nbit;

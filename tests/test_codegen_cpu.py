@@ -20,10 +20,29 @@ static inline uint32_t __builtin_amdgcn_bitop3_b32(uint32_t a, uint32_t b, uint3
   for (int i = 0; i < 8; i++) if ((tt >> i) & 1) { uint32_t m = ~0u; m &= (i & 4) ? a : ~a; m &= (i & 2) ? b : ~b; m &= (i & 1) ? c : ~c; r |= m; }
   return r;
 }
+#define BBB_ACC_WRITE(dst, src) ((dst) = (src))
+#define BBB_ACC_READ(dst, src) ((dst) = (src))
 #include "GEN_INC"
 #include "bitslice_util.hpp"
 extern "C" void step(const uint32_t* a, uint32_t* b, uint32_t* cnt) {
   uint32_t A[NN], B[NN], Cn[LOGN]; memcpy(A, a, sizeof A); STEPFN(A, B, Cn); memcpy(b, B, sizeof B); memcpy(cnt, Cn, sizeof Cn);
+}
+#ifdef PARKFN
+// the variant with explicit AGPR placement: planes listed in LUTOPT256_PARKED travel in pa / pb
+extern "C" void step_parked(const uint32_t* a, uint32_t* b, uint32_t* cnt) {
+  uint32_t A[NN], PA[NN], B[NN], PB[NN], Cn[LOGN];
+  memcpy(A, a, sizeof A); memcpy(PA, a, sizeof PA);
+  for (int i = 0; i < LUTOPT256_NPARKED; i++) A[LUTOPT256_PARKED[i]] = 0xdeadbeefu;      // must not be read
+  PARKFN(A, PA, B, PB, Cn);
+  for (int i = 0; i < LUTOPT256_NPARKED; i++) B[LUTOPT256_PARKED[i]] = PB[LUTOPT256_PARKED[i]];
+  memcpy(b, B, sizeof B); memcpy(cnt, Cn, sizeof Cn);
+}
+#endif
+extern "C" void step_new(const uint32_t* a, uint32_t* b, uint32_t* cnt) {
+  uint32_t A[NN], B[NN], Cn[LOGN]; memcpy(A, a, sizeof A); STEPNEWFN(A, B, Cn); memcpy(b, B, sizeof B); memcpy(cnt, Cn, sizeof Cn);
+}
+extern "C" void advance(const uint32_t* a, uint32_t* b) {
+  uint32_t A[NN], B[NN]; memcpy(A, a, sizeof A); ADVFN(A, B); memcpy(b, B, sizeof B);
 }
 extern "C" void t32(uint32_t* q) { uint32_t Q[32]; memcpy(Q, q, sizeof Q); bbb::transpose32(Q); memcpy(q, Q, sizeof Q); }
 extern "C" unsigned long long gidx(unsigned long long w, unsigned l, unsigned j) { return bbb::gen_index(w, l, j); }
@@ -39,7 +58,7 @@ def build(tmp_path, n):
     so = tmp_path / f"h{n}.so"
     logn = n.bit_length() - 1
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", f"-DNN={n}", f"-DLOGN={logn}",
-                           f"-DSTEPFN=lutopt{n}_step", f"-I{tmp_path}", f"-I{ROOT / 'basebandboard_amd' / 'csrc'}",
+                           f"-DSTEPFN=lutopt{n}_step", f"-DADVFN=lutopt{n}_advance", f"-DSTEPNEWFN=lutopt{n}_step_new", *([f"-DPARKFN=lutopt{n}_step_parked"] if n == 256 else []), f"-I{tmp_path}", f"-I{ROOT / 'basebandboard_amd' / 'csrc'}",
                            str(src), "-o", str(so)])
     return C.CDLL(str(so))
 
@@ -61,15 +80,28 @@ def test_generated_network_matches_oracle(oracle, tmp_path, n):
     b = np.zeros(n, dtype=np.uint32)
     cnt = np.zeros(logn, dtype=np.uint32)
     P = lambda x: x.ctypes.data_as(C.POINTER(C.c_uint32))  # noqa: E731
+    b2 = np.zeros(n, dtype=np.uint32)
     for _ in range(12):
-        lib.step(P(a), P(b), P(cnt))
+        lib.step(P(a), P(b), P(cnt))          # b = A a, cnt = sample of the OLD state a
+        lib.advance(P(a), P(b2))
+        assert np.array_equal(b, b2)
+        if n == 256:
+            b3, cnt3 = np.zeros(n, dtype=np.uint32), np.zeros(logn, dtype=np.uint32)
+            lib.step_parked(P(a), P(b3), P(cnt3))
+            assert np.array_equal(b, b3) and np.array_equal(cnt, cnt3)
+        b4, cnt4 = np.zeros(n, dtype=np.uint32), np.zeros(logn, dtype=np.uint32)
+        lib.step_new(P(a), P(b4), P(cnt4))    # cnt4 = sample of the NEW state
+        assert np.array_equal(b, b4)
         for g in range(32):
-            states[g] = m.step_int(states[g])
-            got = sum(((int(b[p]) >> g) & 1) << p for p in range(n))
-            assert got == states[g]
             v = sum(((int(cnt[q]) >> g) & 1) << q for q in range(logn))
             v = v - n if v >= n // 2 else v
             assert v == m.clt_wrap(m.clt_tree(states[g]))
+            states[g] = m.step_int(states[g])
+            v = sum(((int(cnt4[q]) >> g) & 1) << q for q in range(logn))
+            v = v - n if v >= n // 2 else v
+            assert v == m.clt_wrap(m.clt_tree(states[g]))
+            got = sum(((int(b[p]) >> g) & 1) << p for p in range(n))
+            assert got == states[g]
         a, b = b.copy(), a
 
 
