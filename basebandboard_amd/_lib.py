@@ -17,7 +17,7 @@ SYMBOLS = [
     "bbb_lutopt_load_matrix_file", "bbb_lutopt_create", "bbb_lutopt_destroy", "bbb_lutopt_set_stream",
     "bbb_lutopt_is_specialised", "bbb_lutopt_profile", "bbb_lutopt_profile_read", "bbb_lutopt_state_at", "bbb_awgn_fill_i8", "bbb_awgn_fill_i16", "bbb_awgn_prefetch",
     "bbb_clt_tree_i16", "bbb_prbs_fill", "bbb_prbs_check", "bbb_prbs_check_dev", "bbb_prbs_state_at",
-    "bbb_prbs_detector_run", "bbb_ber_trials", "bbb_ber_trials_dev", "bbb_shaper_fill_i16", "bbb_tx_fill_i16", "bbb_rx_slice", "bbb_gf2_berlekamp_massey", "bbb_gf2_recur",
+    "bbb_prbs_detector_run", "bbb_prbs_detector_stream", "bbb_ber_trials", "bbb_ber_trials_dev", "bbb_shaper_fill_i16", "bbb_tx_fill_i16", "bbb_rx_slice", "bbb_rx_phase_search", "bbb_gf2_berlekamp_massey", "bbb_gf2_recur",
 ]
 
 
@@ -39,6 +39,12 @@ class TxCfg(C.Structure):
     _fields_ = [("coeffs", C.c_int16 * 64), ("source", C.c_int32), ("prbs_k", C.c_int32), ("prbs_state", C.c_uint64),
                 ("bit_en", C.c_int32), ("noise_en", C.c_int32), ("noise_var", C.c_int32), ("reserved", C.c_int32),
                 ("warmup", C.c_uint64)]
+
+
+class DetectorStats(C.Structure):
+    """bbb_detector_stats"""
+    _fields_ = [(n, C.c_uint64) for n in ("bits", "errors", "errors_raw", "reload_clocks", "resyncs", "chunks",
+                                          "chunks_rerun", "serial_fallback")]
 
 
 class Ber(C.Structure):
@@ -86,6 +92,8 @@ def lib():
     l.bbb_prbs_check_dev.argtypes = [i32, u64, u64, u64, vp, vp, i32, vp]
     l.bbb_prbs_state_at.argtypes = [i32, u64, u64, u64p]
     l.bbb_prbs_detector_run.argtypes = [i32, vp, u64, u64, vp, vp, i32, vp]
+    l.bbb_rx_phase_search.argtypes = [vp, u64, u64, u64, i32, i32, C.POINTER(DetectorStats), i32, vp]
+    l.bbb_prbs_detector_stream.argtypes = [i32, vp, u64, vp, vp, C.POINTER(DetectorStats), u64, u64, i32, vp]
     l.bbb_ber_trials.argtypes = [vp, C.POINTER(TrialCfg), i32, C.POINTER(Ber)]
     l.bbb_ber_trials_dev.argtypes = [vp, C.POINTER(TrialCfg), i32, vp]
     l.bbb_shaper_fill_i16.argtypes = [C.POINTER(TxCfg), vp, u64, u64, i32, vp]

@@ -660,6 +660,17 @@ int bbb_prbs_detector_run(int k, const uint8_t *bits_dev, uint64_t nstreams, uin
     return prbs_detector_launch(k, bits_dev, nstreams, n, err_dev, reload_dev, (hipStream_t)hip_stream);
 }
 
+int bbb_prbs_detector_stream(int k, const uint64_t *bits_packed_dev, uint64_t nbits, uint64_t *err_packed_dev,
+                             uint64_t *reload_packed_dev, bbb_detector_stats *stats, uint64_t chunk_bits, uint64_t warm_bits,
+                             int device, void *hip_stream) {
+    if (!prbs_tap(k)) return fail(BBB_EINVAL, "k=" + std::to_string(k) + " invalid for PRBS");
+    if (nbits && !bits_packed_dev) return fail(BBB_EINVAL, "null device pointer");
+    int rc = use_device(device);
+    if (rc) return rc;
+    return prbs_detector_stream_launch(k, bits_packed_dev, nbits, err_packed_dev, reload_packed_dev, stats, chunk_bits,
+                                       warm_bits, (hipStream_t)hip_stream);
+}
+
 // data bits needed by samples [first, first + n): indices M-7 .. M with M = floor((sample - 17) / 8)
 static void tx_bit_range(uint64_t first, uint64_t n, int64_t *m0, uint64_t *nbits) {
     const int64_t lo = ((int64_t)first - 17 >= 0 ? ((int64_t)first - 17) / 8 : -1) - 7;
@@ -737,6 +748,29 @@ int bbb_rx_slice(const int16_t *samples_dev, uint64_t nsamples, uint64_t stride,
     int rc = use_device(device);
     if (rc) return rc;
     return rx_slice_launch(samples_dev, nbits, stride, phase, strict, bits_packed_dev, (hipStream_t)hip_stream);
+}
+
+int bbb_rx_phase_search(const int16_t *samples_dev, uint64_t nsamples, uint64_t stride, uint64_t nphases, int strict, int k,
+                        bbb_detector_stats *stats_out, int device, void *hip_stream) {
+    if (stride == 0) return fail(BBB_EINVAL, "stride must be >= 1");
+    if (!prbs_tap(k)) return fail(BBB_EINVAL, "k=" + std::to_string(k) + " invalid for PRBS");
+    if (nphases == 0) return BBB_OK;
+    if (!stats_out || (nsamples && !samples_dev)) return fail(BBB_EINVAL, "null argument");
+    int rc = use_device(device);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const uint64_t maxbits = nsamples ? (nsamples + stride - 1) / stride : 0;
+    uint64_t *bits = nullptr;
+    if (maxbits) BBB_HIP(hipMalloc(&bits, ((maxbits + 63) / 64) * sizeof(uint64_t)));
+    for (uint64_t p = 0; p < nphases && rc == BBB_OK; p++) {
+        const uint64_t nbits = p < nsamples ? (nsamples - p + stride - 1) / stride : 0;
+        stats_out[p] = bbb_detector_stats{};
+        if (nbits == 0) continue;
+        rc = rx_slice_launch(samples_dev, nbits, stride, p, strict, bits, st);
+        if (rc == BBB_OK) rc = prbs_detector_stream_launch(k, bits, nbits, nullptr, nullptr, &stats_out[p], 0, 0, st);
+    }
+    if (bits) (void)hipFree(bits);
+    return rc;
 }
 
 int bbb_ber_trials_dev(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, uint64_t *counters_dev) {

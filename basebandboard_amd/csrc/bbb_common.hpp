@@ -39,4 +39,8 @@ int prbs_check_launch(int k, uint64_t init_state, uint64_t first_bit, uint64_t n
 int prbs_detector_launch(int k, const uint8_t *bits, uint64_t nstreams, uint64_t n, uint8_t *err,
                          uint8_t *reload, hipStream_t st);
 
+// detector_kernels.hip
+int prbs_detector_stream_launch(int k, const uint64_t *src, uint64_t nbits, uint64_t *err, uint64_t *reload,
+                                bbb_detector_stats *stats, uint64_t chunk_bits, uint64_t warm_bits, hipStream_t st);
+
 }  // namespace bbb

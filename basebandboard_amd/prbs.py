@@ -72,6 +72,30 @@ class PRBSErrorDetector:
                                                     self.device, _stream_ptr(self.device)), "bbb_prbs_detector_run")
         return err, reload
 
+    def run_stream(self, packed, nbits, want_err=False, want_reload=False, chunk_bits=0, warm_bits=0):
+        """The same machine over ONE long packed stream (bit t at word t//64, LSB first), executed in
+        parallel chunks with state hand-off; exact (bbb_prbs_detector_stream).  Returns a dict of
+        totals (errors = err while reload == 0, errors_raw, reload_clocks, resyncs, ...) and, when
+        asked for, the packed `err` / `reload` streams as int64 CUDA tensors."""
+        if packed.dtype != torch.int64 or not packed.is_cuda or not packed.is_contiguous():
+            raise ValueError("packed must be a contiguous int64 CUDA tensor")
+        if packed.numel() * 64 < nbits:
+            raise ValueError("packed holds fewer than nbits bits")
+        nw = (int(nbits) + 63) // 64
+        err = torch.empty(nw, dtype=torch.int64, device=packed.device) if want_err else None
+        rl = torch.empty(nw, dtype=torch.int64, device=packed.device) if want_reload else None
+        st = _lib.DetectorStats()
+        _lib.check(_lib.lib().bbb_prbs_detector_stream(
+            self.k, C.c_void_p(packed.data_ptr()), int(nbits), C.c_void_p(err.data_ptr() if want_err else None),
+            C.c_void_p(rl.data_ptr() if want_reload else None), C.byref(st), int(chunk_bits), int(warm_bits),
+            self.device, _stream_ptr(self.device)), "bbb_prbs_detector_stream")
+        out = {n: int(getattr(st, n)) for n, _ in _lib.DetectorStats._fields_}
+        if want_err:
+            out["err"] = err
+        if want_reload:
+            out["reload"] = rl
+        return out
+
     def count_errors(self, packed, nbits, first_bit=0, init=1):
         """Phase-known bulk check: how many of `nbits` packed bits differ from PRBSk started at
         `init` -- the sum of `err` over a stream for which `reload` stays 0 (prbs.py:79)."""

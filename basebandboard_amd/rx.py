@@ -62,3 +62,26 @@ class RX:
         """Slice, then count the positions that differ from PRBS-k (started `first_bit` bits after `prbs_init`)."""
         bits, nbits = self.slice(samples, first_sample, stride)
         return self.prbsdet.count_errors(bits, nbits, first_bit=first_bit, init=prbs_init), nbits
+
+    def detect(self, samples, first_sample=0, stride=None, want_err=False, want_reload=False):
+        """Slice at this receiver's `sample_delay`, then the exact self-synchronising detector over the
+        whole stream (rx.py:41-46 at scale): totals as PRBSErrorDetector.run_stream returns them."""
+        bits, nbits = self.slice(samples, first_sample, stride)
+        return self.prbsdet.run_stream(bits, nbits, want_err=want_err, want_reload=want_reload)
+
+    def phase_search(self, samples, stride=None, strict=False):
+        """Every setting of the reference's `sample_delay` knob (0 .. samples_per_bit - 1; rx.py:19): the
+        detector's totals per phase and the phase with the fewest errors."""
+        if samples.dtype != torch.int16 or not samples.is_cuda or not samples.is_contiguous():
+            raise ValueError("samples must be a contiguous int16 CUDA tensor")
+        stride = self.samples_per_bit if stride is None else int(stride)
+        nph = self.samples_per_bit
+        st = (_lib.DetectorStats * nph)()
+        dev = samples.device.index or 0
+        _lib.check(_lib.lib().bbb_rx_phase_search(C.c_void_p(samples.data_ptr()), samples.numel(), stride, nph,
+                                                  int(bool(strict)), self.prbs_k, st, dev,
+                                                  C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                   "bbb_rx_phase_search")
+        out = [{n: int(getattr(s, n)) for n, _ in _lib.DetectorStats._fields_} for s in st]
+        best = min(range(nph), key=lambda p: (out[p]["errors"] + out[p]["reload_clocks"], p))
+        return out, best

@@ -185,6 +185,20 @@ def main():
             "check_hbm_read_gb_s": round(nbits / 8 * reps / chk_ms / 1e6, 1),
             "hbm_frac_write": round(nbits / 8 * reps / gen_ms / 1e6 / HBM_PEAK_GBS, 4),
             "hbm_frac_read": round(nbits / 8 * reps / chk_ms / 1e6 / HBM_PEAK_GBS, 4)}
+        # exact self-synchronising detector over the same 1e10-bit stream, with 1e-3 injected errors
+        # (chunked FSM with state hand-off)
+        noise = torch.randint(0, 1000, (pbuf.numel(),), device=pbuf.device) == 0
+        pbuf ^= noise.to(torch.int64) << 13
+        del noise
+        det.run_stream(pbuf, nbits)
+        torch.cuda.synchronize()
+        td = time.perf_counter()
+        ds = det.run_stream(pbuf, nbits)
+        torch.cuda.synchronize()
+        td = time.perf_counter() - td
+        extra["detector_stream"] = {"bits": nbits, "errors": ds["errors"], "resyncs": ds["resyncs"], "chunks": ds["chunks"],
+                                    "chunks_rerun": ds["chunks_rerun"], "gbit_s": round(nbits / td / 1e9, 1),
+                                    "note": "bbb_prbs_detector_stream, totals only, includes its verify passes and host syncs"}
         del pbuf
         # TX output stream: shaped PRBS-31 + scaled CLT noise, int16, 8 samples/bit
         ntx = 1 << 29

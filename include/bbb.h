@@ -134,6 +134,29 @@ int bbb_prbs_state_at(int k, uint64_t init_state, uint64_t nbits, uint64_t *stat
 int bbb_prbs_detector_run(int k, const uint8_t *bits_dev, uint64_t nstreams, uint64_t n,
                           uint8_t *err_dev, uint8_t *reload_dev, int device, void *hip_stream);
 
+/* The same detector over ONE long stream (chunked execution with state
+ * hand-off).  bits_packed_dev: input wire during clock t at word t/64, bit t%64 (the layout
+ * bbb_prbs_fill / bbb_rx_slice write).  err_packed_dev / reload_packed_dev (either may be NULL,
+ * ceil(nbits/64) words): `err` / `reload` sampled after clock t, same packing.  The stream is cut
+ * into chunks of chunk_bits (0: 4096; a multiple of 64), each run by one GPU lane from a
+ * speculative state obtained by running the reset detector over the warm_bits (0: 1024) before the
+ * chunk; every chunk whose speculative start differs from its predecessor's true end state is run
+ * again from that state until the chain is consistent, so the outputs equal the serial machine's
+ * bit for bit (prbs.py:61-99).  *stats is a host result (the call synchronises the stream). */
+typedef struct {
+    uint64_t bits;            /* clocks processed */
+    uint64_t errors;          /* clocks with err == 1 and reload == 0 (what the reference test compares, prbs.py:152-163) */
+    uint64_t errors_raw;      /* clocks with err == 1 */
+    uint64_t reload_clocks;   /* clocks with reload == 1 */
+    uint64_t resyncs;         /* times err_count exceeded k/2 (prbs.py:92), the reload out of reset included */
+    uint64_t chunks;          /* execution detail: chunks, chunk re-runs needed, 1 if the serial guard ran */
+    uint64_t chunks_rerun;
+    uint64_t serial_fallback;
+} bbb_detector_stats;
+int bbb_prbs_detector_stream(int k, const uint64_t *bits_packed_dev, uint64_t nbits, uint64_t *err_packed_dev,
+                             uint64_t *reload_packed_dev, bbb_detector_stats *stats, uint64_t chunk_bits,
+                             uint64_t warm_bits, int device, void *hip_stream);
+
 /* ---- fused Monte-Carlo trial: PRBS -> BPSK + scaled CLT noise -> slicer -> error count --- */
 
 /* One trial.  Bit t (0 <= t < nbits) uses PRBS bit first_bit+t and the CLT sample of LUTOPT
@@ -198,6 +221,13 @@ int bbb_tx_fill_i16(bbb_lutopt *h, const bbb_tx_cfg *cfg, int16_t *out_dev, uint
  * NULL) receives the number of bits.  bits_packed_dev needs ceil(nbits/64) words. */
 int bbb_rx_slice(const int16_t *samples_dev, uint64_t nsamples, uint64_t stride, uint64_t phase, int strict,
                  uint64_t *bits_packed_dev, uint64_t *nbits_out, int device, void *hip_stream);
+
+/* The reference's sampling-phase knob (`sample_delay`, rx.py:19,32-33: 0..samples_per_bit) tried at
+ * every setting: for phase p in [0, nphases) slice bit j = decide(samples_dev[p + j*stride]) and run
+ * the exact detector over the resulting stream; stats_out[p] (host) receives the totals.  The best
+ * phase is the one with the fewest `errors`; nothing here chooses for the caller. */
+int bbb_rx_phase_search(const int16_t *samples_dev, uint64_t nsamples, uint64_t stride, uint64_t nphases, int strict,
+                        int k, bbb_detector_stats *stats_out, int device, void *hip_stream);
 
 /* ---- GF(2) helpers (host only; the pieces of software/rnghunt this path leans on) ------------ */
 

@@ -302,6 +302,48 @@ int bbo_prbs_detector_run(int k, const uint8_t *bits, uint64_t n, uint8_t *err, 
     return 0;
 }
 
+/* The same machine on a packed stream, with the totals the GPU stream runner reports. */
+int bbo_prbs_detector_packed(int k, const uint64_t *words, uint64_t nbits, uint64_t *err_words,
+                             uint64_t *reload_words, uint64_t stats[4])
+{
+    int tap = bbo_prbs_tap(k);
+    if (!tap) return -1;
+    const uint64_t mask = (1ull << k) - 1ull;
+    uint64_t prbs = 1, err_sr = mask;
+    int bit_in = 0, reload_ctr = 0;
+    uint64_t nw = (nbits + 63) / 64;
+    if (err_words) memset(err_words, 0, nw * 8);
+    if (reload_words) memset(reload_words, 0, nw * 8);
+    stats[0] = stats[1] = stats[2] = stats[3] = 0;
+    for (uint64_t i = 0; i < nbits; i++) {
+        int feedback = (int)(((prbs >> (k - 1)) ^ (prbs >> (tap - 1))) & 1u);
+        int rl = reload_ctr != 0;
+        int prbs_in = rl ? bit_in : feedback;
+        int e = bit_in != feedback;
+        int err_count = __builtin_popcountll(err_sr);
+        uint64_t prbs_n = ((prbs << 1) | (uint64_t)prbs_in) & mask;
+        uint64_t err_sr_n = ((err_sr << 1) | (uint64_t)e) & mask;
+        int reload_ctr_n = reload_ctr;
+        if (err_count > k / 2) {
+            reload_ctr_n = k + k / 2;
+            err_sr_n = 0;
+            stats[3]++;                                /* resyncs */
+        } else if (rl) {
+            reload_ctr_n = reload_ctr - 1;
+        }
+        bit_in = (int)((words[i >> 6] >> (i & 63)) & 1u);
+        prbs = prbs_n; err_sr = err_sr_n; reload_ctr = reload_ctr_n;
+        int eo = bit_in != (int)(((prbs >> (k - 1)) ^ (prbs >> (tap - 1))) & 1u);
+        int ro = reload_ctr != 0;
+        if (eo && err_words) err_words[i >> 6] |= 1ull << (i & 63);
+        if (ro && reload_words) reload_words[i >> 6] |= 1ull << (i & 63);
+        stats[1] += (uint64_t)eo;                      /* errors_raw */
+        stats[2] += (uint64_t)ro;                      /* reload_clocks */
+        stats[0] += (uint64_t)(eo && !ro);             /* errors while synced */
+    }
+    return 0;
+}
+
 /* ---- TX noise path + RX slicer --------------------------------------------------- */
 
 static inline int wrap12(int v)

@@ -84,6 +84,11 @@ int bbo_prbs_check_packed(int k, uint64_t *state, uint64_t nbits, const uint64_t
  * clock edge -- exactly what the reference's testbench reads (prbs.py:146-150). */
 int bbo_prbs_detector_run(int k, const uint8_t *bits, uint64_t n, uint8_t *err, uint8_t *reload);
 
+/* Same machine on a packed stream (bit t at word t/64, LSB first); err_words / reload_words may be
+ * NULL; stats = {err while reload==0, err, reload clocks, err_count > k/2 events}. */
+int bbo_prbs_detector_packed(int k, const uint64_t *words, uint64_t nbits, uint64_t *err_words,
+                             uint64_t *reload_words, uint64_t stats[4]);
+
 /* TX noise path + RX slicer (tx.py:75-81, rx.py:29), one sample per bit:
  *   noise = wrap12(g * noise_var), x = wrap12(level(bit) + noise), decision = (x >= 0)
  * level(bit) = bit ? +amp : -amp.  Returns decision (0/1). */

@@ -76,6 +76,8 @@ def _bind(l):
     l.bbo_prbs_packed_fast.argtypes = [C.c_int, u64p, C.c_uint64, u64p]
     l.bbo_prbs_check_packed.argtypes = [C.c_int, u64p, C.c_uint64, u64p, u64p]
     l.bbo_prbs_detector_run.argtypes = [C.c_int, u8p, C.c_uint64, u8p, u8p]
+    l.bbo_prbs_detector_packed.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint64),
+                                           C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     l.bbo_txrx_decide.argtypes = [C.c_int] * 4
     l.bbo_ber_trial.argtypes = [LP, u64p, C.POINTER(_Trial), u64p, u64p]
     l.bbo_rnghunt_recur.argtypes = [C.c_int, C.c_int, u64p, u8p, C.c_int, u8p]
@@ -207,6 +209,21 @@ def prbs_detector_run(k, bits, _lib=None):
     if l.bbo_prbs_detector_run(k, p(bits), len(bits), p(err), p(rl)):
         raise ValueError("k={} invalid for PRBS".format(k))
     return err, rl
+
+
+def prbs_detector_packed(k, words, nbits, _lib=None):
+    """(err_words, reload_words, stats) of the detector on a packed stream; stats = dict(errors, errors_raw,
+    reload_clocks, resyncs)."""
+    l = _lib or lib()
+    words = np.ascontiguousarray(words, dtype=np.uint64)
+    nw = (nbits + 63) // 64
+    assert len(words) >= nw
+    err = np.zeros(nw, dtype=np.uint64)
+    rl = np.zeros(nw, dtype=np.uint64)
+    st = (C.c_uint64 * 4)()
+    if l.bbo_prbs_detector_packed(k, _u64(words), nbits, _u64(err), _u64(rl), st):
+        raise ValueError("k={} invalid for PRBS".format(k))
+    return err, rl, dict(errors=st[0], errors_raw=st[1], reload_clocks=st[2], resyncs=st[3])
 
 
 def shaper(coeffs, k, nsamples, first_sample=0, prbs_state=1, source=0):

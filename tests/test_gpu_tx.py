@@ -123,3 +123,31 @@ def test_tx_rx_loopback(gpu, oracle, golden_shaper):
     rbits = oracle.rx_slice(ref, 8, centre)
     pbits, _ = oracle.prbs_bits(31, len(rbits))
     assert nbits == len(rbits) and errs == int((rbits != pbits).sum()) and errs > 0
+
+
+def test_rx_detect_and_phase_search(gpu, oracle, golden_shaper):
+    """The reference's receiver at scale: TX waveform -> slicer at every `sample_delay` setting -> exact
+    self-synchronising detector.  Each phase's totals equal the oracle's slicer + serial detector on the
+    same samples; the pulse centre is found, and there the noise-free stream has no error after lock."""
+    n = 8 * 150_000
+    centre = (17 + 32) % 8
+    for nv in (0, 15):
+        x = gpu.TX(31, 1, 0, 16, 1 if nv else 0, nv).generate(n)
+        rx = gpu.RX(31, 8, centre)
+        stats, best = rx.phase_search(x)
+        xs = x.cpu().numpy()
+        for p in range(8):
+            bits = oracle.rx_slice(xs, 8, p)
+            w = np.packbits(bits, bitorder="little")
+            w = np.concatenate([w, np.zeros((-len(w)) % 8, dtype=np.uint8)]).view(np.uint64)
+            _, _, st = oracle.prbs_detector_packed(31, w, len(bits))
+            assert stats[p]["bits"] == len(bits)
+            for name in ("errors", "errors_raw", "reload_clocks", "resyncs"):
+                assert stats[p][name] == st[name], (p, name)
+        assert abs(best - centre) <= 1 or abs(best - centre) >= 7
+        d = rx.detect(x)
+        assert d["errors"] == stats[centre]["errors"]
+        if nv == 0:
+            assert d["errors"] == 0 and d["resyncs"] <= 3
+        else:
+            assert d["errors"] > 0

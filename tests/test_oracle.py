@@ -183,3 +183,23 @@ def test_ber_trial_additive_and_sane(oracle):
     theory = 0.5 * erfc(sqrt(100 ** 2 / (2 * 64.0 ** 2)))
     assert abs(ber / theory - 1) < 0.15
     assert m.ber_trial(1, 31, 1, 2000, 0, 16, 0, 1000)[1] == 0      # no noise, no errors
+
+
+@pytest.mark.parametrize("k", (7, 15, 31))
+def test_detector_packed_form_equals_bytewise(oracle, k):
+    """bbo_prbs_detector_packed (the checker of the GPU stream runner) is the same machine as
+    bbo_prbs_detector_run (pinned by the reference's test protocol in test_detector_*)."""
+    n = 20_001
+    bits, _ = oracle.prbs_bits(k, n)
+    bits = np.array(bits, dtype=np.uint8)
+    rng = np.random.default_rng(k)
+    bits ^= (rng.random(n) < 0.02).astype(np.uint8)
+    bits[n // 2: n // 2 + 3 * k] ^= 1
+    e, r = oracle.prbs_detector_run(k, bits)
+    w = np.packbits(bits, bitorder="little")
+    w = np.concatenate([w, np.zeros((-len(w)) % 8, dtype=np.uint8)]).view(np.uint64)
+    e2, r2, st = oracle.prbs_detector_packed(k, w, n)
+    assert np.array_equal(e, np.unpackbits(e2.view(np.uint8), bitorder="little")[:n])
+    assert np.array_equal(r, np.unpackbits(r2.view(np.uint8), bitorder="little")[:n])
+    assert st["errors"] == int(((e == 1) & (r == 0)).sum()) and st["errors_raw"] == int(e.sum())
+    assert st["reload_clocks"] == int(r.sum()) and st["resyncs"] >= 2
