@@ -773,6 +773,15 @@ int bbb_rx_phase_search(const int16_t *samples_dev, uint64_t nsamples, uint64_t 
     return rc;
 }
 
+int bbb_lutopt_search(int k, uint64_t seed, uint64_t first_candidate, uint64_t ncandidates, uint64_t *found_index,
+                      uint16_t *taps_out, uint32_t *row_off_out, bbb_search_stats *stats, int device, void *hip_stream) {
+    if (!found_index) return fail(BBB_EINVAL, "null argument");
+    int rc = use_device(device);
+    if (rc) return rc;
+    return lutopt_search_launch(k, seed, first_candidate, ncandidates, found_index, taps_out, row_off_out, stats,
+                                (hipStream_t)hip_stream);
+}
+
 int bbb_ber_trials_dev(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, uint64_t *counters_dev) {
     if (!h || (ncfg && (!cfgs || !counters_dev)) || ncfg < 0) return fail(BBB_EINVAL, "null argument");
     if (h->device < 0) return fail(BBB_ENODEV, "host-only handle (device -1) cannot run trials");

@@ -43,4 +43,8 @@ int prbs_detector_launch(int k, const uint8_t *bits, uint64_t nstreams, uint64_t
 int prbs_detector_stream_launch(int k, const uint64_t *src, uint64_t nbits, uint64_t *err, uint64_t *reload,
                                 bbb_detector_stats *stats, uint64_t chunk_bits, uint64_t warm_bits, hipStream_t st);
 
+// search_kernels.hip
+int lutopt_search_launch(int k, uint64_t seed, uint64_t first, uint64_t count, uint64_t *found, uint16_t *taps_out,
+                         uint32_t *row_off_out, bbb_search_stats *stats, hipStream_t st);
+
 }  // namespace bbb

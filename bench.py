@@ -215,6 +215,16 @@ def main():
         extra["tx_waveform"] = {"samples": ntx, "gsample_s": round(3 * ntx / t0e.elapsed_time(t1e) / 1e6, 1),
                                 "note": "bbb_tx_fill_i16: PRBS fill + CLT noise fill + shaper/combine kernel, int16 out"}
         del txbuf
+        # the reference's matrix search (software/rnghunt) on the GPU: candidates per second for k = 256
+        from basebandboard_amd import gf2 as _gf2
+        _gf2.search(256, seed=rank + 1, first=0, count=256, device=local_rank)
+        tsr = time.perf_counter()
+        sidx, _, sst = _gf2.search(256, seed=rank + 1, first=1 << 32, count=1 << 17, device=local_rank)
+        tsr = time.perf_counter() - tsr
+        extra["matrix_search_k256"] = {"candidates_tested": sst["tested"], "full_degree": sst["full_degree"],
+                                       "order_divides": sst["order_divides"], "accepted": sst["primitive"], "first_hit": sidx,
+                                       "kcand_s": round(sst["tested"] / tsr / 1e3, 1),
+                                       "note": "bbb_lutopt_search: build + 512 steps + Berlekamp-Massey + primitivity per wavefront"}
         # BER sweep (BASELINE configs[3]/[4]): Eb/N0 0..10 dB, 1e9 bits/point, sharded over ranks
         # (point i -> rank i % world), ONE all-reduce (RCCL) of the uint64 counters.
         nv = 8

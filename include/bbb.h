@@ -242,6 +242,49 @@ int bbb_gf2_berlekamp_massey(const uint8_t *bits, uint64_t n, uint8_t *coeffs_ou
 int bbb_gf2_recur(int nrows, int ncols, const uint64_t *col_words, const uint8_t *x_bits, int nsteps,
                   uint8_t *out_bits);
 
+/* BinaryPolynomial::is_primitive (software/rnghunt/src/binary_polynomial.rs:178-216).  coeffs[i] is
+ * the coefficient of x^(ncoeffs-1-i), the order of BinaryPolynomial::from_coefficients (:48-53).
+ * *result = 1 / 0.  The test needs the prime factors of 2^deg - 1: the degrees in
+ * basebandboard_amd/data/mersenne_factors.txt are served, others give BBB_EUNSUP. */
+int bbb_gf2_poly_is_primitive(const uint8_t *coeffs, int ncoeffs, int *result);
+/* BinaryPolynomial::modexp (:135-163): x^e mod p, e = little-endian 64-bit words; out_coeffs has
+ * ncoeffs bytes in the same order as coeffs. */
+int bbb_gf2_poly_modexp(const uint8_t *coeffs, int ncoeffs, const uint64_t *exponent_words, int nwords,
+                        uint8_t *out_coeffs);
+/* The polynomial rnghunt's search examines for a recurrence (src/bin/rnghunt.rs:27-38): bit 0 of 2k
+ * successive states from the all-ones vector, reversed, through Berlekamp-Massey.  coeffs_out needs
+ * 2k+1 bytes (the reversed sequence of a singular matrix can have complexity above k); entries
+ * 0..*degree are the coefficients, highest power first. */
+int bbb_lutopt_charpoly(int k, const uint16_t *taps, const uint32_t *row_off, uint8_t *coeffs_out, int *degree);
+/* Its acceptance test (rnghunt.rs:40-46): degree == k and primitive, i.e. period 2^k - 1. */
+int bbb_lutopt_is_full_period(int k, const uint16_t *taps, const uint32_t *row_off, int *result);
+/* Its output file (rnghunt.rs:51-53): k lines of k characters, line r character c = A[r][c]; read
+ * back by bbb_lutopt_load_matrix_file and by the reference's util/pack.py, util/verify.py. */
+int bbb_lutopt_save_matrix_file(const char *path, int k, const uint16_t *taps, const uint32_t *row_off);
+
+/* ---- the recurrence search of software/rnghunt, on the GPU ----------------------------------- */
+
+/* Candidate number `candidate` of `seed`: a random k x k matrix with 3 or 4 ones per row (weights
+ * drawn from [3,4,4,4,4,4,4,4], rnghunt.rs:25) and balanced column weights
+ * (BinaryMatrix::random, binary_matrix.rs:81-101), from a counter-based generator so that it is the
+ * same matrix on every host and device (the reference's thread_rng is unseeded; see
+ * csrc/search_rng.hpp for the construction).  taps_out needs 4k entries, row_off_out k+1. */
+int bbb_lutopt_search_candidate(int k, uint64_t seed, uint64_t candidate, uint16_t *taps_out, uint32_t *row_off_out);
+typedef struct {
+    uint64_t tested;          /* candidates examined */
+    uint64_t full_degree;     /* of those: characteristic polynomial of degree k (rnghunt.rs:40) */
+    uint64_t order_divides;   /* of those: x^(2^k - 1) = 1 (first check of is_primitive) */
+    uint64_t primitive;       /* of those: primitive = accepted */
+} bbb_search_stats;
+/* Examine candidates first_candidate .. first_candidate + ncandidates - 1 on the GPU, one per
+ * wavefront at a time: build the matrix, run 2k steps from the all-ones state, Berlekamp-Massey,
+ * degree check, primitivity test (the loop body of rnghunt.rs:23-47).  *found_index receives the
+ * SMALLEST accepted candidate number (UINT64_MAX if none), its taps go to taps_out / row_off_out (host,
+ * may be NULL) after a re-check with the host arithmetic above.  k must be a multiple of 64 in
+ * 64..512 or 16 or 32, with an entry in the factor table.  *stats is a host result. */
+int bbb_lutopt_search(int k, uint64_t seed, uint64_t first_candidate, uint64_t ncandidates, uint64_t *found_index,
+                      uint16_t *taps_out, uint32_t *row_off_out, bbb_search_stats *stats, int device, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,3 +40,109 @@ def test_lutopt_bit0_sequence_has_full_linear_complexity(golden_lutopt, n):
     bits = [u.state_at(t + 1) & 1 for t in range(2 * n)]
     poly = gf2.berlekamp_massey(bits)
     assert poly[0] == n and poly[-1] == 0
+
+
+# ---- polynomial arithmetic and the search's acceptance test (binary_polynomial.rs, rnghunt.rs) ----------
+
+P200 = [1] + [0] * 194 + [1, 0, 1, 1, 0, 1]            # x^200 + x^5 + x^3 + x^2 + 1 (binary_polynomial.rs:337-339)
+P33 = [1, 1, 0, 0, 1, 0, 0, 0, 1, 1, 0, 0, 0, 0, 1, 1, 0, 1, 0, 0, 0, 1, 0, 0, 1, 1, 0, 1, 1, 1, 1, 0, 1, 1]   # :361-364
+
+
+def test_is_primitive_rnghunt_kats():
+    """binary_polynomial.rs:352-371, literally."""
+    assert gf2.poly_is_primitive([1, 1, 0, 0, 1])                       # x^4 + x^3 + 1
+    assert not gf2.poly_is_primitive([1, 0, 1, 1, 1])                   # x^4 + x^2 + x + 1 = (x+1)(...)
+    assert gf2.poly_is_primitive(P33)
+    assert gf2.poly_is_primitive(P200)
+
+
+def test_modexp_and_check_integer_rnghunt_kats():
+    """binary_polynomial.rs:308-350: x^k mod p."""
+    big = [1] + [0] * 255                                               # x^255: "degree(p) > k so mod doesn't come into it"
+    for k in (0, 1, 2, 20, 100):
+        out = gf2.poly_modexp(big, k)
+        assert [i for i, c in enumerate(reversed(out)) if c] == [k]
+    p = [1, 1, 0, 0, 1]
+    assert gf2.poly_modexp(p, 15) == [0, 0, 0, 0, 1]
+    for k in range(1, 15):                                              # primitive: no smaller power of x is 1
+        assert gf2.poly_modexp(p, k) != [0, 0, 0, 0, 1]
+    one = [0] * 200 + [1]
+    for k in range(1, 100):
+        assert gf2.poly_modexp(P200, k) != one
+    assert gf2.poly_modexp(P200, 2 ** 200 - 1) == one
+
+
+def test_prbs_polynomials_are_primitive():
+    """x^k + x^tap + 1 for the seven PRBS orders (gateware/bbb/prbs.py:12-14): maximal length."""
+    for k, tap in bbb.TAPS.items():
+        c = [0] * (k + 1)
+        c[0] = c[k - tap] = c[k] = 1
+        assert gf2.poly_is_primitive(c), k
+
+
+def test_product_arithmetic_equals_the_oracle(tmp_path):
+    from oracle import gf2poly as og
+    rng = np.random.default_rng(3)
+    for n in (4, 16, 33, 64, 200, 256):
+        for _ in range(4):
+            c = rng.integers(0, 2, size=n + 1).tolist()
+            c[0] = 1
+            p = og.from_coefficients(c)
+            assert gf2.poly_is_primitive(c) == og.is_primitive(p)
+            e = int.from_bytes(rng.bytes(n // 8 + 1), "little")
+            got = og.from_coefficients(gf2.poly_modexp(c, e))
+            assert got == og.modexp(p, e)
+    with pytest.raises(bbb._lib.BbbError, match="no factorisation"):
+        gf2.poly_is_primitive([1] + [0] * 16 + [1, 1])                  # degree 18: not in the table
+
+
+@pytest.mark.parametrize("n", (16, 32, 64, 128, 192, 256, 512))
+def test_the_references_found_matrices_are_accepted(n):
+    """The shipped matrices ARE rnghunt's results (software/rnghunt/matrices/N): its own acceptance test,
+    restated, must pass on every one of them; and a spoiled one must fail."""
+    from basebandboard_amd import recurrences
+    rows = recurrences.load_packed(recurrences.matrix_path(n))
+    coeffs, deg = gf2.lutopt_charpoly(rows)
+    assert deg == n and coeffs[0] == 1 and coeffs[-1] == 1
+    assert gf2.is_full_period(rows)
+    bad = [list(r) for r in rows]
+    bad[3] = bad[3][:-1]
+    assert not gf2.is_full_period(bad) or n == 16
+
+
+@pytest.mark.parametrize("n", (16, 32, 64, 128))
+def test_charpoly_equals_the_oracle(n):
+    from oracle import gf2poly as og
+    from basebandboard_amd import recurrences
+    rows = recurrences.load_packed(recurrences.matrix_path(n))
+    coeffs, deg = gf2.lutopt_charpoly(rows)
+    p, L = og.lutopt_charpoly(rows)
+    assert deg == L and og.from_coefficients(coeffs) == p and og.is_primitive(p)
+
+
+@pytest.mark.parametrize("k,seed,cand", [(16, 1, 0), (16, 1, 228), (32, 9, 4), (64, 2, 77), (192, 5, 3), (256, 1, 0), (512, 123456789, 2 ** 40)])
+def test_search_candidates(k, seed, cand):
+    """Candidate matrices: the C++ construction equals the restatement; 3 or 4 distinct taps per row,
+    column weights within one of each other (BinaryMatrix::random, binary_matrix.rs:81-101)."""
+    from oracle import gf2poly as og
+    rows = gf2.search_candidate(k, seed, cand)
+    assert rows == og.search_candidate(k, seed, cand)
+    assert all(len(r) in (3, 4) and len(set(r)) == len(r) for r in rows)
+    colw = np.bincount([c for r in rows for c in r], minlength=k)
+    assert colw.max() - colw.min() <= 1
+    assert 0.02 < sum(len(r) == 3 for r in rows) / k < 0.3 or k <= 32
+
+
+def test_candidate_acceptance_equals_the_oracle():
+    from oracle import gf2poly as og
+    hits = [c for c in range(600) if gf2.is_full_period(gf2.search_candidate(16, 1, c))]
+    assert hits == [c for c in range(600) if og.is_full_period(og.search_candidate(16, 1, c))] == [228, 234, 427, 544]
+
+
+def test_save_matrix_roundtrip(tmp_path):
+    from basebandboard_amd import recurrences
+    rows = gf2.search_candidate(64, 4, 2)
+    gf2.save_matrix(tmp_path / "out", rows)                             # rnghunt writes its result to `out` (rnghunt.rs:46)
+    text = (tmp_path / "out").read_text().splitlines()
+    assert len(text) == 64 and all(len(l) == 64 and set(l) <= {"0", "1"} for l in text)
+    assert [sorted(r) for r in recurrences.load_packed(tmp_path / "out")] == [sorted(r) for r in rows]

@@ -1,0 +1,72 @@
+"""The recurrence search of software/rnghunt on the GPU (bbb_lutopt_search) against the host arithmetic
+and the Python restatement: same accepted candidates, same counts."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def host_scan(gf2, k, seed, lo, hi):
+    full, acc = 0, []
+    for c in range(lo, hi):
+        rows = gf2.search_candidate(k, seed, c)
+        _, deg = gf2.lutopt_charpoly(rows)
+        full += deg == k
+        if deg == k and gf2.is_full_period(rows):
+            acc.append(c)
+    return full, acc
+
+
+@pytest.mark.parametrize("k,seed,n", [(16, 1, 700), (16, 77, 700), (32, 3, 1500), (64, 5, 1500)])
+def test_search_finds_the_first_accepted_candidate(gpu, k, seed, n):
+    from basebandboard_amd import gf2
+    from oracle import gf2poly as og
+    full, acc = host_scan(gf2, k, seed, 0, n)
+    idx, rows, st = gf2.search(k, seed=seed, first=0, count=n)
+    if not acc:
+        assert idx is None and st["tested"] == n and st["full_degree"] == full and st["primitive"] == 0
+        return
+    assert idx == acc[0]
+    assert rows == gf2.search_candidate(k, seed, idx) and og.is_full_period(rows)
+    # the range before the hit, exhaustively: every candidate examined, none accepted, same degree count
+    full0, acc0 = host_scan(gf2, k, seed, 0, idx)
+    idx0, _, st0 = gf2.search(k, seed=seed, first=0, count=idx)
+    assert idx0 is None and not acc0
+    assert st0["tested"] == idx and st0["full_degree"] == full0 and st0["primitive"] == 0
+    # and a window starting behind it finds the next one
+    if len(acc) > 1:
+        idx1, _, _ = gf2.search(k, seed=seed, first=acc[0] + 1, count=n - acc[0] - 1)
+        assert idx1 == acc[1]
+
+
+@pytest.mark.parametrize("k,count", [(128, 4000), (192, 6000), (256, 8000), (512, 20000)])
+def test_search_large_orders(gpu, k, count):
+    """The orders the reference searched (its tool is set to n = 192, rnghunt.rs:14): whatever comes back has
+    been re-checked by the host arithmetic inside the call; here also by the Python restatement, and a
+    sample of the rejected candidates before it is confirmed rejected."""
+    from basebandboard_amd import gf2
+    from oracle import gf2poly as og
+    idx, rows, st = gf2.search(k, seed=2017, first=0, count=count)
+    assert st["tested"] > 0 and st["full_degree"] <= st["tested"] and st["order_divides"] <= st["full_degree"]
+    if idx is None:
+        assert st["tested"] == count and st["primitive"] == 0
+        pytest.skip(f"no full-period matrix among {count} candidates for k={k}: {st}")
+    p, L = og.lutopt_charpoly(rows)
+    assert L == k and og.is_primitive(p)
+    rng = np.random.default_rng(k)
+    for c in rng.integers(0, idx, size=min(idx, 25)):
+        assert not gf2.is_full_period(gf2.search_candidate(k, 2017, int(c)))
+    if k & (k - 1):
+        return                                  # (generator handles exist for power-of-two orders only: the CLT tree)
+    # usable as a generator: full linear complexity of bit 0
+    import basebandboard_amd as bbb
+    u = bbb.LUTOPT.from_packed(rows, init=(1 << k) - 1, device=-1)
+    bits = [u.state_at(t + 1) & 1 for t in range(2 * k)]
+    assert gf2.berlekamp_massey(bits)[0] == k
+
+
+def test_search_errors(gpu):
+    from basebandboard_amd import gf2
+    with pytest.raises(Exception, match="search supports|no factorisation"):
+        gf2.search(20, count=10)
+    assert gf2.search(16, count=0)[0] is None
