@@ -106,3 +106,29 @@ def test_trial_errors(gpu):
     with pytest.raises(ValueError):
         gpu.run_trials(u, [gpu.Trial(nbits=10, amp=10, noise_var=16)])
     assert gpu.run_trials(u, []) == []
+
+
+def test_two_scan_form_of_the_grouped_kernel(oracle):
+    """The grouped kernel has two forms: one scan per setting on X = bit ? ~T : T (taken whenever the two
+    thresholds mirror each other, i.e. for every non-wrapping channel) and the plain two-scan form, which
+    BBB_BER_NO_FAST=1 forces.  Same counters, in a child process because the switch is read once."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = (
+        "import json, basebandboard_amd as g\n"
+        "u = g.LUTOPT.shipped(256)\n"
+        "ts = [g.Trial(nbits=300_001, amp=a, noise_var=nv, prbs_k=k, warmup=16) for a, nv, k in"
+        " [(100, 8, 31), (91, 8, 31), (37, 3, 31), (250, 15, 31), (64, 8, 31), (1, 1, 31), (77, 7, 31)]]\n"
+        "print(json.dumps(g.run_trials(u, ts)))\n")
+    outs = []
+    for env in ({}, {"BBB_BER_NO_FAST": "1"}):
+        r = subprocess.run([sys.executable, "-c", code], cwd=str(ROOT), env={**os.environ, **env}, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0] == outs[1]
+    m = oracle.Lutopt(path=oracle.data_path(256))
+    for (bits, errs), (a, nv) in zip(outs[0], [(100, 8), (91, 8), (37, 3), (250, 15), (64, 8), (1, 1), (77, 7)]):
+        assert (bits, errs) == m.ber_trial(1, 31, 1, a, nv, 16, 0, 300_001)
