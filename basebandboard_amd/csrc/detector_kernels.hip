@@ -171,9 +171,10 @@ det_serial_kernel(const u64 *__restrict src, u64 nbits, u64 nwords, u64 chunk_wo
 
 __global__ void __launch_bounds__(256)
 det_reduce_kernel(u64 nchunks, const DetCount *__restrict counts, u64 *__restrict totals) {
-    const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u64 v[4] = {0, 0, 0, 0};
-    if (c < nchunks) { v[0] = counts[c].err_synced; v[1] = counts[c].err_raw; v[2] = counts[c].reload_clocks; v[3] = counts[c].resyncs; }
+    for (u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x; c < nchunks; c += (u64)gridDim.x * blockDim.x) {
+        v[0] += counts[c].err_synced; v[1] += counts[c].err_raw; v[2] += counts[c].reload_clocks; v[3] += counts[c].resyncs;
+    }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         u64 x = v[q];
@@ -240,7 +241,7 @@ static int detector_stream_k(const u64 *src, u64 nbits, u64 *err, u64 *reload, b
     }
     u64 h[4] = {0, 0, 0, 0};
     (void)hipMemsetAsync(totals, 0, 4 * sizeof(u64), st);
-    hipLaunchKernelGGL(det_reduce_kernel, dim3(grid), dim3(256), 0, st, nchunks, counts, totals);
+    hipLaunchKernelGGL(det_reduce_kernel, dim3(grid < 512 ? grid : 512), dim3(256), 0, st, nchunks, counts, totals);
     hipError_t e = hipMemcpyAsync(h, totals, sizeof h, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     cleanup();
