@@ -263,10 +263,12 @@ def main():
                          "true_bound": "integer VALU (bit-sliced XOR/majority network), not HBM",
                          "valu_lane_ops_per_sample": round(ops_per_step / 32.0, 2),
                          "valu_net_tlaneops_s": round(ops_per_step / 32.0 * achieved / 1e3, 2),
-                         # measured V_BITOP3 issue ceiling at ONE wave per SIMD (the kernel needs the whole
-                         # register file): profiles/r01_design_ubench.log, 30.66 T lane-op/s chip-wide
-                         "valu_peak_1wave_tlaneops_s": 30.66,
-                         "valu_frac_net": round(ops_per_step / 32.0 * achieved / 1e3 / 30.66, 3)},
+                         # issue ceiling at ONE wave per SIMD (the kernel needs the whole register file): one VALU
+                         # instruction per 4 cycles per SIMD (SQ_ACTIVE_INST_VALU = SQ_INSTS_VALU quad-cycles,
+                         # profiles/r01_d_pmc_sq.json) = 256 CUs x 4 SIMDs x 64 lanes x 2.4 GHz / 4; the shader clock
+                         # observed under this kernel is 2.16 GHz (GRBM_GUI_ACTIVE), i.e. 35.4 at the real clock
+                         "valu_peak_1wave_tlaneops_s": 39.32,
+                         "valu_frac_net": round(ops_per_step / 32.0 * achieved / 1e3 / 39.32, 3)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
