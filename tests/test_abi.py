@@ -137,3 +137,25 @@ def test_channel_helpers():
     assert channel.shard(10, 1, 4) == [1, 5, 9]
     with pytest.raises(ValueError, match="invalid for PRBS"):
         bbb.Trial(10, 1, 1, prbs_k=12)
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/bbb.h must be usable from C (the cgo / JNI / FFI side of a host): C11, no C++ constructs."""
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text('#include "bbb.h"\nint main(void) { bbb_trial_cfg c; bbb_detector_stats s; (void)c; (void)s; return BBB_OK; }\n')
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", f"-I{ROOT / 'include'}", str(src)])
+
+
+def test_cpp_caller_links_against_the_library():
+    """examples/bbb_mc.cpp: a plain C++ program on the C ABI (built by build()); it must link and, without a
+    GPU, fail with the library's own error rather than run anything on the CPU."""
+    import subprocess
+    exe = ROOT / "examples" / "bbb_mc"
+    if not exe.exists():
+        subprocess.check_call(["make", "-C", str(ROOT / "examples")])
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("covered by the GPU test")
+    r = subprocess.run([str(exe), "--bits", "1000"], cwd=str(ROOT), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and ("no usable" in r.stderr.lower() or "device" in r.stderr.lower() or "hip" in r.stderr.lower())

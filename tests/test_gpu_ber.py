@@ -132,3 +132,23 @@ def test_two_scan_form_of_the_grouped_kernel(oracle):
     m = oracle.Lutopt(path=oracle.data_path(256))
     for (bits, errs), (a, nv) in zip(outs[0], [(100, 8), (91, 8), (37, 3), (250, 15), (64, 8), (1, 1), (77, 7)]):
         assert (bits, errs) == m.ber_trial(1, 31, 1, a, nv, 16, 0, 300_001)
+
+
+def test_cpp_caller_of_the_c_abi(gpu, oracle):
+    """examples/bbb_mc: no Python, no torch -- library, hipMalloc and printf.  Its counters for a small sweep
+    equal the oracle's; its loopback line reports a clean stream."""
+    import subprocess
+    from conftest import ROOT
+    exe = ROOT / "examples" / "bbb_mc"
+    if not exe.exists():
+        subprocess.check_call(["make", "-C", str(ROOT / "examples")])
+    r = subprocess.run([str(exe), "--bits", "200000", "--from", "2", "--to", "6", "--step", "2", "--k", "15", "--nv", "7", "--loopback", "3000000"],
+                       cwd=str(ROOT), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    rows = [l.split() for l in r.stdout.splitlines() if l and not l.startswith("#")]
+    assert len(rows) == 3
+    m = oracle.Lutopt(path=oracle.data_path(256))
+    for row in rows:
+        amp, bits, errs = int(row[1]), int(row[2]), int(row[3])
+        assert (bits, errs) == m.ber_trial(1, 15, 1, amp, 7, 16, 0, 200_000)
+    assert "loopback: 3000000 bits, 0 errors" in r.stdout
