@@ -121,3 +121,23 @@ def test_prbs31_beyond_2_pow_35_bits(gpu, oracle):
     assert gpu.PRBSErrorDetector(31).count_errors(buf, nbits, first_bit=5) == 2
     del buf
     torch.cuda.empty_cache()
+
+
+def test_baseline_config3_full_size_with_error_mask(gpu):
+    """BASELINE.json configs[2] at its full size: 1e10 bits of PRBS-31 through generator -> checker, clean and
+    with a fixed XOR mask on every (1e6+7)-th bit: exact counts from the phase-known
+    checker AND from the self-synchronising detector (isolated errors: each flagged exactly once)."""
+    nbits = 10_000_000_000
+    p = gpu.PRBS(31)
+    det = gpu.PRBSErrorDetector(31)
+    buf2 = p.generate(nbits)
+    assert det.count_errors(buf2, nbits) == 0
+    pos = torch.arange(0, nbits, 1_000_007, dtype=torch.int64, device=buf2.device)
+    flip = torch.zeros_like(buf2)
+    flip.index_put_((pos // 64,), torch.ones_like(pos) << (pos % 64))      # distinct words
+    buf2 ^= flip
+    del flip
+    assert det.count_errors(buf2, nbits) == pos.numel() == 10_000
+    st = det.run_stream(buf2, nbits)
+    first_in_reload = 1 if st["reload_clocks"] > 0 else 0                  # bit 0 arrives during the reload out of reset
+    assert st["errors_raw"] + 0 >= 10_000 - first_in_reload and st["errors"] in (10_000, 10_000 - first_in_reload)
