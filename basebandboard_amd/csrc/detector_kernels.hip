@@ -38,38 +38,48 @@ __host__ __device__ constexpr int det_tap_of(int k) {
 struct DetCount { u64 err_synced, err_raw, reload_clocks, resyncs; };
 
 // 64 (or `nvalid` < 64) clocks on input word w.  Output bit i of errw / rlw = `err` / `reload` sampled
-// after clock i, what the reference testbench reads (prbs.py:146-150).
-template <int K>
+// after clock i, what the reference testbench reads (prbs.py:146-150).  All one-bit signals are kept as
+// 0 / 1 in bit 0 of a register so that every line below is one instruction:
+//   e   = bit_in ^ feedback                      (:79; it is also the `err` output of the previous clock)
+//   rl  = reload_ctr != 0 = min(reload_ctr, 1)   (:99)
+//   pin = rl ? bit_in : feedback = fb ^ (e & rl) (:75-76)
+template <int K, bool EMIT>
 __device__ __forceinline__ void det_word(DetState &s, u64 w, int nvalid, u64 &errw, u64 &rlw, unsigned &trig) {
     constexpr int TAP = det_tap_of(K);
     constexpr uint32_t MASK = (uint32_t)((1ull << K) - 1ull);
     uint32_t prbs = s.prbs, err_sr = s.err_sr, bit_in = s.bit_in;
-    int reload_ctr = s.reload_ctr;
+    uint32_t ctr = (uint32_t)s.reload_ctr;
     uint32_t fb = ((prbs >> (K - 1)) ^ (prbs >> (TAP - 1))) & 1u;            // prbs.py:73-74
+    uint32_t e = bit_in ^ fb, rl = ctr < 1u ? ctr : 1u;
     errw = 0; rlw = 0;
 #pragma unroll 1
     for (int half = 0; half < 2; half++) {
         uint32_t wh = (uint32_t)(w >> (32 * half)), eh = 0, rh = 0;
         const int n = nvalid - 32 * half < 0 ? 0 : (nvalid - 32 * half > 32 ? 32 : nvalid - 32 * half);
-#pragma unroll 4
+#pragma unroll 8
         for (int i = 0; i < n; i++) {
-            const bool rl = reload_ctr != 0;
-            const uint32_t pin = rl ? bit_in : fb;                            // :75-76
-            const uint32_t e = bit_in ^ fb;                                   // :79
             const bool t = __builtin_popcount(err_sr) > K / 2;                // :86-87, :92
-            prbs = ((prbs << 1) | pin) & MASK;                                // :68
+            const uint32_t pin = __builtin_amdgcn_bitop3_b32(fb, e, rl, 0x78);     // fb ^ (e & rl)
+            prbs = (prbs << 1) | pin;                                         // :68 (bits >= K are never read)
             err_sr = t ? 0u : (((err_sr << 1) | e) & MASK);                   // :81, :94
-            reload_ctr = t ? K + K / 2 : (rl ? reload_ctr - 1 : reload_ctr);  // :93, :95-97
-            trig += t ? 1u : 0u;
+            const uint32_t dec = ctr - rl;                                    // :95-97
+            ctr = t ? (uint32_t)(K + K / 2) : dec;                            // :93
+            if (EMIT) trig += t ? 1u : 0u;
             bit_in = (wh >> i) & 1u;                                          // :66
             fb = ((prbs >> (K - 1)) ^ (prbs >> (TAP - 1))) & 1u;
-            eh |= (bit_in ^ fb) << i;
-            rh |= (reload_ctr != 0 ? 1u : 0u) << i;
+            e = bit_in ^ fb;
+            rl = ctr < 1u ? ctr : 1u;
+            if (EMIT) {
+                eh |= e << i;
+                rh |= rl << i;
+            }
         }
-        errw |= (u64)eh << (32 * half);
-        rlw |= (u64)rh << (32 * half);
+        if (EMIT) {
+            errw |= (u64)eh << (32 * half);
+            rlw |= (u64)rh << (32 * half);
+        }
     }
-    s.prbs = prbs; s.err_sr = err_sr; s.reload_ctr = reload_ctr; s.bit_in = bit_in;
+    s.prbs = prbs & MASK; s.err_sr = err_sr; s.reload_ctr = (int32_t)ctr; s.bit_in = bit_in;
 }
 
 __device__ __forceinline__ DetState det_reset(int k) {
@@ -94,7 +104,7 @@ __device__ __forceinline__ void det_span(DetState &s, const u64 *__restrict src,
         const int nvalid = left >= 64 ? 64 : (int)left;
         u64 ew, rw;
         unsigned trig = 0;
-        det_word<K>(s, src[w], nvalid, ew, rw, trig);
+        det_word<K, EMIT>(s, src[w], nvalid, ew, rw, trig);
         if (EMIT) {
             if (err) err[w] = ew;
             if (reload) reload[w] = rw;
@@ -191,43 +201,44 @@ static int detector_stream_k(const u64 *src, u64 nbits, u64 *err, u64 *reload, b
     const u64 chunk_words = chunk_bits / 64, warm_words = (warm_bits + 63) / 64;
     const u64 nchunks = (nwords + chunk_words - 1) / chunk_words;
     if (nchunks > 0x7fffffffull) return fail(BBB_EINVAL, "too many chunks; raise chunk_bits");
-    DetState *spec = nullptr, *endst = nullptr;
-    DetCount *counts = nullptr;
-    unsigned *list = nullptr, *nlist = nullptr;
-    u64 *totals = nullptr;
-    BBB_HIP(hipMalloc(&spec, nchunks * sizeof(DetState)));
-    BBB_HIP(hipMalloc(&endst, nchunks * sizeof(DetState)));
-    BBB_HIP(hipMalloc(&counts, nchunks * sizeof(DetCount)));
-    BBB_HIP(hipMalloc(&list, nchunks * sizeof(unsigned)));
-    BBB_HIP(hipMalloc(&nlist, sizeof(unsigned)));
-    BBB_HIP(hipMalloc(&totals, 4 * sizeof(u64)));
-    auto cleanup = [&]() {
-        (void)hipFree(spec); (void)hipFree(endst); (void)hipFree(counts); (void)hipFree(list); (void)hipFree(nlist); (void)hipFree(totals);
-    };
+    // one stream-ordered allocation: spec | endst | counts | list | nlist + totals
+    const size_t o_spec = 0, o_end = o_spec + nchunks * sizeof(DetState), o_cnt = o_end + nchunks * sizeof(DetState),
+                 o_list = o_cnt + nchunks * sizeof(DetCount), o_tail = (o_list + nchunks * sizeof(unsigned) + 7) & ~(size_t)7,
+                 total = o_tail + 8 * sizeof(u64);
+    char *ws = nullptr;
+    BBB_HIP(hipMallocAsync((void **)&ws, total, st));
+    DetState *spec = (DetState *)(ws + o_spec), *endst = (DetState *)(ws + o_end);
+    DetCount *counts = (DetCount *)(ws + o_cnt);
+    unsigned *list = (unsigned *)(ws + o_list);
+    u64 *tail = (u64 *)(ws + o_tail);                 // tail[0..3] totals, low half of tail[4] = number of bad chunks
+    unsigned *nlist = (unsigned *)(tail + 4);
+    auto cleanup = [&]() { (void)hipFreeAsync(ws, st); };
     const unsigned grid = (unsigned)((nchunks + 255) / 256);
     hipLaunchKernelGGL(det_chunk_kernel<K>, dim3(grid), dim3(256), 0, st, 0, src, nbits, nwords, chunk_words, warm_words,
                        nchunks, (const unsigned *)nullptr, 0u, spec, endst, counts, err, reload);
     u64 rerun = 0, passes = 0;
     bool serial = false;
+    u64 h[5] = {0, 0, 0, 0, 0};
     for (;;) {
-        unsigned nbad = 0;
-        if (nchunks > 1) {
-            (void)hipMemsetAsync(nlist, 0, sizeof(unsigned), st);
+        // verify, and reduce at once in the hope that the chain is already consistent: one round trip
+        (void)hipMemsetAsync(tail, 0, 5 * sizeof(u64), st);
+        if (nchunks > 1)
             hipLaunchKernelGGL(det_verify_kernel, dim3((unsigned)((nchunks + 254) / 256)), dim3(256), 0, st, nchunks, spec, endst,
                                list, nlist);
-            hipError_t e = hipMemcpyAsync(&nbad, nlist, sizeof(unsigned), hipMemcpyDeviceToHost, st);
-            if (e == hipSuccess) e = hipStreamSynchronize(st);
-            if (e != hipSuccess) { cleanup(); BBB_HIP(e); }
-        }
+        hipLaunchKernelGGL(det_reduce_kernel, dim3(grid < 512 ? grid : 512), dim3(256), 0, st, nchunks, counts, tail);
+        hipError_t e = hipMemcpyAsync(h, tail, sizeof h, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { cleanup(); BBB_HIP(e); }
+        const unsigned nbad = (unsigned)(h[4] & 0xffffffffull);
         if (!nbad) break;
         passes++;
         if (passes > 32) {
             // the speculation does not settle on this stream: continue serially from the first bad chunk
-            std::vector<unsigned> h(nbad);
-            hipError_t e = hipMemcpy(h.data(), list, nbad * sizeof(unsigned), hipMemcpyDeviceToHost);
+            std::vector<unsigned> hb(nbad);
+            e = hipMemcpy(hb.data(), list, nbad * sizeof(unsigned), hipMemcpyDeviceToHost);
             if (e != hipSuccess) { cleanup(); BBB_HIP(e); }
-            unsigned c0 = h[0];
-            for (unsigned x : h) c0 = x < c0 ? x : c0;
+            unsigned c0 = hb[0];
+            for (unsigned x : hb) c0 = x < c0 ? x : c0;
             hipLaunchKernelGGL(det_serial_kernel<K>, dim3(1), dim3(64), 0, st, src, nbits, nwords, chunk_words, nchunks, (u64)c0,
                                spec, endst, counts, err, reload);
             serial = true;
@@ -239,13 +250,7 @@ static int detector_stream_k(const u64 *src, u64 nbits, u64 *err, u64 *reload, b
         hipLaunchKernelGGL(det_chunk_kernel<K>, dim3((nbad + 255) / 256), dim3(256), 0, st, 1, src, nbits, nwords, chunk_words,
                            warm_words, nchunks, (const unsigned *)list, nbad, spec, endst, counts, err, reload);
     }
-    u64 h[4] = {0, 0, 0, 0};
-    (void)hipMemsetAsync(totals, 0, 4 * sizeof(u64), st);
-    hipLaunchKernelGGL(det_reduce_kernel, dim3(grid < 512 ? grid : 512), dim3(256), 0, st, nchunks, counts, totals);
-    hipError_t e = hipMemcpyAsync(h, totals, sizeof h, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
     cleanup();
-    BBB_HIP(e);
     BBB_HIP(hipGetLastError());
     if (stats) {
         stats->bits = nbits;
