@@ -191,6 +191,9 @@ awgn256_kernel(const uint32_t *__restrict planes, int8_t *__restrict dst, unsign
     const unsigned lane = threadIdx.x;
     const unsigned long long wave = blockIdx.x;
     const unsigned long long LG = wave * 64 + lane;
+    // highest wave priority: when the seeding of the next fill (bbb_awgn_prefetch) shares the SIMD it gets the
+    // issue slots this wave leaves free instead of every other one
+    __builtin_amdgcn_s_setprio(3);
 
     // lutopt256_step yields the sample of the state it is GIVEN (and its successor): the planes hold
     // the state before the first sample, so advance once
