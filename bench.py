@@ -153,6 +153,21 @@ def main():
     kern_avg_ms = kern_ms / max(calls, 1)
     achieved = NSAMP / (kern_avg_ms * 1e-3) / 1e9 if kern_avg_ms > 0 else 0.0
 
+    # attainable write ceiling on this box: a plain streaming fill of the same 1e9 bytes
+    fill_gbs = None
+    if rank == 0:
+        fb = torch.empty(NSAMP, dtype=torch.int8, device=f"cuda:{local_rank}")
+        fb.fill_(1)
+        f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        f0.record()
+        for _ in range(5):
+            fb.fill_(1)
+        f1.record()
+        torch.cuda.synchronize()
+        fill_gbs = 5 * NSAMP / f0.elapsed_time(f1) / 1e6
+        del fb
+
     # PMC-measured HBM write bytes per launch, if a profile summary of this command is committed
     traffic = None
     pmc = ROOT / "profiles" / "r01_awgn256_pmc.json"
@@ -269,6 +284,8 @@ def main():
                          "kernel": "awgn256_kernel", "kernel_ms_avg": round(kern_avg_ms, 4),
                          "seed_ms_avg": round(seed_ms / max(calls, 1), 4), "launches_timed": int(calls),
                          "algorithmic_bytes_per_launch": NSAMP,
+                         "streaming_fill_gb_s": round(fill_gbs, 1) if fill_gbs else None,
+                         "frac_of_streaming_fill": round(achieved / fill_gbs, 4) if fill_gbs else None,
                          "true_bound": "integer VALU (bit-sliced XOR/majority network), not HBM",
                          "valu_lane_ops_per_sample": round(ops_per_step / 32.0, 2),
                          "valu_net_tlaneops_s": round(ops_per_step / 32.0 * achieved / 1e3, 2),
