@@ -123,7 +123,7 @@ __device__ __forceinline__ void xor_inplace(u32x4 &a, const u32x4 &b) {
 template <int K, bool CHECK, int WPL, bool LW>
 __global__ void __launch_bounds__(64, 2)   // >= 2 waves per SIMD: at most 256 registers
 prbs_stream_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwords, u64 rows_per_wave,
-                   u64 *__restrict buf, u64 *__restrict nerr) {
+                   u64 *__restrict buf, u64 *__restrict nerr, int nt) {
     typedef typename LaneWords<WPL>::type lw_t;
     constexpr int TAP = tap_of(K);
     constexpr int RW = 64 * WPL;                 // words per row
@@ -277,8 +277,13 @@ prbs_stream_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwords,
             } else {
 #pragma unroll
                 for (int i = 0; i < K; i++) xor_inplace(V[i], V[(i - TAP + K) % K]);
+                if (nt) {        // BBB_PRBS_FILL_NT=1 (timing experiment): stores that do not stay in the caches
 #pragma unroll
-                for (int i = 0; i < K; i++) reinterpret_cast<lw_t *>(rowp + (u64)i * RW)[lane] = V[i];
+                    for (int i = 0; i < K; i++) __builtin_nontemporal_store(V[i], &reinterpret_cast<lw_t *>(rowp + (u64)i * RW)[lane]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < K; i++) reinterpret_cast<lw_t *>(rowp + (u64)i * RW)[lane] = V[i];
+                }
             }
             continue;
         }
@@ -342,6 +347,7 @@ static int launch_stream_w(int k, int ki, u64 init_state, u64 first_bit, u64 nbi
 #define BBB_PRBS_FN(KK) case KK: fn = (const void *)prbs_stream_kernel<KK, CHECK, WPL, LW>; break;
     switch (k) { BBB_PRBS_FN(7) BBB_PRBS_FN(9) BBB_PRBS_FN(11) BBB_PRBS_FN(15) BBB_PRBS_FN(20) BBB_PRBS_FN(23) BBB_PRBS_FN(31) }
 #undef BBB_PRBS_FN
+    static const int nt = (!CHECK && std::getenv("BBB_PRBS_FILL_NT")) ? 1 : 0;
     static int cached_per_cu[8] = {0};                 // per K (this function is instantiated per CHECK/WPL/LW)
     int &slot = cached_per_cu[ki];
     if (slot == 0) {
@@ -364,7 +370,7 @@ static int launch_stream_w(int k, int ki, u64 init_state, u64 first_bit, u64 nbi
 #define BBB_PRBS_CASE(KK)                                                                                       \
     case KK:                                                                                                    \
         hipLaunchKernelGGL((prbs_stream_kernel<KK, CHECK, WPL, LW>), grid, block, 0, st, ki, init_state, first_bit, \
-                           nbits, nwords, rpw, buf, nerr);                                                      \
+                           nbits, nwords, rpw, buf, nerr, nt);                                                  \
         break;
     switch (k) {
         BBB_PRBS_CASE(7) BBB_PRBS_CASE(9) BBB_PRBS_CASE(11) BBB_PRBS_CASE(15)
