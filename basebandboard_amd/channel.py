@@ -106,6 +106,23 @@ def sweep(trials, runner, rank=0, world=1, group=None):
     return total
 
 
+def sweep_seeds(trials, runner, world=1, group=None):
+    """The other way to shard a Monte-Carlo sweep (points x seeds): EVERY rank
+    runs all `trials` on its own generator (a different `init` per rank), so that each rank makes one
+    pass over its noise stream for the whole sweep, and the counters of the ranks are summed with ONE
+    all-reduce: `world` times the bits per point in the time of one sweep.  Returns int64 [len(trials), 2]."""
+    import torch.distributed as dist
+    total = runner(list(trials), len(trials)).clone()
+    if world > 1:
+        if dist.get_backend(group) == "gloo" and total.is_cuda:      # CPU rehearsal of a GPU sweep
+            host = total.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            total.copy_(host)
+        else:
+            dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+    return total
+
+
 def gpu_runner(urng):
     """The `runner` for `sweep` on a GPU rank."""
     def run(local_trials, n):

@@ -251,12 +251,15 @@ def main():
                                        "note": "bbb_lutopt_search: build + 512 steps + Berlekamp-Massey + primitivity per wavefront"}
         # BER sweep (BASELINE configs[3]/[4]): Eb/N0 0..10 dB, 1e9 bits/point, sharded over ranks
         # (point i -> rank i % world), ONE all-reduce (RCCL) of the uint64 counters.
+        # N > 1 (BASELINE configs[4]): points x seeds -- every rank runs all 11 points on its own seed (one noise
+        # pass per rank), the counters are summed over ranks: N times the bits per point in the same time.
         nv = 8
         trials = [channel.Trial(nbits=1_000_000_000, amp=channel.amp_for_ebn0(db, nv), noise_var=nv) for db in range(11)]
-        channel.sweep(trials, channel.gpu_runner(u), rank=rank, world=world)   # untimed: builds the jump plans
+        us = u if world == 1 else bbb.LUTOPT.shipped(256, init=1 + rank, device=local_rank)
+        channel.sweep_seeds(trials, channel.gpu_runner(us), world=world)       # untimed: builds the jump plans
         torch.cuda.synchronize(); barrier()
         tb = time.perf_counter()
-        total = channel.sweep(trials, channel.gpu_runner(u), rank=rank, world=world)
+        total = channel.sweep_seeds(trials, channel.gpu_runner(us), world=world)
         torch.cuda.synchronize(); barrier()
         tber = time.perf_counter() - tb
         tot = total.cpu().tolist()
@@ -265,7 +268,8 @@ def main():
                         "ber": e / b if b else None, "q_theory": channel.ber_theory(channel.ebn0_db(t.amp, nv))}
                        for t, (b, e) in zip(trials, tot)],
             "gbit_s": round(sum(b for b, _ in tot) / tber / 1e9, 2), "seconds": round(tber, 4),
-            "reduce": "torch.distributed.all_reduce(int64[11,2], SUM) over RCCL" if world > 1 else "single rank"}
+            "seeds": world,
+            "reduce": "torch.distributed.all_reduce(int64[11,2], SUM) over RCCL, one seed per rank" if world > 1 else "single rank"}
 
     if rank == 0:
         out = {

@@ -71,3 +71,51 @@ def test_shard_is_a_partition():
             parts = [shard(n, r, world) for r in range(world)]
             assert sorted(i for p in parts for i in p) == list(range(n))
             assert max(map(len, parts)) - min(map(len, parts)) <= 1
+
+
+def _oracle_runner_seed(seed):
+    import sys
+    sys.path.insert(0, str(ROOT))
+    import oracle as O
+    m = O.Lutopt(path=O.data_path(256))
+
+    def run(local_trials, n):
+        out = torch.zeros((n, 2), dtype=torch.int64)
+        for i, t in enumerate(local_trials):
+            b, e = m.ber_trial(seed, t.prbs_k, t.prbs_state, t.amp, t.noise_var, t.warmup, t.first_bit, t.nbits)
+            out[i, 0], out[i, 1] = b, e
+        return out
+    return run
+
+
+def _worker_seeds(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from basebandboard_amd.channel import sweep_seeds
+    total = sweep_seeds(_trials(), _oracle_runner_seed(1 + rank), world=world)
+    q.put((rank, total.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_seed_sharded_sweep_sums_the_seeds():
+    """points x seeds (BASELINE configs[4]): every rank runs all points on its own seed; the reduced counters
+    are the sums of the per-seed single-rank sweeps."""
+    from basebandboard_amd.channel import sweep_seeds
+    per_seed = [sweep_seeds(_trials(), _oracle_runner_seed(s), world=1).tolist() for s in (1, 2)]
+    expect = [[a[0] + b[0], a[1] + b[1]] for a, b in zip(*per_seed)]
+    assert per_seed[0] != per_seed[1]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_seeds, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0] == got[1] == expect
