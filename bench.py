@@ -70,6 +70,23 @@ def cpu_baseline():
             "threads_value": round(nthr * n / dtn / 1e9, 5), "threads": nthr}
 
 
+def cpu_baseline_other():
+    """The oracle's restatements of configs[2] / configs[3] on one host core (bounded samples), for `extra`."""
+    import oracle as O
+    lib = O.lib(path="/tmp/libbbb_oracle_native.so")
+    nb = 400_000_000
+    t0 = time.perf_counter()
+    O.prbs_packed(31, nb, fast=True, _lib=lib)
+    tp = time.perf_counter() - t0
+    m = O.Lutopt(path=O.data_path(256), _lib=lib)
+    nbe = 2_000_000
+    t0 = time.perf_counter()
+    m.ber_trial(1, 31, 1, 128, 8, WARM_STATE, 0, nbe)
+    tb = time.perf_counter() - t0
+    return {"prbs31_fill_gbit_s": round(nb / tp / 1e9, 3), "ber_trial_mbit_s": round(nbe / tb / 1e6, 2), "cores": 1, "kind": "port",
+            "sample": f"{nb} PRBS-31 bits (word-parallel restatement); one {nbe}-bit BPSK trial (LUTOPT-256 + CLT + channel)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -302,6 +319,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+            if extra:
+                extra["cpu_baseline_other"] = cpu_baseline_other()
         if extra:
             out["extra"] = extra
         print(json.dumps(out))
