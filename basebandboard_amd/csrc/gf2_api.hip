@@ -4,6 +4,7 @@
 //                      sequence; the search tool applies it to bit 0 of 2n recurrence steps,
 //                      src/bin/rnghunt.rs:28-36)
 //   recur              software/rnghunt/src/binary_matrix.rs:68-76 (bit 0 of successive A x)
+//   dot                binary_matrix.rs:52-63 (A x)
 //   poly_modexp / poly_is_primitive   src/binary_polynomial.rs:135-216 (arithmetic in gf2poly.hpp)
 //   lutopt_charpoly / is_full_period  the acceptance test of the search tool, src/bin/rnghunt.rs:27-46
 //   lutopt_save_matrix_file           its output format, src/bin/rnghunt.rs:51-53
@@ -67,6 +68,19 @@ int bbb_gf2_recur(int nrows, int ncols, const uint64_t *col_words, const uint8_t
         A.matvec(x, x);
         out_bits[s] = (uint8_t)(x[0] & 1ull);
     }
+    return BBB_OK;
+}
+
+// BinaryMatrix::dot (binary_matrix.rs:52-63) on the same storage: y = A x over GF(2), any shape up to 512 x 512.
+int bbb_gf2_dot(int nrows, int ncols, const uint64_t *col_words, const uint8_t *x_bits, uint8_t *out_bits) {
+    if (!col_words || !x_bits || !out_bits) return fail(BBB_EINVAL, "null argument");
+    if (nrows < 1 || ncols < 1 || nrows > BBB_MAX_K || ncols > BBB_MAX_K) return fail(BBB_EINVAL, "shape must be within 512 x 512");
+    const int wpc = (nrows + 63) / 64;
+    uint64_t acc[8] = {0};
+    for (int c = 0; c < ncols; c++)
+        if (x_bits[c] & 1)
+            for (int w = 0; w < wpc; w++) acc[w] ^= col_words[(size_t)c * wpc + w];
+    for (int r = 0; r < nrows; r++) out_bits[r] = (uint8_t)((acc[r / 64] >> (63 - (r % 64))) & 1ull);
     return BBB_OK;
 }
 

@@ -38,6 +38,16 @@ def recur(nrows, ncols, col_words, x_bits, nsteps):
     return out
 
 
+def dot(nrows, ncols, col_words, x_bits):
+    """BinaryMatrix::dot on rnghunt's column-major, MSbit-first words (binary_matrix.rs:52-63)."""
+    cw = np.array(col_words, dtype=np.uint64)
+    xb = np.array(x_bits, dtype=np.uint8)
+    out = np.zeros(nrows, dtype=np.uint8)
+    p = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint8))  # noqa: E731
+    _lib.check(_lib.lib().bbb_gf2_dot(nrows, ncols, cw.ctypes.data_as(C.POINTER(C.c_uint64)), p(xb), p(out)), "bbb_gf2_dot")
+    return out
+
+
 def _u8(a):
     return a.ctypes.data_as(C.POINTER(C.c_uint8))
 

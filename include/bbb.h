@@ -242,6 +242,8 @@ int bbb_gf2_berlekamp_massey(const uint8_t *bits, uint64_t n, uint8_t *coeffs_ou
 int bbb_gf2_recur(int nrows, int ncols, const uint64_t *col_words, const uint8_t *x_bits, int nsteps,
                   uint8_t *out_bits);
 
+/* BinaryMatrix::dot (binary_matrix.rs:52-63), same storage: out_bits[r] = (A x)[r], nrows bytes. */
+int bbb_gf2_dot(int nrows, int ncols, const uint64_t *col_words, const uint8_t *x_bits, uint8_t *out_bits);
 /* BinaryPolynomial::is_primitive (software/rnghunt/src/binary_polynomial.rs:178-216).  coeffs[i] is
  * the coefficient of x^(ncoeffs-1-i), the order of BinaryPolynomial::from_coefficients (:48-53).
  * *result = 1 / 0.  The test needs the prime factors of 2^deg - 1: the degrees in

@@ -26,6 +26,18 @@ def test_recur_rnghunt_kat(golden_gf2):
     assert out.tolist() == g["out_bits"]
 
 
+def test_dot_rnghunt_kat(golden_gf2):
+    g = golden_gf2["test_dot"]                                                  # binary_matrix.rs:133-180 (64 x 128)
+    out = gf2.dot(g["nrows"], g["ncols"], [int(w, 16) for w in g["col_words_hex"]], g["x_bits"])
+    assert out.tolist() == g["out_bits"]
+    r = golden_gf2["test_recur"]                                                # recur = repeated dot, first bit
+    x, bits = r["x_bits"], []
+    for _ in range(r["n"]):
+        x = gf2.dot(r["nrows"], r["ncols"], [int(w, 16) for w in r["col_words_hex"]], x).tolist()
+        bits.append(x[0])
+    assert bits == r["out_bits"]
+
+
 @pytest.mark.parametrize("k", sorted(bbb.TAPS))
 def test_prbs_golden_bits_have_the_right_minimal_polynomial(golden_prbs, k):
     bits = [int(c) for c in golden_prbs[str(k)]["bits"][: 2 * k + 8]]

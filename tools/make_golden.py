@@ -136,6 +136,22 @@ def main():
             "out_bits": [1, 0, 1, 1, 0, 0, 0, 1, 1, 1, 0, 0, 0, 1, 1, 1, 0, 0, 0, 1, 1, 1, 0, 0],
         }
     }
+    # binary_matrix.rs:133-180 (test_dot): a 64 x 128 matrix, a 128-bit vector and their product; the numbers
+    # are read out of the reference's test at generation time (data, not code)
+    import re
+    ref = pathlib.Path("/root/reference/software/rnghunt/src/binary_matrix.rs")
+    if ref.exists():
+        src = ref.read_text()
+        body = src[src.index("fn test_dot()"):src.index("fn test_recur()")]
+        words = re.findall(r"0x[0-9A-Fa-f]{16}", body)
+        vecs = re.findall(r"&?\[\s*((?:[01],\s*)+[01])\s*\]", body)
+        assert len(words) == 128 and len(vecs) == 2
+        gf2["test_dot"] = {"nrows": 64, "ncols": 128, "col_words_hex": words,
+                           "x_bits": [int(c) for c in re.findall(r"[01]", vecs[0])],
+                           "out_bits": [int(c) for c in re.findall(r"[01]", vecs[1])]}
+        assert len(gf2["test_dot"]["x_bits"]) == 128 and len(gf2["test_dot"]["out_bits"]) == 64
+    else:                                   # no reference checkout here: keep the committed vector
+        gf2["test_dot"] = json.load(open(OUT / "gf2.json"))["test_dot"]
     json.dump(gf2, open(OUT / "gf2.json", "w"), indent=0)
     # ---- pulse shaper (gateware/bbb/bitshaper.py) ----------------------------------------
     # coefficient sets exactly as PRBSShaper.from_rcf computes them (bitshaper.py:97-109) for the
