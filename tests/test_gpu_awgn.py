@@ -194,3 +194,18 @@ def test_prefetch_hint_changes_nothing_but_timing(gpu, oracle):
     g.prefetch(n, first_step=16)
     t = gpu.Trial(nbits=50_000, amp=100, noise_var=8)
     assert gpu.run_trials(u, [t])[0] == m.ber_trial(1, 31, 1, 100, 8, 16, 0, 50_000)
+
+
+def test_baseline_config2_whole_buffer(gpu, oracle):
+    """BASELINE.json configs[1] at its full size, every byte: 1e9 samples of the sequential reference stream
+    (init = 1, 16 warm-up steps as the reference's test skips, rng.py:161-162) against the oracle's single
+    sequential pass (~25 s of one host core).  Covers every segment seam, every round and the ragged tail."""
+    n = 1_000_000_000
+    u = gpu.LUTOPT.shipped(256)
+    got = gpu.CLTGRNG(u).generate(n, first_step=16).cpu().numpy()
+    m = oracle.Lutopt(path=oracle.data_path(256))
+    exp = m.awgn(1, 16, n, fast=True)
+    assert got.shape == exp.shape and np.array_equal(got, exp)
+    # sigma^2 = 2^(log2 n - 2) = 64 (software/clt-grng/clt-grng-evaluate.py:18-21), mean 0
+    x = got[: 50_000_000].astype(np.float64)
+    assert abs(x.mean()) < 0.01 and abs(x.var() - 64.0) < 0.1
