@@ -196,16 +196,32 @@ def test_prefetch_hint_changes_nothing_but_timing(gpu, oracle):
     assert gpu.run_trials(u, [t])[0] == m.ber_trial(1, 31, 1, 100, 8, 16, 0, 50_000)
 
 
-def test_baseline_config2_whole_buffer(gpu, oracle):
+def test_baseline_configs_2_and_4_at_full_size(gpu, oracle):
     """BASELINE.json configs[1] at its full size, every byte: 1e9 samples of the sequential reference stream
     (init = 1, 16 warm-up steps as the reference's test skips, rng.py:161-162) against the oracle's single
-    sequential pass (~25 s of one host core).  Covers every segment seam, every round and the ragged tail."""
+    sequential pass (~25 s of one host core).  Covers every segment seam, every round and the ragged tail.
+    The same oracle stream then prices three points of configs[3] (1e9 bits each, PRBS-31, one sample per
+    bit): the channel of tx.py:75-81 / rx.py:29 evaluated with numpy on the host must give the fused kernel's
+    error counts exactly."""
     n = 1_000_000_000
     u = gpu.LUTOPT.shipped(256)
     got = gpu.CLTGRNG(u).generate(n, first_step=16).cpu().numpy()
     m = oracle.Lutopt(path=oracle.data_path(256))
     exp = m.awgn(1, 16, n, fast=True)
     assert got.shape == exp.shape and np.array_equal(got, exp)
+    del got
     # sigma^2 = 2^(log2 n - 2) = 64 (software/clt-grng/clt-grng-evaluate.py:18-21), mean 0
-    x = got[: 50_000_000].astype(np.float64)
+    x = exp[: 50_000_000].astype(np.float64)
     assert abs(x.mean()) < 0.01 and abs(x.var() - 64.0) < 0.1
+    del x
+    words, _ = oracle.prbs_packed(31, n, fast=True)
+    bits = np.unpackbits(words.view(np.uint8), bitorder="little")[:n].astype(bool)
+    nv = 8
+    trials = [gpu.Trial(nbits=n, amp=gpu.channel.amp_for_ebn0(db, nv), noise_var=nv, prbs_k=31, warmup=16) for db in (0, 5, 10)]
+    counts = gpu.run_trials(u, trials)
+    noise = exp.astype(np.int16) * np.int16(nv)                    # |g * nv| <= 1024: no 12-bit wrap here
+    for t, (nb, ne) in zip(trials, counts):
+        lvl = np.where(bits, np.int16(t.amp), np.int16(-t.amp))
+        rx = ((lvl + noise + 2048) & 4095) - 2048                  # 12-bit signed register (tx.py:80-81)
+        errors = int(np.count_nonzero((rx >= 0) != bits))          # rx.py:29
+        assert (nb, ne) == (n, errors), (t.amp, ne, errors)
