@@ -249,6 +249,34 @@ awgn256_kernel(const uint32_t *__restrict planes, int8_t *__restrict dst, unsign
     }
 }
 
+// int8 -> int16 (sign extension), 16 samples per lane: the int16 form of the k = 256 stream is the fast
+// int8 fill followed by this pass
+__global__ void __launch_bounds__(256)
+widen_i8_i16_kernel(const u32x4 *__restrict src, u32x4 *__restrict dst, unsigned long long n16) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n16) return;
+    const u32x4 v = src[i];
+    u32x4 lo, hi;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const uint32_t x = v[w];
+        const uint32_t a = (uint32_t)(uint16_t)(int16_t)(int8_t)(x & 0xff) | ((uint32_t)(uint16_t)(int16_t)(int8_t)((x >> 8) & 0xff) << 16);
+        const uint32_t b = (uint32_t)(uint16_t)(int16_t)(int8_t)((x >> 16) & 0xff) | ((uint32_t)(uint16_t)(int16_t)(int8_t)(x >> 24) << 16);
+        if (w < 2) { lo[2 * w] = a; lo[2 * w + 1] = b; } else { hi[2 * (w - 2)] = a; hi[2 * (w - 2) + 1] = b; }
+    }
+    dst[2 * i] = lo;
+    dst[2 * i + 1] = hi;
+}
+
+int widen_i8_i16_launch(const int8_t *src, int16_t *dst, uint64_t n, hipStream_t st) {
+    const unsigned long long n16 = (n + 15) / 16;
+    if (!n16) return BBB_OK;
+    hipLaunchKernelGGL(widen_i8_i16_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st,
+                       reinterpret_cast<const u32x4 *>(src), reinterpret_cast<u32x4 *>(dst), n16);
+    BBB_HIP(hipGetLastError());
+    return BBB_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Table-driven kernel for any power-of-two k <= 512 and any tap lists (slow path: used for the
 // reference's small test matrices and for k != 256).  State planes live in global scratch

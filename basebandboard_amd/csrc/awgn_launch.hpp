@@ -12,6 +12,7 @@ int awgn_seed_launch(int k, const uint32_t *d_tabs, const uint32_t *s16, uint64_
                      uint64_t stride, unsigned nlanes, uint32_t *d_planes, hipStream_t st);
 int awgn256_fill_launch(const uint32_t *d_planes, int8_t *dst, uint64_t nsamples, unsigned L, uint64_t G,
                         unsigned nlanes, hipStream_t st);
+int widen_i8_i16_launch(const int8_t *src, int16_t *dst, uint64_t n, hipStream_t st);   // n rounded up to 16 by the caller's buffers
 int awgn_generic_fill_launch(int k, const uint16_t *d_taps, const uint32_t *d_row_off, uint32_t *d_planes2,
                              void *dst, int elem_size, uint64_t nsamples, unsigned L, uint64_t G, unsigned nlanes,
                              hipStream_t st);

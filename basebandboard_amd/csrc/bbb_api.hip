@@ -589,6 +589,14 @@ int bbb_awgn_fill_i8(bbb_lutopt *h, int8_t *dst_dev, uint64_t nsamples, uint64_t
 }
 
 int bbb_awgn_fill_i16(bbb_lutopt *h, int16_t *dst_dev, uint64_t nsamples, uint64_t first_step) {
+    if (h && h->specialised && h->device >= 0 && nsamples && dst_dev && !((uintptr_t)dst_dev & 15) && (nsamples % 16) == 0) {
+        // the generated k = 256 kernel writes int8: fill a scratch buffer with it, then sign-extend
+        BBB_HIP(hipSetDevice(h->device));
+        int rc = grow(&h->d_txnoise, &h->txnoise_cap, (size_t)(nsamples + 15) / 4 + 4);
+        if (rc) return rc;
+        if ((rc = awgn_fill(h, h->d_txnoise, 1, nsamples, first_step))) return rc;
+        return widen_i8_i16_launch((const int8_t *)h->d_txnoise, dst_dev, nsamples, h->stream);
+    }
     return awgn_fill(h, dst_dev, 2, nsamples, first_step);
 }
 

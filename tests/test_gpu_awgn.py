@@ -225,3 +225,19 @@ def test_baseline_configs_2_and_4_at_full_size(gpu, oracle):
         rx = ((lvl + noise + 2048) & 4095) - 2048                  # 12-bit signed register (tx.py:80-81)
         errors = int(np.count_nonzero((rx >= 0) != bits))          # rx.py:29
         assert (nb, ne) == (n, errors), (t.amp, ne, errors)
+
+
+@pytest.mark.parametrize("n", (16, 4096, 1_000_000 - 64, 1_000_003))
+def test_int16_form_of_the_n256_stream(gpu, oracle, n):
+    """bbb_awgn_fill_i16 on the k = 256 generator: the same samples, sign-extended (multiples of 16 take the
+    generated int8 kernel plus a widening pass, other lengths the table-driven kernel)."""
+    import ctypes as C
+    from basebandboard_amd import _lib
+    u = gpu.LUTOPT.shipped(256, init=0x1234567)
+    out = torch.full((n + 32,), 777, dtype=torch.int16, device="cuda")
+    _lib.check(_lib.lib().bbb_awgn_fill_i16(u._h, C.c_void_p(out.data_ptr()), n, 40), "bbb_awgn_fill_i16")
+    m = oracle.Lutopt(path=oracle.data_path(256))
+    exp = m.awgn(0x1234567, 40, n, fast=True).astype(np.int16)
+    got = out.cpu().numpy()
+    assert np.array_equal(got[:n], exp)
+    assert (got[n + 16:] == 777).all()                     # nothing written beyond the rounded-up length
