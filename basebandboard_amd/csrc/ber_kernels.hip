@@ -143,7 +143,9 @@ ber256_kernel(const uint32_t *__restrict planes, const uint32_t *__restrict prbs
                                                        // round loop, the 96 of them would be spilled to VGPR lanes
 #pragma unroll
                     for (int q = 0; q < 8; q++) tmx[c][q] = (uint32_t)(((int32_t)((uint32_t)th << (31 - q))) >> 31);
-                    eqm[c] = tk.strict0[cc] ? 0u : ~0u;
+                    // ~0 where bit 0 uses ">=" too; through readfirstlane so that it stays a scalar MASK operand of
+                    // one V_OR (as a condition it costs a select and two lane reads per setting)
+                    eqm[c] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(0u - (uint32_t)(tk.strict0[cc] == 0)));
                 }
             }
 #pragma unroll 1
@@ -190,8 +192,10 @@ ber256_kernel(const uint32_t *__restrict planes, const uint32_t *__restrict prbs
                     for (int q = 0; q < 8; q++) X[q] = T[q] ^ pb_;
 #pragma unroll
                     for (int c = 0; c < kPerPass; c++) {
+                        // (settings beyond ncfg are evaluated too, on a copy of the last one: no branch per setting;
+                        // their counters are never read)
                         const int cc = pass * kPerPass + c;
-                        if (cc < NC && cc < tk.ncfg) {
+                        if (cc < NC) {
                             uint32_t ge = pb_ | eqm[c];
 #pragma unroll
                             for (int q = 0; q < 8; q++) ge = __builtin_amdgcn_bitop3_b32(X[q], ge, tmx[c][q], 0xD4);
