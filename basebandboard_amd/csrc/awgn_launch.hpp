@@ -18,6 +18,10 @@ int awgn_generic_fill_launch(int k, const uint16_t *d_taps, const uint32_t *d_ro
                              hipStream_t st);
 int clt_tree_launch(int k, const uint64_t *states, uint64_t nstates, int16_t *out, hipStream_t st);
 bool awgn256_matches(int k, const uint16_t *taps, const uint32_t *row_off);
+// awgn_small.hip: generated kernels for the shipped n16 / n32 / n64 / n128 matrices
+int awgn_small_matches(int k, const uint16_t *taps, const uint32_t *row_off);
+int awgn_small_fill_launch(int k, const uint32_t *d_planes, int8_t *dst, uint64_t nsamples, unsigned L, uint64_t G,
+                           unsigned nlanes, hipStream_t st);
 
 // fused BER trial kernels (ber_kernels.hip)
 struct TrialDev {            // one trial as the kernel sees it

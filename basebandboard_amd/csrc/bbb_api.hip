@@ -59,6 +59,7 @@ using namespace bbb;
 struct bbb_lutopt {
     int k = 0, W64 = 0, W32 = 0, device = 0;
     bool specialised = false;
+    int small_fast = 0;          // 16 / 32 / 64 / 128 when (k, taps) is the shipped matrix a generated small kernel exists for
     hipStream_t stream = nullptr;
     std::vector<uint16_t> taps;
     std::vector<uint32_t> row_off;
@@ -283,6 +284,8 @@ int awgn_fill(bbb_lutopt *h, void *dst, int elem_size, uint64_t nsamples, uint64
         }
         return rc;
     }
+    if (h->small_fast && elem_size == 1)
+        return awgn_small_fill_launch(h->small_fast, h->d_planes, (int8_t *)dst, nsamples, (unsigned)L, G, nlanes, h->stream);
     h->planes_valid = false;    // the table-driven kernel advances the planes in place
     return awgn_generic_fill_launch(h->k, h->d_taps, h->d_row_off, h->d_planes, dst, elem_size, nsamples, (unsigned)L, G,
                                     nlanes, h->stream);
@@ -479,6 +482,7 @@ int bbb_lutopt_create(bbb_lutopt **out, int k, const uint16_t *taps, const uint3
     (void)any;   // an all-zero state is legal in the HDL too (it just stays zero)
     h->pw.reset(new GF2Powers(A));
     h->specialised = awgn256_matches(k, taps, row_off);
+    h->small_fast = awgn_small_matches(k, taps, row_off);
     if (device == -1) {
         *out = h.release();
         return BBB_OK;

@@ -77,8 +77,8 @@ def test_n256_large_seams_and_checksum(gpu, oracle):
 
 @pytest.mark.parametrize("n", (16, 32, 64, 128))
 def test_small_matrices_match_golden_and_oracle(gpu, oracle, golden_lutopt, n):
-    """The reference's own test matrices (n16 in test_lutopt, n32 in test_cltgrng) on the GPU's
-    table-driven kernel."""
+    """The reference's own test matrices (n16 in test_lutopt, n32 in test_cltgrng) on the GPU: the shipped
+    n16 ... n128 have generated kernels of their own (csrc/awgn_small.hip)."""
     u = gpu.LUTOPT.shipped(n)
     assert not u.specialised
     g = gpu.CLTGRNG(u)
@@ -90,6 +90,29 @@ def test_small_matrices_match_golden_and_oracle(gpu, oracle, golden_lutopt, n):
     got = g.generate(70_001, first_step=2 * int(np.log2(n))).cpu().numpy()
     exp = ref_stream(oracle, n, 1, 2 * int(np.log2(n)), 70_001)
     assert np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("n", (16, 32, 64, 128))
+@pytest.mark.parametrize("nsamples,first,init", [(1, 0, 1), (15, 3, 1), (17, 0, 5), (4097, 1000, 1), (1_000_003, 12, 0xBEEF), (3_000_000, 10**9 + 7, 1)])
+def test_small_generated_kernels_ragged(gpu, oracle, n, nsamples, first, init):
+    u = gpu.LUTOPT.shipped(n, init=init)
+    got = gpu.CLTGRNG(u).generate(nsamples, first_step=first).cpu().numpy()
+    m = oracle.Lutopt(path=oracle.data_path(n))
+    exp = m.awgn(u.state_at(first), 0, nsamples)
+    assert np.array_equal(got, exp)
+    assert got.min() >= -(n // 2) and got.max() < n // 2            # a log2(n)-bit signed value (rng.py:78)
+
+
+@pytest.mark.parametrize("n", (16, 64, 128))
+def test_other_small_matrices_take_the_table_driven_kernel(gpu, oracle, n):
+    """A matrix that is not the shipped one (here: a candidate of the search) has no generated kernel; the
+    table-driven path must give its stream."""
+    from basebandboard_amd import gf2
+    rows = gf2.search_candidate(n, 3, 11)
+    u = gpu.LUTOPT.from_packed(rows, init=(1 << n) - 1)
+    got = gpu.CLTGRNG(u).generate(20_011, first_step=5).cpu().numpy()
+    m = oracle.Lutopt(packed=rows)
+    assert np.array_equal(got, m.awgn((1 << n) - 1, 5, 20_011))
 
 
 def test_n512_int16(gpu, oracle):
