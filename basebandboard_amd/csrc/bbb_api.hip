@@ -59,6 +59,7 @@ using namespace bbb;
 struct bbb_lutopt {
     int k = 0, W64 = 0, W32 = 0, device = 0;
     bool specialised = false;
+    bbb_custom_fill_fn custom_fill = nullptr;   // a kernel built for this very matrix (bbb_lutopt_set_custom_fill)
     int small_fast = 0;          // 16 / 32 / 64 / 128 when (k, taps) is the shipped matrix a generated small kernel exists for
     hipStream_t stream = nullptr;
     std::vector<uint16_t> taps;
@@ -283,6 +284,11 @@ int awgn_fill(bbb_lutopt *h, void *dst, int elem_size, uint64_t nsamples, uint64
             h->prof_pending.push_back(ev);
         }
         return rc;
+    }
+    if (h->custom_fill && elem_size == 1) {
+        const int e = h->custom_fill(h->d_planes, (int8_t *)dst, nsamples, (uint32_t)L, G, nlanes, (void *)h->stream);
+        if (e) return fail(BBB_EHIP, std::string("custom sample kernel: ") + hipGetErrorString((hipError_t)e));
+        return BBB_OK;
     }
     if (h->small_fast && elem_size == 1)
         return awgn_small_fill_launch(h->small_fast, h->d_planes, (int8_t *)dst, nsamples, (unsigned)L, G, nlanes, h->stream);
@@ -519,6 +525,14 @@ int bbb_lutopt_destroy(bbb_lutopt *h) {
 int bbb_lutopt_set_stream(bbb_lutopt *h, void *hip_stream) {
     if (!h) return fail(BBB_EINVAL, "null handle");
     h->stream = (hipStream_t)hip_stream;
+    return BBB_OK;
+}
+
+int bbb_lutopt_set_custom_fill(bbb_lutopt *h, bbb_custom_fill_fn fn) {
+    if (!h) return fail(BBB_EINVAL, "null handle");
+    if (fn && (h->k > 256 || (h->k & (h->k - 1)))) return fail(BBB_EUNSUP, "custom kernels exist for power-of-two k <= 256");
+    h->custom_fill = fn;
+    h->planes_valid = false;
     return BBB_OK;
 }
 

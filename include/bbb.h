@@ -157,6 +157,16 @@ int bbb_prbs_detector_stream(int k, const uint64_t *bits_packed_dev, uint64_t nb
                              uint64_t *reload_packed_dev, bbb_detector_stats *stats, uint64_t chunk_bits,
                              uint64_t warm_bits, int device, void *hip_stream);
 
+/* A sample kernel built for the handle's own matrix (one that is not among the shipped ones, e.g. a result of
+ * bbb_lutopt_search): `fn` launches it on hip_stream for the bit-plane start states the library prepares
+ * (planes_dev[p * nlanes + lane_global] = state bit p of 32 generators, the state BEFORE the first sample; generator
+ * numbering and segment geometry as csrc/custom_fill_template.hip uses them) and returns 0 or a hipError_t.
+ * bbb_awgn_fill_i8 then calls it instead of the table-driven kernel.  basebandboard_amd.LUTOPT.specialise() generates,
+ * compiles (hipcc) and attaches such a kernel; fn == NULL detaches.  k must be a power of two <= 256. */
+typedef int (*bbb_custom_fill_fn)(const uint32_t *planes_dev, int8_t *dst_dev, uint64_t nsamples, uint32_t L, uint64_t G,
+                                  uint32_t nlanes, void *hip_stream);
+int bbb_lutopt_set_custom_fill(bbb_lutopt *h, bbb_custom_fill_fn fn);
+
 /* ---- fused Monte-Carlo trial: PRBS -> BPSK + scaled CLT noise -> slicer -> error count --- */
 
 /* One trial.  Bit t (0 <= t < nbits) uses PRBS bit first_bit+t and the CLT sample of LUTOPT

@@ -2,6 +2,7 @@
 and the Python restatement: same accepted candidates, same counts."""
 import numpy as np
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 
@@ -70,3 +71,34 @@ def test_search_errors(gpu):
     with pytest.raises(Exception, match="search supports|no factorisation"):
         gf2.search(20, count=10)
     assert gf2.search(16, count=0)[0] is None
+
+
+@pytest.mark.parametrize("k", (32, 128))
+def test_found_matrix_gets_its_own_kernel(gpu, oracle, tmp_path, k):
+    """search -> specialise -> generate: a matrix that the search returns has no shipped kernel; LUTOPT.specialise
+    generates the straight-line network for it, compiles it with hipcc and attaches it.  The stream must be the
+    table-driven kernel's and the oracle's; and it is an order of magnitude faster."""
+    import shutil
+    import time
+    if not shutil.which("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc on this machine")
+    from basebandboard_amd import gf2
+    idx, rows, _ = gf2.search(k, seed=11, first=0, count=20000)
+    assert idx is not None
+    import basebandboard_amd as bbb
+    u = bbb.LUTOPT.from_packed(rows, init=(1 << k) - 1)
+    g = bbb.CLTGRNG(u)
+    n = 3_000_017
+    slow = g.generate(n, first_step=9)
+    torch.cuda.synchronize(); t0 = time.perf_counter(); g.generate(n, first_step=9 + n); torch.cuda.synchronize(); t_slow = time.perf_counter() - t0
+    u.specialise(build_dir=tmp_path)
+    fast = g.generate(n, first_step=9)
+    torch.cuda.synchronize(); t0 = time.perf_counter(); g.generate(n, first_step=9 + n); torch.cuda.synchronize(); t_fast = time.perf_counter() - t0
+    assert torch.equal(slow, fast)
+    m = oracle.Lutopt(packed=rows)
+    assert np.array_equal(fast[:200_000].cpu().numpy(), m.awgn((1 << k) - 1, 9, 200_000))
+    assert t_fast < t_slow / 3
+    # a second handle finds the cached library
+    u2 = bbb.LUTOPT.from_packed(rows, init=5)
+    u2.specialise(build_dir=tmp_path)
+    assert np.array_equal(bbb.CLTGRNG(u2).generate(10_000).cpu().numpy(), m.awgn(5, 0, 10_000))
