@@ -51,7 +51,7 @@ class DetectorStats(C.Structure):
 
 class SearchStats(C.Structure):
     """bbb_search_stats"""
-    _fields_ = [(n, C.c_uint64) for n in ("tested", "full_degree", "order_divides", "primitive")]
+    _fields_ = [(n, C.c_uint64) for n in ("tested", "full_degree", "order_divides", "primitive", "kernel_ns")]
 
 
 class Ber(C.Structure):

@@ -27,6 +27,7 @@ typedef unsigned long long u64;
 struct SearchOut {
     u64 found;           // smallest accepted candidate (atomicMin), ~0 if none
     u64 tested, full_degree, order_divides, primitive;
+    u64 kernel_ns;       // filled by the host from HIP events
 };
 
 // index i <- index i-1, index 0 <- ins (uniform 0/1)
@@ -272,7 +273,10 @@ static int search_run(u64 seed, u64 first, u64 count, const MersenneEntry *me, S
     BBB_HIP(hipMalloc(&d_exps, (size_t)me->nexp * EW * sizeof(u64)));
     hipError_t e = hipMalloc(&d_out, sizeof(SearchOut));
     if (e != hipSuccess) { (void)hipFree(d_exps); BBB_HIP(e); }
-    SearchOut init = {~0ull, 0, 0, 0, 0};
+    SearchOut init = {~0ull, 0, 0, 0, 0, 0};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    (void)hipEventCreate(&ev0);
+    (void)hipEventCreate(&ev1);
     e = hipMemcpyAsync(d_exps, (const void *)(kMersenneWords + me->offset), (size_t)me->nexp * EW * sizeof(u64), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d_out, &init, sizeof init, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
@@ -281,11 +285,17 @@ static int search_run(u64 seed, u64 first, u64 count, const MersenneEntry *me, S
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
         const u64 maxwaves = (u64)ncu * 16;
         const unsigned grid = (unsigned)(count < maxwaves ? count : maxwaves);
+        (void)hipEventRecord(ev0, st);
         hipLaunchKernelGGL(search_kernel<K>, dim3(grid), dim3(64), 0, st, seed, first, count, (const u64 *)d_exps, me->nexp, d_out);
+        (void)hipEventRecord(ev1, st);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(h_out, d_out, sizeof(SearchOut), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
+    float ms = 0.f;
+    if (e == hipSuccess && hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) h_out->kernel_ns = (u64)(ms * 1e6);
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
     (void)hipFree(d_exps);
     (void)hipFree(d_out);
     BBB_HIP(e);
@@ -296,7 +306,7 @@ int lutopt_search_launch(int k, uint64_t seed, uint64_t first, uint64_t count, u
                          uint32_t *row_off_out, bbb_search_stats *stats, hipStream_t st) {
     const MersenneEntry *me = mersenne_entry(k);
     if (!me) return fail(BBB_EUNSUP, "no factorisation of 2^" + std::to_string(k) + " - 1 in the table");
-    SearchOut o = {~0ull, 0, 0, 0, 0};
+    SearchOut o = {~0ull, 0, 0, 0, 0, 0};
     int rc = BBB_OK;
     if (count) {
         switch (k) {
@@ -316,6 +326,7 @@ int lutopt_search_launch(int k, uint64_t seed, uint64_t first, uint64_t count, u
         stats->full_degree = o.full_degree;
         stats->order_divides = o.order_divides;
         stats->primitive = o.primitive;
+        stats->kernel_ns = o.kernel_ns;
     }
     if (found) *found = o.found;
     if (o.found != ~0ull) {

@@ -264,8 +264,10 @@ def main():
         tsr = time.perf_counter() - tsr
         extra["matrix_search_k256"] = {"candidates_tested": sst["tested"], "full_degree": sst["full_degree"],
                                        "order_divides": sst["order_divides"], "accepted": sst["primitive"], "first_hit": sidx,
-                                       "kcand_s": round(sst["tested"] / tsr / 1e3, 1),
-                                       "note": "bbb_lutopt_search: build + 512 steps + Berlekamp-Massey + primitivity per wavefront"}
+                                       "kcand_s": round(sst["tested"] / (sst["kernel_ns"] * 1e-9) / 1e3, 1) if sst["kernel_ns"] else None,
+                                       "call_ms": round(tsr * 1e3, 2),
+                                       "note": "bbb_lutopt_search: build + 512 steps + Berlekamp-Massey + primitivity per wavefront; "
+                                               "kcand_s from the kernel's duration, call_ms includes the host re-check of the hit"}
         # BER sweep (BASELINE configs[3]/[4]): Eb/N0 0..10 dB, 1e9 bits/point, sharded over ranks
         # (point i -> rank i % world), ONE all-reduce (RCCL) of the uint64 counters.
         # N > 1 (BASELINE configs[4]): points x seeds -- every rank runs all 11 points on its own seed (one noise

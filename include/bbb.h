@@ -287,6 +287,7 @@ typedef struct {
     uint64_t full_degree;     /* of those: characteristic polynomial of degree k (rnghunt.rs:40) */
     uint64_t order_divides;   /* of those: x^(2^k - 1) = 1 (first check of is_primitive) */
     uint64_t primitive;       /* of those: primitive = accepted */
+    uint64_t kernel_ns;       /* duration of the search kernel (HIP events); the call adds the host re-check of a hit */
 } bbb_search_stats;
 /* Examine candidates first_candidate .. first_candidate + ncandidates - 1 on the GPU, one per
  * wavefront at a time: build the matrix, run 2k steps from the all-ones state, Berlekamp-Massey,
