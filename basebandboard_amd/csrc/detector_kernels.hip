@@ -82,6 +82,38 @@ __device__ __forceinline__ void det_word(DetState &s, u64 w, int nvalid, u64 &er
     s.prbs = prbs & MASK; s.err_sr = err_sr; s.reload_ctr = (int32_t)ctr; s.bit_in = bit_in;
 }
 
+// The common case, 64 clocks at once: the detector is locked (reload_ctr == 0) and stays locked through the word.
+// Then the LFSR free-runs (prbs.py:75-76 with reload == 0), so its next 64 feedback bits F follow from the state
+// alone -- x[t] = x[t-K] ^ x[t-TAP], TAP new bits per pair of 64-bit shifts -- the error bits are
+// E = (input delayed by the bit_in register) ^ F, and no reload can trigger inside the word if the old history plus
+// E hold at most K/2 ones (every K-bit window is a subset).  Otherwise: false, and det_word runs the clocks one by one.
+template <int K, bool EMIT>
+__device__ __forceinline__ bool det_word_fast(DetState &s, u64 w, u64 &errw) {
+    constexpr int TAP = det_tap_of(K);
+    constexpr uint32_t MASK = (uint32_t)((1ull << K) - 1ull);
+    if (s.reload_ctr != 0) return false;
+    // H bit p = x[t-64+p]: the last K sequence bits sit at the top (prbs bit m = x[t-1-m])
+    const u64 H = (u64)__builtin_bitreverse32(s.prbs) << 32;
+    u64 F = 0;                                              // F bit j = x[t+j]
+#pragma unroll
+    for (int j0 = 0; j0 < 64; j0 += TAP) {
+        const int pk = 64 + j0 - K, pt = 64 + j0 - TAP;     // where the two lagged copies start in (H : F)
+        const u64 gk = pk < 64 ? ((H >> (pk & 63)) | (pk ? F << ((64 - pk) & 63) : 0ull)) : (pk == 64 ? F : F >> ((pk - 64) & 63));
+        const u64 gt = pt < 64 ? ((H >> (pt & 63)) | (pt ? F << ((64 - pt) & 63) : 0ull)) : (pt == 64 ? F : F >> ((pt - 64) & 63));
+        F |= ((gk ^ gt) & ((1ull << TAP) - 1ull)) << j0;
+    }
+    const u64 E = ((w << 1) | (u64)s.bit_in) ^ F;           // e_i = bit_in ^ feedback (:79), bit_in = the previous input bit
+    if (__builtin_popcountll(E) + __builtin_popcount(s.err_sr) > K / 2) return false;
+    s.prbs = __builtin_bitreverse32((uint32_t)(F >> 32)) & MASK;      // the newest bit at bit 0 (:68)
+    s.err_sr = __builtin_bitreverse32((uint32_t)(E >> 32)) & MASK;    // (:81)
+    s.bit_in = (uint32_t)(w >> 63);
+    if (EMIT) {
+        const u64 f64 = ((s.prbs >> (K - 1)) ^ (s.prbs >> (TAP - 1))) & 1u;
+        errw = w ^ ((F >> 1) | (f64 << 63));                // err after clock i = input i ^ next feedback
+    }
+    return true;
+}
+
 __device__ __forceinline__ DetState det_reset(int k) {
     DetState s;
     s.prbs = 1u;                                   // prbs.py:62
@@ -99,12 +131,13 @@ __device__ __forceinline__ bool det_equal(const DetState &a, const DetState &b) 
 template <int K, bool EMIT>
 __device__ __forceinline__ void det_span(DetState &s, const u64 *__restrict src, u64 w0, u64 w1, u64 nbits,
                                          u64 *__restrict err, u64 *__restrict reload, DetCount &cnt) {
-    for (u64 w = w0; w < w1; w++) {
+    typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+    auto one = [&](u64 w, u64 word) {
         const u64 left = nbits - w * 64;
         const int nvalid = left >= 64 ? 64 : (int)left;
-        u64 ew, rw;
+        u64 ew = 0, rw = 0;
         unsigned trig = 0;
-        det_word<K, EMIT>(s, src[w], nvalid, ew, rw, trig);
+        if (nvalid != 64 || !det_word_fast<K, EMIT>(s, word, ew)) det_word<K, EMIT>(s, word, nvalid, ew, rw, trig);
         if (EMIT) {
             if (err) err[w] = ew;
             if (reload) reload[w] = rw;
@@ -113,7 +146,15 @@ __device__ __forceinline__ void det_span(DetState &s, const u64 *__restrict src,
             cnt.err_synced += __builtin_popcountll(ew & ~rw);
             cnt.resyncs += trig;
         }
+    };
+    u64 w = w0;
+    if ((w & 1) && w < w1) { one(w, src[w]); w++; }
+    for (; w + 2 <= w1; w += 2) {                     // 16-byte loads: half as many requests per lane
+        const u64x2 v = *reinterpret_cast<const u64x2 *>(src + w);
+        one(w, v.x);
+        one(w + 1, v.y);
     }
+    if (w < w1) one(w, src[w]);
 }
 
 // mode 0: speculative run of every chunk.  mode 1: re-run of the chunks in `list` from end[c-1].
@@ -268,7 +309,12 @@ static int detector_stream_k(const u64 *src, u64 nbits, u64 *err, u64 *reload, b
 int prbs_detector_stream_launch(int k, const uint64_t *src, uint64_t nbits, uint64_t *err, uint64_t *reload,
                                 bbb_detector_stats *stats, uint64_t chunk_bits, uint64_t warm_bits, hipStream_t st) {
     if (!det_tap_of(k)) return fail(BBB_EINVAL, "k=" + std::to_string(k) + " invalid for PRBS");
-    if (chunk_bits == 0) chunk_bits = 4096;
+    if (chunk_bits == 0) {
+        // about four waves of lanes per SIMD, but chunks of 4096 ... 32768 bits: the warm-up before every chunk is
+        // 1024 bits of extra work, and short inputs should still fill the device
+        const uint64_t want = (nbits / 262144 + 127) / 128 * 128;
+        chunk_bits = want < 4096 ? 4096 : (want > 32768 ? 32768 : want);
+    }
     if (warm_bits == 0) warm_bits = 1024;
     if (chunk_bits % 64) return fail(BBB_EINVAL, "chunk_bits must be a multiple of 64");
     if (nbits == 0) {

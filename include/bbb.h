@@ -138,7 +138,7 @@ int bbb_prbs_detector_run(int k, const uint8_t *bits_dev, uint64_t nstreams, uin
  * hand-off).  bits_packed_dev: input wire during clock t at word t/64, bit t%64 (the layout
  * bbb_prbs_fill / bbb_rx_slice write).  err_packed_dev / reload_packed_dev (either may be NULL,
  * ceil(nbits/64) words): `err` / `reload` sampled after clock t, same packing.  The stream is cut
- * into chunks of chunk_bits (0: 4096; a multiple of 64), each run by one GPU lane from a
+ * into chunks of chunk_bits (0: 4096 ... 32768 by the length; a multiple of 64), each run by one GPU lane from a
  * speculative state obtained by running the reset detector over the warm_bits (0: 1024) before the
  * chunk; every chunk whose speculative start differs from its predecessor's true end state is run
  * again from that state until the chain is consistent, so the outputs equal the serial machine's
