@@ -128,33 +128,65 @@ __device__ __forceinline__ bool det_equal(const DetState &a, const DetState &b) 
 }
 
 // runs words [w0, w1) of the stream from state s; emits outputs and counts when EMIT
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+
+// one input word: the word-at-once path when it applies, else clock by clock; outputs and counters when EMIT
+template <int K, bool EMIT>
+__device__ __forceinline__ void det_one(DetState &s, u64 w, u64 word, u64 nbits, u64 *__restrict err, u64 *__restrict reload,
+                                        DetCount &cnt) {
+    const u64 left = nbits - w * 64;
+    const int nvalid = left >= 64 ? 64 : (int)left;
+    u64 ew = 0, rw = 0;
+    unsigned trig = 0;
+    if (nvalid != 64 || !det_word_fast<K, EMIT>(s, word, ew)) det_word<K, EMIT>(s, word, nvalid, ew, rw, trig);
+    if (EMIT) {
+        if (err) err[w] = ew;
+        if (reload) reload[w] = rw;
+        cnt.err_raw += __builtin_popcountll(ew);
+        cnt.reload_clocks += __builtin_popcountll(rw);
+        cnt.err_synced += __builtin_popcountll(ew & ~rw);
+        cnt.resyncs += trig;
+    }
+}
+
+// runs words [w0, w1) of the stream from state s, every lane on its own (16-byte loads where aligned)
 template <int K, bool EMIT>
 __device__ __forceinline__ void det_span(DetState &s, const u64 *__restrict src, u64 w0, u64 w1, u64 nbits,
                                          u64 *__restrict err, u64 *__restrict reload, DetCount &cnt) {
-    typedef u64 u64x2 __attribute__((ext_vector_type(2)));
-    auto one = [&](u64 w, u64 word) {
-        const u64 left = nbits - w * 64;
-        const int nvalid = left >= 64 ? 64 : (int)left;
-        u64 ew = 0, rw = 0;
-        unsigned trig = 0;
-        if (nvalid != 64 || !det_word_fast<K, EMIT>(s, word, ew)) det_word<K, EMIT>(s, word, nvalid, ew, rw, trig);
-        if (EMIT) {
-            if (err) err[w] = ew;
-            if (reload) reload[w] = rw;
-            cnt.err_raw += __builtin_popcountll(ew);
-            cnt.reload_clocks += __builtin_popcountll(rw);
-            cnt.err_synced += __builtin_popcountll(ew & ~rw);
-            cnt.resyncs += trig;
-        }
-    };
     u64 w = w0;
-    if ((w & 1) && w < w1) { one(w, src[w]); w++; }
-    for (; w + 2 <= w1; w += 2) {                     // 16-byte loads: half as many requests per lane
+    if ((w & 1) && w < w1) { det_one<K, EMIT>(s, w, src[w], nbits, err, reload, cnt); w++; }
+    for (; w + 2 <= w1; w += 2) {
         const u64x2 v = *reinterpret_cast<const u64x2 *>(src + w);
-        one(w, v.x);
-        one(w + 1, v.y);
+        det_one<K, EMIT>(s, w, v.x, nbits, err, reload, cnt);
+        det_one<K, EMIT>(s, w + 1, v.y, nbits, err, reload, cnt);
     }
-    if (w < w1) one(w, src[w]);
+    if (w < w1) det_one<K, EMIT>(s, w, src[w], nbits, err, reload, cnt);
+}
+
+// The same for a whole wave of 64 consecutive full chunks: the 64 lanes' next 16 words (128 bytes each) are fetched
+// together as 64 full lines (8 load instructions, each covering 8 rows) into LDS and every lane then reads its own
+// row -- one line request per 128 bytes instead of one per 16 bytes.  [first, first + nw) per lane, nw a multiple of 16.
+template <int K, bool EMIT>
+__device__ __forceinline__ void det_span_tiled(DetState &s, const u64 *__restrict src, u64 first_row0, u64 row_stride, u64 nw,
+                                               u64 my_first, u64 nbits, u64 *__restrict err, u64 *__restrict reload,
+                                               DetCount &cnt, u64x2 (*tile)[9], unsigned lane) {
+    for (u64 off = 0; off < nw; off += 16) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const unsigned row = (unsigned)q * 8 + (lane >> 3), piece = lane & 7;
+            tile[row][piece] = *reinterpret_cast<const u64x2 *>(src + first_row0 + off + (u64)row * row_stride + piece * 2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int p = 0; p < 8; p++) {
+            const u64x2 v = tile[lane][p];
+            det_one<K, EMIT>(s, my_first + off + 2 * p, v.x, nbits, err, reload, cnt);
+            det_one<K, EMIT>(s, my_first + off + 2 * p + 1, v.y, nbits, err, reload, cnt);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 // mode 0: speculative run of every chunk.  mode 1: re-run of the chunks in `list` from end[c-1].
@@ -162,8 +194,28 @@ template <int K>
 __global__ void __launch_bounds__(256)
 det_chunk_kernel(int mode, const u64 *__restrict src, u64 nbits, u64 nwords, u64 chunk_words, u64 warm_words,
                  u64 nchunks, const unsigned *__restrict list, unsigned nlist, DetState *__restrict spec,
-                 DetState *__restrict endst, DetCount *__restrict counts, u64 *__restrict err, u64 *__restrict reload) {
+                 DetState *__restrict endst, DetCount *__restrict counts, u64 *__restrict err, u64 *__restrict reload,
+                 int tiles_ok) {
+    __shared__ u64x2 tiles[4][64][9];             // [wave][row][16-byte piece], rows padded to 144 bytes
     const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned lane = threadIdx.x & 63;
+    if (mode == 0) {
+        // a wave whose 64 chunks are all full, lie behind a full warm-up and start on 128-byte boundaries
+        const u64 c0 = idx - lane;
+        if (tiles_ok && c0 + 64 <= nchunks && c0 * chunk_words >= warm_words && (c0 + 64) * chunk_words * 64 <= nbits) {
+            const u64 c = idx, w0 = c * chunk_words;
+            DetState s = det_reset(K);
+            DetCount cnt = {0, 0, 0, 0}, dummy = {0, 0, 0, 0};
+            u64x2 (*tile)[9] = tiles[threadIdx.x >> 6];
+            det_span_tiled<K, false>(s, src, c0 * chunk_words - warm_words, chunk_words, warm_words, w0 - warm_words, nbits, nullptr,
+                                     nullptr, dummy, tile, lane);
+            spec[c] = s;
+            det_span_tiled<K, true>(s, src, c0 * chunk_words, chunk_words, chunk_words, w0, nbits, err, reload, cnt, tile, lane);
+            endst[c] = s;
+            counts[c] = cnt;
+            return;
+        }
+    }
     u64 c;
     if (mode == 0) {
         if (idx >= nchunks) return;
@@ -255,8 +307,10 @@ static int detector_stream_k(const u64 *src, u64 nbits, u64 *err, u64 *reload, b
     unsigned *nlist = (unsigned *)(tail + 4);
     auto cleanup = [&]() { (void)hipFreeAsync(ws, st); };
     const unsigned grid = (unsigned)((nchunks + 255) / 256);
+    // cooperative 128-byte loads need chunks and warm-up in whole 16-word rows on 16-byte aligned data
+    const int tiles_ok = chunk_words % 16 == 0 && warm_words % 16 == 0 && warm_words > 0 && ((uintptr_t)src & 15) == 0;
     hipLaunchKernelGGL(det_chunk_kernel<K>, dim3(grid), dim3(256), 0, st, 0, src, nbits, nwords, chunk_words, warm_words,
-                       nchunks, (const unsigned *)nullptr, 0u, spec, endst, counts, err, reload);
+                       nchunks, (const unsigned *)nullptr, 0u, spec, endst, counts, err, reload, tiles_ok);
     u64 rerun = 0, passes = 0;
     bool serial = false;
     u64 h[5] = {0, 0, 0, 0, 0};
@@ -289,7 +343,7 @@ static int detector_stream_k(const u64 *src, u64 nbits, u64 *err, u64 *reload, b
         }
         rerun += nbad;
         hipLaunchKernelGGL(det_chunk_kernel<K>, dim3((nbad + 255) / 256), dim3(256), 0, st, 1, src, nbits, nwords, chunk_words,
-                           warm_words, nchunks, (const unsigned *)list, nbad, spec, endst, counts, err, reload);
+                           warm_words, nchunks, (const unsigned *)list, nbad, spec, endst, counts, err, reload, 0);
     }
     cleanup();
     BBB_HIP(hipGetLastError());
