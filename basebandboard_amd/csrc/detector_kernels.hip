@@ -130,22 +130,30 @@ __device__ __forceinline__ bool det_equal(const DetState &a, const DetState &b) 
 // runs words [w0, w1) of the stream from state s; emits outputs and counts when EMIT
 typedef u64 u64x2 __attribute__((ext_vector_type(2)));
 
-// one input word: the word-at-once path when it applies, else clock by clock; outputs and counters when EMIT
+// one input word: the word-at-once path when it applies, else clock by clock; counters when EMIT
 template <int K, bool EMIT>
-__device__ __forceinline__ void det_one(DetState &s, u64 w, u64 word, u64 nbits, u64 *__restrict err, u64 *__restrict reload,
-                                        DetCount &cnt) {
+__device__ __forceinline__ void det_core(DetState &s, u64 w, u64 word, u64 nbits, u64 &ew, u64 &rw, DetCount &cnt) {
     const u64 left = nbits - w * 64;
     const int nvalid = left >= 64 ? 64 : (int)left;
-    u64 ew = 0, rw = 0;
+    ew = 0; rw = 0;
     unsigned trig = 0;
     if (nvalid != 64 || !det_word_fast<K, EMIT>(s, word, ew)) det_word<K, EMIT>(s, word, nvalid, ew, rw, trig);
     if (EMIT) {
-        if (err) err[w] = ew;
-        if (reload) reload[w] = rw;
         cnt.err_raw += __builtin_popcountll(ew);
         cnt.reload_clocks += __builtin_popcountll(rw);
         cnt.err_synced += __builtin_popcountll(ew & ~rw);
         cnt.resyncs += trig;
+    }
+}
+
+template <int K, bool EMIT>
+__device__ __forceinline__ void det_one(DetState &s, u64 w, u64 word, u64 nbits, u64 *__restrict err, u64 *__restrict reload,
+                                        DetCount &cnt) {
+    u64 ew, rw;
+    det_core<K, EMIT>(s, w, word, nbits, ew, rw, cnt);
+    if (EMIT) {
+        if (err) err[w] = ew;
+        if (reload) reload[w] = rw;
     }
 }
 
@@ -170,22 +178,46 @@ template <int K, bool EMIT>
 __device__ __forceinline__ void det_span_tiled(DetState &s, const u64 *__restrict src, u64 first_row0, u64 row_stride, u64 nw,
                                                u64 my_first, u64 nbits, u64 *__restrict err, u64 *__restrict reload,
                                                DetCount &cnt, u64x2 (*tile)[9], unsigned lane) {
+    auto sync = [] { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    // the tile written back the same way: 64 whole lines per 8 store instructions
+    auto store_tile = [&](u64 *__restrict out, u64 off) {
+        sync();
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const unsigned row = (unsigned)q * 8 + (lane >> 3), piece = lane & 7;
+            *reinterpret_cast<u64x2 *>(out + first_row0 + off + (u64)row * row_stride + piece * 2) = tile[row][piece];
+        }
+        sync();
+    };
     for (u64 off = 0; off < nw; off += 16) {
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const unsigned row = (unsigned)q * 8 + (lane >> 3), piece = lane & 7;
             tile[row][piece] = *reinterpret_cast<const u64x2 *>(src + first_row0 + off + (u64)row * row_stride + piece * 2);
         }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        sync();
+        u64x2 in[8];
+#pragma unroll
+        for (int p = 0; p < 8; p++) in[p] = tile[lane][p];
+        sync();                                    // every lane has its row: the tile can take the outputs
+        u64x2 eo[8], ro[8];
 #pragma unroll
         for (int p = 0; p < 8; p++) {
-            const u64x2 v = tile[lane][p];
-            det_one<K, EMIT>(s, my_first + off + 2 * p, v.x, nbits, err, reload, cnt);
-            det_one<K, EMIT>(s, my_first + off + 2 * p + 1, v.y, nbits, err, reload, cnt);
+            u64 e0, r0, e1, r1;
+            det_core<K, EMIT>(s, my_first + off + 2 * p, in[p].x, nbits, e0, r0, cnt);
+            det_core<K, EMIT>(s, my_first + off + 2 * p + 1, in[p].y, nbits, e1, r1, cnt);
+            eo[p].x = e0; eo[p].y = e1; ro[p].x = r0; ro[p].y = r1;
         }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        if (EMIT && err) {
+#pragma unroll
+            for (int p = 0; p < 8; p++) tile[lane][p] = eo[p];
+            store_tile(err, off);
+        }
+        if (EMIT && reload) {
+#pragma unroll
+            for (int p = 0; p < 8; p++) tile[lane][p] = ro[p];
+            store_tile(reload, off);
+        }
     }
 }
 
