@@ -30,8 +30,11 @@ class TX:
         self.bit_en, self.src_sel, self.noise_en, self.noise_var = bool(bit_en), int(src_sel), bool(noise_en), int(noise_var)
         self.device = int(device)
 
-    def generate(self, nsamples, first_sample=0, warmup=16, out=None):
-        """Samples first_sample .. first_sample + nsamples - 1 of `x` (int16, 12-bit signed)."""
+    def generate(self, nsamples, first_sample=0, warmup=16, out=None, stream_on=True):
+        """Samples first_sample .. first_sample + nsamples - 1 of `x` (int16, 12-bit signed).
+        stream_on: announce that the next call continues where this one ends (bbb_awgn_prefetch), so that the
+        noise generator's start states for it are derived beside this call's kernels; a call that does not
+        continue there simply ignores the hint."""
         dev = torch.device("cuda", self.device)
         if out is None:
             out = torch.empty(int(nsamples), dtype=torch.int16, device=dev)
@@ -42,4 +45,7 @@ class TX:
         self.urng._bind_stream()
         _lib.check(_lib.lib().bbb_tx_fill_i16(self.urng._h, C.byref(cfg), C.c_void_p(out.data_ptr()), int(nsamples),
                                               int(first_sample)), "bbb_tx_fill_i16")
+        if stream_on and self.noise_en:
+            _lib.check(_lib.lib().bbb_awgn_prefetch(self.urng._h, int(nsamples), int(warmup) + int(first_sample) + int(nsamples)),
+                       "bbb_awgn_prefetch")
         return out[:nsamples]
