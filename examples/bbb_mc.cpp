@@ -2,10 +2,13 @@
 // LUTOPT-256 / CLT noise generator, the Monte-Carlo loop of BASELINE.json configs[3].  No torch, no Python:
 // the library, hipMalloc'd buffers and printf.  Build: make -C examples   (hipcc, links ../basebandboard_amd/libbbb_hip.so)
 //
-//   bbb_mc [--matrix FILE] [--k 31] [--bits 1e9] [--nv 8] [--from 0] [--to 10] [--step 1] [--loopback BITS]
+//   bbb_mc [--matrix FILE] [--init HEX] [--seeds N] [--k 31] [--bits 1e9] [--nv 8] [--from 0] [--to 10] [--step 1]
+//          [--loopback BITS]
 //
 // --matrix takes the reference's 0/1 text format (software/rnghunt/matrices/256) or nothing (the shipped
-// matrix).  --loopback additionally runs generator -> exact detector on BITS bits.
+// matrix).  --init is the generator's reset state (hex, default 1: gateware/bbb/rng.py:21); --seeds N repeats the sweep
+// with reset states init, init+1, ... and sums the counters (the points x seeds shape of BASELINE.json configs[4]).
+// --loopback additionally runs generator -> exact detector on BITS bits.
 #include "../include/bbb.h"
 
 #include <hip/hip_runtime.h>
@@ -51,12 +54,15 @@ static bool load_taps_file(const std::string &path, int *k, std::vector<uint16_t
 
 int main(int argc, char **argv) {
     std::string matrix;
-    int k = 31, nv = 8;
+    int k = 31, nv = 8, seeds = 1;
+    unsigned long long init0 = 1;
     double bits = 1e9, from = 0, to = 10, step = 1, loopback = 0;
     for (int i = 1; i + 1 < argc; i += 2) {
         const std::string a = argv[i];
         if (a == "--matrix") matrix = argv[i + 1];
         else if (a == "--k") k = std::atoi(argv[i + 1]);
+        else if (a == "--init") init0 = std::strtoull(argv[i + 1], nullptr, 16);
+        else if (a == "--seeds") seeds = std::atoi(argv[i + 1]);
         else if (a == "--nv") nv = std::atoi(argv[i + 1]);
         else if (a == "--bits") bits = std::atof(argv[i + 1]);
         else if (a == "--from") from = std::atof(argv[i + 1]);
@@ -83,10 +89,7 @@ int main(int argc, char **argv) {
         bbb_free(t);
         bbb_free(o);
     }
-    const uint64_t init[8] = {1, 0, 0, 0, 0, 0, 0, 0};                 // reset value 1 (gateware/bbb/rng.py:21)
-    bbb_lutopt *h = nullptr;
-    CHECK(bbb_lutopt_create(&h, n, taps.data(), off.data(), init, 0));
-
+    if (seeds < 1 || init0 == 0) { std::fprintf(stderr, "--seeds >= 1 and a non-zero --init expected\n"); return 2; }
     // amplitude for an Eb/N0: sigma of the scaled CLT sample is 8 * nv (CLTGRNG variance 64), one sample per bit
     std::vector<bbb_trial_cfg> cfg;
     for (double db = from; db <= to + 1e-9; db += step) {
@@ -100,18 +103,28 @@ int main(int argc, char **argv) {
         c.nbits = (uint64_t)bits;
         cfg.push_back(c);
     }
-    std::vector<bbb_ber> out(cfg.size());
-    CHECK(bbb_ber_trials(h, cfg.data(), (int)cfg.size(), out.data()));   // first call builds the jump plans
-    hipEvent_t e0, e1;
-    (void)hipEventCreate(&e0);
-    (void)hipEventCreate(&e1);
-    (void)hipEventRecord(e0, nullptr);
-    CHECK(bbb_ber_trials(h, cfg.data(), (int)cfg.size(), out.data()));
-    (void)hipEventRecord(e1, nullptr);
-    (void)hipEventSynchronize(e1);
+    std::vector<bbb_ber> out(cfg.size()), part(cfg.size());
+    bbb_lutopt *h = nullptr;
     float ms = 0;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    std::printf("# PRBS-%d, noise_var %d, %.3g bits per point, %zu points in %.3f ms\n", k, nv, bits, cfg.size(), ms);
+    for (int sd = 0; sd < seeds; sd++) {
+        const uint64_t init[8] = {init0 + (uint64_t)sd, 0, 0, 0, 0, 0, 0, 0};     // reset value (gateware/bbb/rng.py:21)
+        if (h) CHECK(bbb_lutopt_destroy(h));
+        CHECK(bbb_lutopt_create(&h, n, taps.data(), off.data(), init, 0));
+        CHECK(bbb_ber_trials(h, cfg.data(), (int)cfg.size(), part.data()));  // first call builds the jump plans
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0, nullptr);
+        CHECK(bbb_ber_trials(h, cfg.data(), (int)cfg.size(), part.data()));
+        (void)hipEventRecord(e1, nullptr);
+        (void)hipEventSynchronize(e1);
+        float one = 0;
+        (void)hipEventElapsedTime(&one, e0, e1);
+        ms += one;
+        for (size_t i = 0; i < cfg.size(); i++) { out[i].bits += part[i].bits; out[i].errors += part[i].errors; }
+    }
+    std::printf("# PRBS-%d, noise_var %d, %.3g bits per point and seed, %d seed(s), %zu points in %.3f ms\n", k, nv, bits, seeds,
+                cfg.size(), ms);
     std::printf("# EbN0_dB  amp  bits  errors  BER  Q(sqrt(2EbN0))\n");
     for (size_t i = 0; i < cfg.size(); i++) {
         const double ebn0 = (double)cfg[i].amp * cfg[i].amp / (2.0 * 64.0 * nv * nv);

@@ -152,3 +152,11 @@ def test_cpp_caller_of_the_c_abi(gpu, oracle):
         amp, bits, errs = int(row[1]), int(row[2]), int(row[3])
         assert (bits, errs) == m.ber_trial(1, 15, 1, amp, 7, 16, 0, 200_000)
     assert "loopback: 3000000 bits, 0 errors" in r.stdout
+    # points x seeds: two reset states summed
+    r = subprocess.run([str(exe), "--bits", "100000", "--from", "4", "--to", "4", "--k", "15", "--nv", "7", "--init", "a5", "--seeds", "2"],
+                       cwd=str(ROOT), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    row = [l.split() for l in r.stdout.splitlines() if l and not l.startswith("#")][0]
+    amp = int(row[1])
+    e = [m.ber_trial(s, 15, 1, amp, 7, 16, 0, 100_000) for s in (0xa5, 0xa6)]
+    assert (int(row[2]), int(row[3])) == (e[0][0] + e[1][0], e[0][1] + e[1][1])
