@@ -79,3 +79,20 @@ def test_capture_decoder(gpu):
     raw = struct.pack("<8192h", *x.tolist())
     bits = gpu.RX.decode_capture(raw)
     assert np.array_equal(bits, (x.astype(float) > 0).astype(np.uint8)[::4])
+
+
+def test_determinism_and_resume(gpu):
+    """the same seed twice gives identical bytes; (state, offset) is the whole checkpoint --
+    a stream generated in three pieces with different handles equals the stream generated at once."""
+    n = 5_000_011
+    a = gpu.CLTGRNG(gpu.LUTOPT.shipped(256, init=0xC0FFEE)).generate(n, first_step=16)
+    b = gpu.CLTGRNG(gpu.LUTOPT.shipped(256, init=0xC0FFEE)).generate(n, first_step=16)
+    assert torch.equal(a, b)
+    cuts = (0, 1_234_567, 3_000_001, n)
+    parts = [gpu.CLTGRNG(gpu.LUTOPT.shipped(256, init=0xC0FFEE)).generate(cuts[i + 1] - cuts[i], first_step=16 + cuts[i]) for i in range(3)]
+    assert torch.equal(torch.cat(parts), a)
+    p = gpu.PRBS(23, init=0x1ABCD)
+    whole = p.generate(64 * 100_000)
+    pieces = [gpu.PRBS(23, init=0x1ABCD).generate(64 * 25_000, first_bit=64 * 25_000 * i) for i in range(4)]
+    assert torch.equal(torch.cat(pieces), whole)
+    assert gpu.PRBS(23, init=p.state_at(64 * 50_000)).generate(64 * 50_000).equal(whole[50_000:])
