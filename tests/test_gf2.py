@@ -158,3 +158,21 @@ def test_save_matrix_roundtrip(tmp_path):
     text = (tmp_path / "out").read_text().splitlines()
     assert len(text) == 64 and all(len(l) == 64 and set(l) <= {"0", "1"} for l in text)
     assert [sorted(r) for r in recurrences.load_packed(tmp_path / "out")] == [sorted(r) for r in rows]
+
+
+def test_host_arithmetic_under_sanitizers(tmp_path):
+    """The product's host-side GF(2) headers (gf2.hpp, gf2poly.hpp, search_rng.hpp) under AddressSanitizer +
+    UndefinedBehaviorSanitizer, on the reference's polynomial KATs, candidate matrices of every order and a jump."""
+    import subprocess
+    from conftest import ROOT
+    gen = ROOT / "basebandboard_amd" / "csrc" / "gen" / "mersenne_factors.inc"
+    if not gen.exists():
+        subprocess.check_call(["make", "-C", str(ROOT / "basebandboard_amd" / "csrc"), "gen/mersenne_factors.inc"])
+    exe = tmp_path / "san_gf2"
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                        str(ROOT / "tests" / "san_gf2.cpp"), "-o", str(exe)], capture_output=True, text=True)
+    if r.returncode != 0 and "sanitize" in (r.stderr or ""):
+        pytest.skip("no sanitizer runtime for g++ here")
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300, env={"ASAN_OPTIONS": "detect_leaks=0"})
+    assert out.returncode == 0 and out.stdout.startswith("ok "), out.stderr[-2000:]

@@ -203,3 +203,21 @@ def test_detector_packed_form_equals_bytewise(oracle, k):
     assert np.array_equal(r, np.unpackbits(r2.view(np.uint8), bitorder="little")[:n])
     assert st["errors"] == int(((e == 1) & (r == 0)).sum()) and st["errors_raw"] == int(e.sum())
     assert st["reload_clocks"] == int(r.sum()) and st["resyncs"] >= 2
+
+
+@pytest.mark.parametrize("n", (16, 256, 512))
+def test_oracle_under_sanitizers(tmp_path, n):
+    """The checker itself under AddressSanitizer + UndefinedBehaviorSanitizer (sanitizers
+    run on the host build only): every oracle entry point on small inputs, no report, stable output."""
+    import subprocess
+    from conftest import ROOT
+    exe = tmp_path / "san"
+    r = subprocess.run(["gcc", "-O1", "-g", "-std=c11", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-mpopcnt",
+                        str(ROOT / "tests" / "san_driver.c"), str(ROOT / "oracle" / "bbb_oracle.c"), "-o", str(exe), "-lm"],
+                       capture_output=True, text=True)
+    if r.returncode != 0 and "sanitize" in (r.stderr or ""):
+        pytest.skip("no sanitizer runtime for gcc here")
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([str(exe), str(ROOT / "basebandboard_amd" / "data" / f"lutopt_{n}.taps")], capture_output=True, text=True, timeout=120,
+                         env={"ASAN_OPTIONS": "detect_leaks=0"})
+    assert out.returncode == 0 and out.stdout.startswith("ok "), out.stderr[-2000:]
