@@ -15,7 +15,7 @@ BBB_OK, BBB_EINVAL, BBB_ENOMEM, BBB_EHIP, BBB_EIO, BBB_ENODEV, BBB_EUNSUP = 0, -
 SYMBOLS = [
     "bbb_abi_version", "bbb_strerror", "bbb_last_error_detail", "bbb_device_count", "bbb_free",
     "bbb_lutopt_load_matrix_file", "bbb_lutopt_create", "bbb_lutopt_destroy", "bbb_lutopt_set_stream",
-    "bbb_lutopt_is_specialised", "bbb_lutopt_set_custom_fill", "bbb_lutopt_profile", "bbb_lutopt_profile_read", "bbb_lutopt_state_at", "bbb_awgn_fill_i8", "bbb_awgn_fill_i16", "bbb_awgn_prefetch",
+    "bbb_lutopt_is_specialised", "bbb_lutopt_set_custom_fill", "bbb_lutopt_profile", "bbb_lutopt_profile_read", "bbb_lutopt_state_at", "bbb_lutopt_fill_words", "bbb_awgn_fill_i8", "bbb_awgn_fill_i16", "bbb_awgn_prefetch",
     "bbb_clt_tree_i16", "bbb_prbs_fill", "bbb_prbs_check", "bbb_prbs_check_dev", "bbb_prbs_state_at",
     "bbb_prbs_detector_run", "bbb_prbs_detector_stream", "bbb_ber_trials", "bbb_ber_trials_dev", "bbb_shaper_fill_i16", "bbb_tx_fill_i16", "bbb_rx_slice", "bbb_rx_phase_search", "bbb_gf2_berlekamp_massey", "bbb_gf2_recur",
     "bbb_gf2_dot", "bbb_gf2_poly_is_primitive", "bbb_gf2_poly_modexp", "bbb_lutopt_charpoly", "bbb_lutopt_is_full_period",
@@ -62,6 +62,17 @@ class Ber(C.Structure):
 _lib = None
 
 
+def select_build(name):
+    """Choose which build of the library this process loads; must be called before the first use.
+    "product" (default) = libbbb_hip.so.  "experiments" = libbbb_hip_exp.so, the same sources compiled with
+    -DBBB_EXPERIMENTS, in which BBB_* environment variables select kernel variants for A/B timing; the product
+    build has no such switches."""
+    global LIB_PATH
+    if _lib is not None:
+        raise RuntimeError("the library is already loaded")
+    LIB_PATH = _HERE / {"product": "libbbb_hip.so", "experiments": "libbbb_hip_exp.so"}[name]
+
+
 def lib():
     """Load libbbb_hip.so (once).  Raises if the HIP extension has not been built."""
     global _lib
@@ -90,6 +101,7 @@ def lib():
     l.bbb_lutopt_state_at.argtypes = [vp, u64, u64p]
     l.bbb_lutopt_profile.argtypes = [vp, i32]
     l.bbb_lutopt_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), u64p, i32]
+    l.bbb_lutopt_fill_words.argtypes = [vp, vp, u64, u64, i32]
     l.bbb_awgn_fill_i8.argtypes = [vp, vp, u64, u64]
     l.bbb_awgn_fill_i16.argtypes = [vp, vp, u64, u64]
     l.bbb_awgn_prefetch.argtypes = [vp, u64, u64]

@@ -26,6 +26,7 @@
 #include "awgn_launch.hpp"
 
 #include <cstdlib>
+#include <mutex>
 #include "gen/lutopt256_gen.inc"
 
 namespace bbb {
@@ -41,8 +42,8 @@ namespace bbb {
 // index).  States are stored word-major, S[w * stride + g], so that this kernel and the
 // bit-slicing pass touch consecutive addresses from consecutive lanes.
 //
-// Table layout: an entry of W32 words is cut into chunks of C = min(W32, 4) words (one 16-byte
-// access each for C = 4); chunk zc of all 16 entries of nibble n is contiguous:
+// Table layout: an entry of W32 words is cut into chunks of C = 4, 2 or 1 words (the largest that
+// divides W32; one 16-byte access each for C = 4); chunk zc of all 16 entries of nibble n is contiguous:
 //   index(n, v, zc, zz) = ((n * (W32/C) + zc) * 16 + v) * C + zz
 // so the 16 possible 16-byte LDS reads of one (n, zc) cover 256 consecutive bytes = every bank once:
 // lanes reading different entries never conflict, lanes reading the same entry broadcast.
@@ -52,7 +53,7 @@ namespace bbb {
 template <int W32, typename TabPtr>
 __device__ __forceinline__ void nibble_matvec_part(TabPtr tab, int nlo, int nhi, const uint32_t (&x)[W32],
                                                    uint32_t (&y)[W32]) {
-    constexpr int C = W32 < 4 ? W32 : 4;
+    constexpr int C = (W32 % 4 == 0) ? 4 : (W32 % 2 == 0 ? 2 : 1);
     constexpr int NC = W32 / C;
     typedef uint32_t chunk_t __attribute__((ext_vector_type(C)));
     // two lookups are folded per accumulate: y ^= e0 ^ e1 is ONE V_BITOP3 (0x96) per word
@@ -186,7 +187,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 awgn256_kernel(const uint32_t *__restrict planes, int8_t *__restrict dst, unsigned long long nsamples,
-               unsigned L, unsigned long long G, unsigned nlanes, unsigned long long dbg_mask) {
+               unsigned L, unsigned long long G, unsigned nlanes) {
     __shared__ uint32_t Z[16 * 8 * 64];
     const unsigned lane = threadIdx.x;
     const unsigned long long wave = blockIdx.x;
@@ -238,7 +239,7 @@ awgn256_kernel(const uint32_t *__restrict planes, int8_t *__restrict dst, unsign
                 if (g < G && off < nsamples) {
                     const u32x4 v = {o[0][q], o[1][q], o[2][q], o[3][q]};
                     if (off + 16 <= nsamples) {
-                        *reinterpret_cast<u32x4 *>(dst + (off & dbg_mask)) = v;
+                        *reinterpret_cast<u32x4 *>(dst + off) = v;
                     } else {
                         const unsigned n = (unsigned)(nsamples - off);
                         for (unsigned e = 0; e < n; e++) dst[off + e] = (int8_t)((o[e >> 2][q] >> (8 * (e & 3))) & 0xff);
@@ -325,6 +326,44 @@ awgn_generic_kernel(int k, int logk, const uint16_t *__restrict taps, const uint
 }
 
 // ---------------------------------------------------------------------------------------------
+// The uniform word stream LUTOPT.x in bulk (rng.py:29-40 "outputs x on each clock"; the reference
+// dumps it for dieharder in software/rnghunt/util/verify.py:37-52): state t as k/32 consecutive
+// 32-bit words, word j = state bits 32j..32j+31 with bit 32j the LSB, or -- msb_first, verify.py's
+// text-to-int conversion -- the MSB.  Table driven like awgn_generic_kernel (any k multiple of 32,
+// any taps); per step every 32-plane block is transposed back to one word per generator.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+lutopt_words_kernel(int k, const uint16_t *__restrict taps, const uint32_t *__restrict row_off,
+                    uint32_t *__restrict planes2, uint32_t *__restrict dst, unsigned long long nstates, unsigned L,
+                    unsigned long long G, unsigned nlanes, int msb_first) {
+    const unsigned lane = threadIdx.x;
+    const unsigned long long wave = blockIdx.x;
+    const unsigned long long LG = wave * 64 + lane;
+    const unsigned wps = (unsigned)k / 32;
+    uint32_t *cur = planes2, *nxt = planes2 + (size_t)k * nlanes;
+    for (unsigned t = 0; t < L; t++) {
+        for (int r = 0; r < k; r++) {
+            uint32_t acc = 0;
+            for (uint32_t e = row_off[r]; e < row_off[r + 1]; e++) acc ^= cur[(size_t)taps[e] * nlanes + LG];
+            nxt[(size_t)r * nlanes + LG] = acc;
+        }
+        for (unsigned wq = 0; wq < wps; wq++) {
+            uint32_t q[32];
+#pragma unroll
+            for (int p = 0; p < 32; p++) q[p] = nxt[(size_t)(32 * wq + p) * nlanes + LG];
+            transpose32(q);                      // q[j] bit p = state bit 32wq+p of generator j
+#pragma unroll
+            for (unsigned j = 0; j < 32; j++) {
+                const unsigned long long g = gen_index(wave, lane, j);
+                const unsigned long long off = g * L + t;
+                if (g < G && off < nstates) dst[off * wps + wq] = msb_first ? __builtin_bitreverse32(q[j]) : q[j];
+            }
+        }
+        uint32_t *sw = cur; cur = nxt; nxt = sw;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Adder tree on caller-supplied words (clt-grng-evaluate.py:8-16), closed form: +1 weight where
 // popcount(bit index) is even.
 // ---------------------------------------------------------------------------------------------
@@ -356,10 +395,16 @@ static int seed_and_slice(int k, const uint32_t *d_tabs, const uint32_t *s16, ui
     while ((1ull << (2 * levels)) < G) levels++;
     const int nnib_h = (k + 3) / 4, half_h = (nnib_h + 1) / 2 + ((nnib_h + 1) / 2 & 1);
     const size_t lds = (size_t)half_h * 16 * W32 * sizeof(uint32_t);      // half a table at a time
-    static bool attr_set = false;
-    if (!attr_set && lds > 48 * 1024) {
-        BBB_HIP(hipFuncSetAttribute((const void *)seed_level_kernel<W32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+    if (lds > 48 * 1024) {     // per device (hipFuncSetAttribute applies to the current one), guarded
+        static std::mutex mu;
+        static bool attr_set[64] = {false};
+        int dev = 0;
+        BBB_HIP(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> g(mu);
+        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+            BBB_HIP(hipFuncSetAttribute((const void *)seed_level_kernel<W32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        }
     }
     hipLaunchKernelGGL((seed_store16_kernel<W32>), dim3(1), dim3(64), 0, st, s, (unsigned long long)G,
                        (unsigned long long)stride, d_states);
@@ -380,22 +425,20 @@ int awgn_seed_launch(int k, const uint32_t *d_tabs, const uint32_t *s16, uint64_
     switch ((k + 31) / 32) {
     case 1: return seed_and_slice<1>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st);
     case 2: return seed_and_slice<2>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st);
-    case 4: return seed_and_slice<4>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st);
-    case 8: return seed_and_slice<8>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st);
-    case 16: return seed_and_slice<16>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st);
-    default: return fail(BBB_EINVAL, "k must be a power of two in [16, 512]");
+    case 3: case 4: return seed_and_slice<4>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st);
+    case 5: case 6: return seed_and_slice<6>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st);
+    case 7: case 8: return seed_and_slice<8>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st);
+    case 9: case 10: case 11: case 12: return seed_and_slice<12>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st);
+    case 13: case 14: case 15: case 16: return seed_and_slice<16>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st);
+    default: return fail(BBB_EINVAL, "k must be in [2, 512]");
     }
 }
 
 int awgn256_fill_launch(const uint32_t *d_planes, int8_t *dst, uint64_t nsamples, unsigned L, uint64_t G,
                         unsigned nlanes, hipStream_t st) {
     const unsigned nwaves = nlanes / 64;
-    // timing experiment only: BBB_DEBUG_NOSTORE=1 runs the same arithmetic with every store masked off
-    static const bool nostore = std::getenv("BBB_DEBUG_NOSTORE") != nullptr;
-    // BBB_DEBUG_STOREMASK=<hex>: fold every store address into a small window (timing experiment)
-    static const unsigned long long mask = std::getenv("BBB_DEBUG_STOREMASK") ? std::strtoull(std::getenv("BBB_DEBUG_STOREMASK"), nullptr, 16) : ~0ull;
     hipLaunchKernelGGL(awgn256_kernel, dim3(nwaves), dim3(64), 0, st, d_planes, dst, (unsigned long long)nsamples, L,
-                       (unsigned long long)(nostore ? 0 : G), nlanes, mask);
+                       (unsigned long long)G, nlanes);
     BBB_HIP(hipGetLastError());
     return BBB_OK;
 }
@@ -412,6 +455,14 @@ int awgn_generic_fill_launch(int k, const uint16_t *d_taps, const uint32_t *d_ro
     else
         hipLaunchKernelGGL((awgn_generic_kernel<int16_t>), dim3(nwaves), dim3(64), 0, st, k, logk, d_taps, d_row_off,
                            d_planes2, (int16_t *)dst, (unsigned long long)nsamples, L, (unsigned long long)G, nlanes);
+    BBB_HIP(hipGetLastError());
+    return BBB_OK;
+}
+
+int lutopt_words_launch(int k, const uint16_t *d_taps, const uint32_t *d_row_off, uint32_t *d_planes2, uint32_t *dst,
+                        uint64_t nstates, unsigned L, uint64_t G, unsigned nlanes, bool msb_first, hipStream_t st) {
+    hipLaunchKernelGGL(lutopt_words_kernel, dim3(nlanes / 64), dim3(64), 0, st, k, d_taps, d_row_off, d_planes2, dst,
+                       (unsigned long long)nstates, L, (unsigned long long)G, nlanes, msb_first ? 1 : 0);
     BBB_HIP(hipGetLastError());
     return BBB_OK;
 }

@@ -16,6 +16,9 @@ int widen_i8_i16_launch(const int8_t *src, int16_t *dst, uint64_t n, hipStream_t
 int awgn_generic_fill_launch(int k, const uint16_t *d_taps, const uint32_t *d_row_off, uint32_t *d_planes2,
                              void *dst, int elem_size, uint64_t nsamples, unsigned L, uint64_t G, unsigned nlanes,
                              hipStream_t st);
+// LUTOPT.x as 32-bit words, k/32 per state (k a multiple of 32), table driven
+int lutopt_words_launch(int k, const uint16_t *d_taps, const uint32_t *d_row_off, uint32_t *d_planes2, uint32_t *dst,
+                        uint64_t nstates, unsigned L, uint64_t G, unsigned nlanes, bool msb_first, hipStream_t st);
 int clt_tree_launch(int k, const uint64_t *states, uint64_t nstates, int16_t *out, hipStream_t st);
 bool awgn256_matches(int k, const uint16_t *taps, const uint32_t *row_off);
 // awgn_small.hip: generated kernels for the shipped n16 / n32 / n64 / n128 matrices
@@ -37,8 +40,8 @@ int ber256_launch(const uint32_t *d_planes, const uint32_t *d_prbs_planes, const
                   unsigned long long *d_counters, hipStream_t st);
 int prbs_state_at_host(int k, uint64_t init_state, uint64_t nbits, uint64_t *state);
 
-// pulse shaper / transmitter output (tx_kernels.hip); d_bits holds data bits m0.. packed LSB first
-int tx_waveform_launch(const int16_t *coeffs, const uint64_t *d_bits, int64_t m0, int source, const int8_t *d_noise,
+// pulse shaper / transmitter output (tx_kernels.hip); d_bits holds data bits m0 .. m0+navail-1 packed LSB first
+int tx_waveform_launch(const int16_t *coeffs, const uint64_t *d_bits, int64_t m0, uint64_t navail, int source, const int8_t *d_noise,
                        int noise_var, int bit_en, int noise_en, uint64_t first_sample, uint64_t nsamples,
                        int16_t *d_out, hipStream_t st);
 

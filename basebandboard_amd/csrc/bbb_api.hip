@@ -107,6 +107,15 @@ struct bbb_lutopt {
 
 namespace {
 
+// device-side state width in 32-bit words: the seeding / bit-slicing kernels exist for these widths, a k in
+// between is padded with zero words (rows and columns beyond k are empty, so the padding stays zero)
+int pad_w32(int k) {
+    const int w = (k + 31) / 32;
+    for (int c : {1, 2, 4, 6, 8, 12, 16})
+        if (w <= c) return c;
+    return 16;
+}
+
 int grow(uint32_t **p, size_t *cap, size_t need_words) {
     if (*cap >= need_words) return BBB_OK;
     if (*p) BBB_HIP(hipFree(*p));
@@ -119,8 +128,8 @@ int grow(uint32_t **p, size_t *cap, size_t need_words) {
 
 // Nibble-combination table of one matrix (layout: see seed kernels in awgn_kernels.hip).
 void nibble_table(const GF2Mat &M, uint32_t *out) {
-    const int k = M.n, W32 = (k + 31) / 32, nnib = (k + 3) / 4;
-    const int C = W32 < 4 ? W32 : 4, NC = W32 / C;
+    const int k = M.n, W32 = pad_w32(k), nnib = (k + 3) / 4;
+    const int C = (W32 % 4 == 0) ? 4 : (W32 % 2 == 0 ? 2 : 1), NC = W32 / C;
     std::vector<uint32_t> cols((size_t)k * W32, 0u);
     for (int r = 0; r < k; r++) {
         const uint64_t *row = M.row(r);
@@ -150,7 +159,7 @@ void nibble_table(const GF2Mat &M, uint32_t *out) {
 // Radix-4 jump plan of M: for e < levels and j = 1..3 the table of M^(j*4^e), packed
 // [e][j-1][table], uploaded to the device.
 int build_plan(const GF2Mat &M, int levels, JumpPlan *plan) {
-    const int k = M.n, W32 = (k + 31) / 32, nnib = (k + 3) / 4;
+    const int k = M.n, W32 = pad_w32(k), nnib = (k + 3) / 4;
     const size_t nt = (size_t)nnib * 16 * W32;
     std::vector<uint32_t> host((size_t)levels * 3 * nt, 0);
     GF2Mat m1 = M;                                   // M^(4^e)
@@ -176,7 +185,7 @@ void first16(const JumpPlan &plan, const uint64_t *s0, uint32_t *out) {
     std::memset(out, 0, sizeof(uint32_t) * 256);
     for (int i = 0; i < 16; i++) {
         if (i) plan.B.matvec(x, x);
-        for (int w = 0; w < 2 * W; w++) out[i * 16 + w] = (uint32_t)(x[w >> 1] >> (32 * (w & 1)));
+        for (int w = 0; w < 2 * W && w < 16; w++) out[i * 16 + w] = (uint32_t)(x[w >> 1] >> (32 * (w & 1)));
     }
 }
 
@@ -221,6 +230,15 @@ void partition(const bbb_lutopt *h, uint64_t n, unsigned granule, uint64_t *L, u
     *nlanes = (unsigned)(waves * 64);
 }
 
+// Every kernel that touches d_states / d_planes on the main stream is followed by this: after a prefetch swap
+// these buffers become the side stream's, which must not seed into them while such a kernel is still running.
+int mark_planes_read(bbb_lutopt *h) {
+    if (!h->cur_last_read) BBB_HIP(hipEventCreateWithFlags(&h->cur_last_read, hipEventDisableTiming));
+    BBB_HIP(hipEventRecord(h->cur_last_read, h->stream));
+    h->cur_read_pending = true;
+    return BBB_OK;
+}
+
 // make d_planes hold the bit-sliced states A^(first + g*L) init, g < G
 int prepare_planes(bbb_lutopt *h, uint64_t first, uint64_t L, uint64_t G, unsigned nlanes) {
     if (h->planes_valid && h->planes_first == first && h->planes_L == L && h->planes_G == G) return BBB_OK;
@@ -236,6 +254,7 @@ int prepare_planes(bbb_lutopt *h, uint64_t first, uint64_t L, uint64_t G, unsign
     h->planes_valid = false;
     rc = awgn_seed_launch(h->k, plan->d_cols, s16, G, h->d_states, G, nlanes, h->d_planes, h->stream);
     if (rc) return rc;
+    if ((rc = mark_planes_read(h))) return rc;
     h->planes_valid = true;
     h->planes_first = first; h->planes_L = L; h->planes_G = G;
     return BBB_OK;
@@ -246,12 +265,14 @@ int awgn_fill(bbb_lutopt *h, void *dst, int elem_size, uint64_t nsamples, uint64
     if (nsamples == 0) return BBB_OK;
     if (!dst || ((uintptr_t)dst & 15)) return fail(BBB_EINVAL, "dst must be a 16-byte aligned device pointer");
     if (first_step + nsamples < first_step) return fail(BBB_EINVAL, "first_step + nsamples overflows");
+    if (h->k & (h->k - 1)) return fail(BBB_EUNSUP, "CLTGRNG needs k to be a power of two (rng.py:72-76)");
     if (elem_size == 1 && h->k > 256) return fail(BBB_EUNSUP, "k > 256 needs the int16 output");
     if (h->device < 0) return fail(BBB_ENODEV, "host-only handle (device -1) cannot generate samples");
     BBB_HIP(hipSetDevice(h->device));
     uint64_t L, G;
     unsigned nlanes;
     partition(h, nsamples, 16, &L, &G, &nlanes);
+    if (L > 0xffffff00ull) return fail(BBB_EINVAL, "nsamples too large for one call (segment length must fit 32 bits): split it");
     bbb_lutopt::ProfEv ev{};
     if (h->profiling) {
         BBB_HIP(hipEventCreate(&ev.e0)); BBB_HIP(hipEventCreate(&ev.e1)); BBB_HIP(hipEventCreate(&ev.e2));
@@ -274,11 +295,7 @@ int awgn_fill(bbb_lutopt *h, void *dst, int elem_size, uint64_t nsamples, uint64
     if (h->specialised && elem_size == 1) {
         if (h->profiling) BBB_HIP(hipEventRecord(ev.e1, h->stream));
         rc = awgn256_fill_launch(h->d_planes, (int8_t *)dst, nsamples, (unsigned)L, G, nlanes, h->stream);
-        if (!rc) {
-            if (!h->cur_last_read) BBB_HIP(hipEventCreateWithFlags(&h->cur_last_read, hipEventDisableTiming));
-            BBB_HIP(hipEventRecord(h->cur_last_read, h->stream));
-            h->cur_read_pending = true;
-        }
+        if (!rc) rc = mark_planes_read(h);
         if (h->profiling) {
             BBB_HIP(hipEventRecord(ev.e2, h->stream));
             h->prof_pending.push_back(ev);
@@ -288,13 +305,16 @@ int awgn_fill(bbb_lutopt *h, void *dst, int elem_size, uint64_t nsamples, uint64
     if (h->custom_fill && elem_size == 1) {
         const int e = h->custom_fill(h->d_planes, (int8_t *)dst, nsamples, (uint32_t)L, G, nlanes, (void *)h->stream);
         if (e) return fail(BBB_EHIP, std::string("custom sample kernel: ") + hipGetErrorString((hipError_t)e));
-        return BBB_OK;
+        return mark_planes_read(h);
     }
-    if (h->small_fast && elem_size == 1)
-        return awgn_small_fill_launch(h->small_fast, h->d_planes, (int8_t *)dst, nsamples, (unsigned)L, G, nlanes, h->stream);
+    if (h->small_fast && elem_size == 1) {
+        rc = awgn_small_fill_launch(h->small_fast, h->d_planes, (int8_t *)dst, nsamples, (unsigned)L, G, nlanes, h->stream);
+        return rc ? rc : mark_planes_read(h);
+    }
     h->planes_valid = false;    // the table-driven kernel advances the planes in place
-    return awgn_generic_fill_launch(h->k, h->d_taps, h->d_row_off, h->d_planes, dst, elem_size, nsamples, (unsigned)L, G,
-                                    nlanes, h->stream);
+    rc = awgn_generic_fill_launch(h->k, h->d_taps, h->d_row_off, h->d_planes, dst, elem_size, nsamples, (unsigned)L, G,
+                                  nlanes, h->stream);
+    return rc ? rc : mark_planes_read(h);
 }
 
 // tabulate the channel of tx.py:75-81 / rx.py:29 into threshold lists over T = sample + 128
@@ -367,6 +387,8 @@ int ber_run(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, unsigned long lo
         uint64_t L, G;
         unsigned nlanes;
         partition(h, c.nbits, 2, &L, &G, &nlanes);
+        // per-lane counters are 32 bits wide and count up to 32 L
+        if (L >= (1ull << 27)) return fail(BBB_EINVAL, "nbits too large for one trial (about 2^47): split it with first_bit");
         for (int j = 0; j < n; j++) { td[(size_t)(i + j)].L = (uint32_t)L; td[(size_t)(i + j)].G = G; td[(size_t)(i + j)].nbits = c.nbits; }
         int rc;
         if ((rc = prepare_planes(h, c.warmup + c.first_bit, L, G, nlanes))) return rc;
@@ -382,6 +404,7 @@ int ber_run(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, unsigned long lo
         first16(*pp, ps64, ps16);
         if ((rc = awgn_seed_launch(c.prbs_k, pp->d_cols, ps16, G, h->d_pstates, G, nlanes, h->d_pplanes, h->stream))) return rc;
         if ((rc = ber256_launch(h->d_planes, h->d_pplanes, &td[(size_t)i], n, nlanes, counters_dev + 2 * (size_t)i, h->stream))) return rc;
+        if ((rc = mark_planes_read(h))) return rc;
         i += n;
     }
     return BBB_OK;
@@ -454,7 +477,9 @@ int bbb_lutopt_load_matrix_file(const char *path, int *k, uint16_t **taps, uint3
 int bbb_lutopt_create(bbb_lutopt **out, int k, const uint16_t *taps, const uint32_t *row_off,
                       const uint64_t *init_words, int device) {
     if (!out || !taps || !row_off || !init_words) return fail(BBB_EINVAL, "null argument");
-    if (k < 16 || k > BBB_MAX_K || (k & (k - 1))) return fail(BBB_EINVAL, "k must be a power of two in [16, 512]");
+    // LUTOPT itself puts no constraint on k (rng.py:21-40; rng_recurrences.py:105 ships n192, rnghunt searches
+    // n = 192, rnghunt.rs:14); only CLTGRNG needs a power of two (rng.py:72-76) -- checked where samples are asked for
+    if (k < 2 || k > BBB_MAX_K) return fail(BBB_EINVAL, "k must be in [2, 512]");
     GF2Mat A(k);
     for (int r = 0; r < k; r++) {
         const uint32_t n = row_off[r + 1] - row_off[r];
@@ -474,7 +499,7 @@ int bbb_lutopt_create(bbb_lutopt **out, int k, const uint16_t *taps, const uint3
     std::unique_ptr<bbb_lutopt> h(new bbb_lutopt);
     h->k = k;
     h->W64 = (k + 63) / 64;
-    h->W32 = (k + 31) / 32;
+    h->W32 = pad_w32(k);
     h->device = device;
     h->taps.assign(taps, taps + row_off[k]);
     h->row_off.assign(row_off, row_off + k + 1);
@@ -564,7 +589,7 @@ int bbb_lutopt_profile_read(bbb_lutopt *h, double *seed_ms, double *kernel_ms, u
 
 int bbb_lutopt_state_at(bbb_lutopt *h, uint64_t nsteps, uint64_t *state_words) {
     if (!h || !state_words) return fail(BBB_EINVAL, "null argument");
-    h->pw->apply(nsteps, h->init, state_words);
+    h->pw->apply(nsteps, h->init, state_words);       // ceil(k/64) words
     return BBB_OK;
 }
 
@@ -576,6 +601,7 @@ int bbb_awgn_prefetch(bbb_lutopt *h, uint64_t nsamples, uint64_t first_step) {
     uint64_t L, G;
     unsigned nlanes;
     partition(h, nsamples, 16, &L, &G, &nlanes);
+    if (L > 0xffffff00ull) return BBB_OK;                         // the matching fill will refuse; nothing to prepare
     JumpPlan *plan;
     int rc = get_plan(h, L, &plan);
     if (rc) return rc;
@@ -618,6 +644,27 @@ int bbb_awgn_fill_i16(bbb_lutopt *h, int16_t *dst_dev, uint64_t nsamples, uint64
     return awgn_fill(h, dst_dev, 2, nsamples, first_step);
 }
 
+int bbb_lutopt_fill_words(bbb_lutopt *h, uint32_t *dst_dev, uint64_t nstates, uint64_t first_step, int msb_first) {
+    if (!h) return fail(BBB_EINVAL, "null handle");
+    if (h->k % 32) return fail(BBB_EUNSUP, "the word stream is defined for k a multiple of 32 (util/verify.py:41,50)");
+    if (nstates == 0) return BBB_OK;
+    if (!dst_dev || ((uintptr_t)dst_dev & 3)) return fail(BBB_EINVAL, "dst must be a 4-byte aligned device pointer");
+    if (first_step + nstates < first_step) return fail(BBB_EINVAL, "first_step + nstates overflows");
+    if (nstates > (1ull << 48)) return fail(BBB_EINVAL, "nstates must be <= 2^48 per call");
+    if (h->device < 0) return fail(BBB_ENODEV, "host-only handle (device -1) cannot generate words");
+    BBB_HIP(hipSetDevice(h->device));
+    uint64_t L, G;
+    unsigned nlanes;
+    partition(h, nstates, 1, &L, &G, &nlanes);
+    int rc = prepare_planes(h, first_step, L, G, nlanes);
+    if (rc) return rc;
+    h->planes_valid = false;    // the table-driven kernel advances the planes in place
+    rc = lutopt_words_launch(h->k, h->d_taps, h->d_row_off, h->d_planes, dst_dev, nstates, (unsigned)L, G, nlanes,
+                             msb_first != 0, h->stream);
+    if (!rc) rc = mark_planes_read(h);
+    return rc;
+}
+
 int bbb_clt_tree_i16(int k, const uint64_t *states_dev, uint64_t nstates, int16_t *out_dev, int device,
                      void *hip_stream) {
     if (k < 2 || k > BBB_MAX_K || (k & (k - 1)) || (k & 63)) return fail(BBB_EINVAL, "k must be 64, 128, 256 or 512");
@@ -652,21 +699,19 @@ int bbb_prbs_check(int k, uint64_t init_state, uint64_t first_bit, uint64_t nbit
     int rc = use_device(device);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)hip_stream;
-    // one 8-byte device counter per device, allocated once (a malloc/free pair per call would cost
-    // as much as checking a gigabyte)
-    static std::mutex mu;
-    static uint64_t *slots[64] = {nullptr};
+    // the counter belongs to this call (stream-ordered allocation from the device's pool: microseconds, and
+    // two threads or streams checking on one device never share it)
     uint64_t *d = nullptr;
-    {
-        std::lock_guard<std::mutex> g(mu);
-        if (device >= 64) return fail(BBB_EINVAL, "device index too large");
-        if (!slots[device]) BBB_HIP(hipMalloc((void **)&slots[device], sizeof(uint64_t)));
-        d = slots[device];
+    BBB_HIP(hipMallocAsync((void **)&d, sizeof(uint64_t), st));
+    hipError_t e = hipMemsetAsync(d, 0, sizeof(uint64_t), st);
+    rc = e == hipSuccess ? bbb_prbs_check_dev(k, init_state, first_bit, nbits, src_packed_dev, d, device, hip_stream)
+                         : fail(BBB_EHIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e));
+    if (rc == BBB_OK) {
+        e = hipMemcpyAsync(nerr, d, sizeof(uint64_t), hipMemcpyDeviceToHost, st);
+        if (e != hipSuccess) rc = fail(BBB_EHIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e));
     }
-    BBB_HIP(hipMemsetAsync(d, 0, sizeof(uint64_t), st));
-    rc = bbb_prbs_check_dev(k, init_state, first_bit, nbits, src_packed_dev, d, device, hip_stream);
+    (void)hipFreeAsync(d, st);
     if (rc) return rc;
-    BBB_HIP(hipMemcpyAsync(nerr, d, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     BBB_HIP(hipStreamSynchronize(st));
     return BBB_OK;
 }
@@ -734,7 +779,7 @@ int bbb_shaper_fill_i16(const bbb_tx_cfg *cfg, int16_t *out_dev, uint64_t nsampl
         BBB_HIP(hipMallocAsync((void **)&d_bits, ((nbits + 63) / 64 + 2) * sizeof(uint64_t), st));
         rc = prbs_fill_launch(cfg->prbs_k, cfg->prbs_state, (uint64_t)m0, nbits, d_bits, st);
     }
-    if (!rc) rc = tx_waveform_launch(cfg->coeffs, d_bits, m0, cfg->source, nullptr, 0, 1, 0, first_sample, nsamples, out_dev, st);
+    if (!rc) rc = tx_waveform_launch(cfg->coeffs, d_bits, m0, d_bits ? nbits : 0, cfg->source, nullptr, 0, 1, 0, first_sample, nsamples, out_dev, st);
     if (d_bits) (void)hipFreeAsync(d_bits, st);
     return rc;
 }
@@ -751,7 +796,8 @@ int bbb_tx_fill_i16(bbb_lutopt *h, const bbb_tx_cfg *cfg, int16_t *out_dev, uint
     int64_t m0;
     uint64_t nbits;
     tx_bit_range(first_sample, nsamples, &m0, &nbits);
-    if (cfg->source == 0 && nbits && cfg->bit_en) {
+    const bool have_bits = cfg->source == 0 && nbits && cfg->bit_en;
+    if (have_bits) {
         if ((rc = grow(&h->d_txbits, &h->txbits_cap, (size_t)((nbits + 63) / 64 + 2) * 2))) return rc;
         if ((rc = prbs_fill_launch(cfg->prbs_k, cfg->prbs_state, (uint64_t)m0, nbits, (uint64_t *)h->d_txbits, h->stream))) return rc;
     }
@@ -759,9 +805,9 @@ int bbb_tx_fill_i16(bbb_lutopt *h, const bbb_tx_cfg *cfg, int16_t *out_dev, uint
         if ((rc = grow(&h->d_txnoise, &h->txnoise_cap, (size_t)(nsamples + 15) / 4 + 4))) return rc;
         if ((rc = awgn_fill(h, h->d_txnoise, 1, nsamples, cfg->warmup + first_sample))) return rc;   // tx.py:70-71
     }
-    return tx_waveform_launch(cfg->coeffs, (const uint64_t *)h->d_txbits, m0, cfg->bit_en ? cfg->source : 1,
-                              (const int8_t *)h->d_txnoise, cfg->noise_var, cfg->bit_en, cfg->noise_en, first_sample,
-                              nsamples, out_dev, h->stream);
+    return tx_waveform_launch(cfg->coeffs, have_bits ? (const uint64_t *)h->d_txbits : nullptr, m0, have_bits ? nbits : 0,
+                              cfg->bit_en ? cfg->source : 1, (const int8_t *)h->d_txnoise, cfg->noise_var, cfg->bit_en,
+                              cfg->noise_en, first_sample, nsamples, out_dev, h->stream);
 }
 
 int bbb_rx_slice(const int16_t *samples_dev, uint64_t nsamples, uint64_t stride, uint64_t phase, int strict,

@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 
 #include "../../include/bbb.h"
@@ -30,6 +31,17 @@ inline int fail(int code, const std::string &what) {
 int use_device(int device);
 
 constexpr int kWave = 64;   // CDNA wavefront
+
+// Timing-experiment knobs (kernel variants selected through the environment) exist only in builds made with
+// -DBBB_EXPERIMENTS; the shipped library ignores the environment: no variable can change what it computes.
+#ifdef BBB_EXPERIMENTS
+inline int env_knob(const char *name, int dflt) {
+    const char *v = std::getenv(name);
+    return v ? std::atoi(v) : dflt;
+}
+#else
+constexpr int env_knob(const char *, int dflt) { return dflt; }
+#endif
 
 // ---- PRBS entry points implemented in prbs_kernels.hip -------------------------------------
 int prbs_fill_launch(int k, uint64_t init_state, uint64_t first_bit, uint64_t nbits,

@@ -259,7 +259,7 @@ int ber256_launch(const uint32_t *d_planes, const uint32_t *d_prbs_planes, const
         tk.thrx[c] = (int16_t)(256 - tk.thr[c][1][0]);
         tk.strict0[c] = (int8_t)d;
     }
-    static const bool no_fast = std::getenv("BBB_BER_NO_FAST") != nullptr;     // (A/B timing of the two forms)
+    static const bool no_fast = env_knob("BBB_BER_NO_FAST", 0) != 0;     // (A/B timing of the two forms; -DBBB_EXPERIMENTS only)
     if (fast && !no_fast)
         hipLaunchKernelGGL(ber256_kernel<kBerFast>, dim3(nlanes / 64), dim3(64), 0, st, d_planes, d_prbs_planes, tk, nlanes,
                            d_counters);

@@ -123,7 +123,7 @@ __device__ __forceinline__ void xor_inplace(u32x4 &a, const u32x4 &b) {
 template <int K, bool CHECK, int WPL, bool LW>
 __global__ void __launch_bounds__(64, 2)   // >= 2 waves per SIMD: at most 256 registers
 prbs_stream_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwords, u64 rows_per_wave,
-                   u64 *__restrict buf, u64 *__restrict nerr, int nt) {
+                   u64 *__restrict buf, u64 *__restrict nerr) {
     typedef typename LaneWords<WPL>::type lw_t;
     constexpr int TAP = tap_of(K);
     constexpr int RW = 64 * WPL;                 // words per row
@@ -277,13 +277,8 @@ prbs_stream_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwords,
             } else {
 #pragma unroll
                 for (int i = 0; i < K; i++) xor_inplace(V[i], V[(i - TAP + K) % K]);
-                if (nt) {        // BBB_PRBS_FILL_NT=1 (timing experiment): stores that do not stay in the caches
 #pragma unroll
-                    for (int i = 0; i < K; i++) __builtin_nontemporal_store(V[i], &reinterpret_cast<lw_t *>(rowp + (u64)i * RW)[lane]);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < K; i++) reinterpret_cast<lw_t *>(rowp + (u64)i * RW)[lane] = V[i];
-                }
+                for (int i = 0; i < K; i++) reinterpret_cast<lw_t *>(rowp + (u64)i * RW)[lane] = V[i];
             }
             continue;
         }
@@ -327,8 +322,8 @@ prbs_stream_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwords,
 // words per lane: 1 (8-byte accesses, a 2K-register window, 15.5 KiB of LDS for K = 31) measured
 // faster than 2 for both directions (profiles/r01_prbs_sweep.log); overridable for experiments
 static int prbs_wpl(bool check) {
-    static const int fill = std::getenv("BBB_PRBS_FILL_WPL") ? std::atoi(std::getenv("BBB_PRBS_FILL_WPL")) : 1;
-    static const int chk = std::getenv("BBB_PRBS_CHECK_WPL") ? std::atoi(std::getenv("BBB_PRBS_CHECK_WPL")) : 1;
+    static const int fill = env_knob("BBB_PRBS_FILL_WPL", 1);      // knobs exist only in -DBBB_EXPERIMENTS builds
+    static const int chk = env_knob("BBB_PRBS_CHECK_WPL", 1);
     const int v = check ? chk : fill;
     return v == 1 ? 1 : 2;
 }
@@ -347,17 +342,20 @@ static int launch_stream_w(int k, int ki, u64 init_state, u64 first_bit, u64 nbi
 #define BBB_PRBS_FN(KK) case KK: fn = (const void *)prbs_stream_kernel<KK, CHECK, WPL, LW>; break;
     switch (k) { BBB_PRBS_FN(7) BBB_PRBS_FN(9) BBB_PRBS_FN(11) BBB_PRBS_FN(15) BBB_PRBS_FN(20) BBB_PRBS_FN(23) BBB_PRBS_FN(31) }
 #undef BBB_PRBS_FN
-    static const int nt = (!CHECK && std::getenv("BBB_PRBS_FILL_NT")) ? 1 : 0;
-    static int cached_per_cu[8] = {0};                 // per K (this function is instantiated per CHECK/WPL/LW)
-    int &slot = cached_per_cu[ki];
-    if (slot == 0) {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, 0) != hipSuccess || per_cu < 1) per_cu = 4;
-        slot = per_cu;
+    {   // occupancy of this instantiation, per K, cached under a lock (the same for every gfx950 device)
+        static std::mutex mu;
+        static int cached_per_cu[8] = {0};
+        std::lock_guard<std::mutex> g(mu);
+        int &slot = cached_per_cu[ki];
+        if (slot == 0) {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+            slot = per_cu;
+        }
+        per_cu = slot;
     }
-    per_cu = slot;
     // the generator is fastest with 4 waves per CU (stores need little latency hiding and fewer,
     // longer regions amortise the bootstrap); the checker takes every wave it can get
-    static const int cap_env = std::getenv("BBB_PRBS_WAVES_PER_CU") ? std::atoi(std::getenv("BBB_PRBS_WAVES_PER_CU")) : -1;
+    static const int cap_env = env_knob("BBB_PRBS_WAVES_PER_CU", -1);
     const int cap = cap_env >= 0 ? cap_env : (CHECK ? 0 : 4);
     if (cap > 0 && per_cu > cap) per_cu = cap;
     const u64 target_waves = (u64)ncu * (u64)per_cu;
@@ -370,7 +368,7 @@ static int launch_stream_w(int k, int ki, u64 init_state, u64 first_bit, u64 nbi
 #define BBB_PRBS_CASE(KK)                                                                                       \
     case KK:                                                                                                    \
         hipLaunchKernelGGL((prbs_stream_kernel<KK, CHECK, WPL, LW>), grid, block, 0, st, ki, init_state, first_bit, \
-                           nbits, nwords, rpw, buf, nerr, nt);                                                  \
+                           nbits, nwords, rpw, buf, nerr);                                                      \
         break;
     switch (k) {
         BBB_PRBS_CASE(7) BBB_PRBS_CASE(9) BBB_PRBS_CASE(11) BBB_PRBS_CASE(15)
@@ -394,8 +392,8 @@ static int launch_stream(int k, u64 init_state, u64 first_bit, u64 nbits, u64 *b
     // both directions: register window, 8-byte accesses (same-box A/B in profiles/README.md); the
     // LDS-window variants stay selectable for experiments
     // (both measured: profiles/r01_prbs_sweep.log)
-    static const int lw_fill = std::getenv("BBB_PRBS_FILL_LW") ? std::atoi(std::getenv("BBB_PRBS_FILL_LW")) : 0;
-    static const int lw_chk = std::getenv("BBB_PRBS_CHECK_LW") ? std::atoi(std::getenv("BBB_PRBS_CHECK_LW")) : 0;
+    static const int lw_fill = env_knob("BBB_PRBS_FILL_LW", 0);
+    static const int lw_chk = env_knob("BBB_PRBS_CHECK_LW", 0);
     const bool lw = CHECK ? lw_chk != 0 : lw_fill != 0;
     if (prbs_wpl(CHECK) == 1)
         return lw ? launch_stream_w<CHECK, 1, true>(k, ki, init_state, first_bit, nbits, buf, nerr, st)

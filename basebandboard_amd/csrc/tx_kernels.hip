@@ -24,7 +24,7 @@ struct Coeffs64 { int16_t c[64]; };
 __device__ __forceinline__ int wrap12_dev(int v) { return (int)((unsigned)v << 20) >> 20; }
 
 __global__ void __launch_bounds__(256)
-tx_waveform_kernel(Coeffs64 cf, const unsigned long long *__restrict bits, long long m0, int source,
+tx_waveform_kernel(Coeffs64 cf, const unsigned long long *__restrict bits, long long m0, unsigned long long navail, int source,
                    const int8_t *__restrict noise, int noise_var, int bit_en, int noise_en,
                    unsigned long long first_sample, unsigned long long nsamples, int16_t *__restrict out) {
     __shared__ int16_t T[8 * 256];
@@ -49,7 +49,9 @@ tx_waveform_kernel(Coeffs64 cf, const unsigned long long *__restrict bits, long 
         const long long M0 = np0 >> 3;                                      // floor
         // Q bit j = data bit M0-7+j, j = 0..9 (bits before the first one are 0: the reset shift register)
         unsigned Q = 0;
-        if (source == 0 && M0 - 7 >= m0) {
+        // `bits` holds data bits m0 .. m0+navail-1 and nothing else may be read: a window reaching past them
+        // (only bits that no sample of the request needs) takes the bit-by-bit path, which reads 0 there
+        if (source == 0 && M0 - 7 >= m0 && (unsigned long long)(M0 - 7 - m0) + 10 <= navail) {
             const unsigned long long rel = (unsigned long long)(M0 - 7 - m0);
             const unsigned sh = (unsigned)(rel & 63);
             unsigned long long w = bits[rel >> 6] >> sh;
@@ -63,7 +65,7 @@ tx_waveform_kernel(Coeffs64 cf, const unsigned long long *__restrict bits, long 
                 if (m >= 0) {
                     if (source == 0) {
                         const unsigned long long rel = (unsigned long long)(m - m0);
-                        b = (unsigned)((bits[rel >> 6] >> (rel & 63)) & 1ull);
+                        if (m >= m0 && rel < navail) b = (unsigned)((bits[rel >> 6] >> (rel & 63)) & 1ull);
                     } else {
                         b = (m & 255) == 0;                                  // Pulser: counter == 0 (tx.py:28-30)
                     }
@@ -101,7 +103,7 @@ tx_waveform_kernel(Coeffs64 cf, const unsigned long long *__restrict bits, long 
     }
 }
 
-int tx_waveform_launch(const int16_t *coeffs, const uint64_t *d_bits, int64_t m0, int source, const int8_t *d_noise,
+int tx_waveform_launch(const int16_t *coeffs, const uint64_t *d_bits, int64_t m0, uint64_t navail, int source, const int8_t *d_noise,
                        int noise_var, int bit_en, int noise_en, uint64_t first_sample, uint64_t nsamples,
                        int16_t *d_out, hipStream_t st) {
     if (nsamples == 0) return BBB_OK;
@@ -111,7 +113,7 @@ int tx_waveform_launch(const int16_t *coeffs, const uint64_t *d_bits, int64_t m0
     uint64_t blocks = (groups + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(tx_waveform_kernel, dim3((unsigned)blocks), dim3(256), 0, st, cf,
-                       (const unsigned long long *)d_bits, (long long)m0, source, d_noise, noise_var, bit_en, noise_en,
+                       (const unsigned long long *)d_bits, (long long)m0, (unsigned long long)(d_bits ? navail : 0), source, d_noise, noise_var, bit_en, noise_en,
                        (unsigned long long)first_sample, (unsigned long long)nsamples, d_out);
     BBB_HIP(hipGetLastError());
     return BBB_OK;

@@ -133,6 +133,23 @@ class LUTOPT:
         _lib.check(_lib.lib().bbb_lutopt_state_at(self._h, nsteps, out), "bbb_lutopt_state_at")
         return sum(int(w) << (64 * i) for i, w in enumerate(out))
 
+    def generate_words(self, nstates, first_step=0, msb_first=False, out=None):
+        """`x` in bulk: the states after first_step + 1 ... first_step + nstates clocks as k/32 consecutive 32-bit
+        words each (int32 CUDA tensor of nstates * k/32 elements holding the bit patterns).  msb_first=True gives
+        the words of the dieharder dump the reference writes (software/rnghunt/util/verify.py:37-52)."""
+        if self.k % 32:
+            raise ValueError("the word stream needs k to be a multiple of 32")
+        dev = torch.device("cuda", self.device)
+        n = int(nstates) * (self.k // 32)
+        if out is None:
+            out = torch.empty(n, dtype=torch.int32, device=dev)
+        if out.dtype != torch.int32 or out.numel() < n or not out.is_contiguous() or out.device != dev:
+            raise ValueError(f"out must be a contiguous int32 tensor on {dev} with >= nstates * k/32 elements")
+        self._bind_stream()
+        _lib.check(_lib.lib().bbb_lutopt_fill_words(self._h, C.c_void_p(out.data_ptr()), int(nstates), int(first_step),
+                                                    int(bool(msb_first))), "bbb_lutopt_fill_words")
+        return out[:n]
+
     def profile(self, enable=True):
         """Time the generator kernels on the device (hipEvents on the launch stream)."""
         _lib.check(_lib.lib().bbb_lutopt_profile(self._h, int(enable)), "bbb_lutopt_profile")

@@ -87,6 +87,42 @@ def cpu_baseline_other():
             "sample": f"{nb} PRBS-31 bits (word-parallel restatement); one {nbe}-bit BPSK trial (LUTOPT-256 + CLT + channel)"}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes (one per GPU,
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), pass rank 0's stdout (the one JSON line) through and return
+    non-zero if any rank fails.  The shape of the reference's only multi-worker program -- workers plus one
+    channel back to the parent (software/rnghunt/src/bin/rnghunt.rs:16-18,54-65).  The parent never
+    initialises the GPU, and nothing is exec'ed over a process that has."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, str(pathlib.Path(__file__).resolve())] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    pending = dict(enumerate(procs))
+    while pending:
+        for r, p in list(pending.items()):
+            code = p.poll()
+            if code is None:
+                continue
+            del pending[r]
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                for q in pending.values():
+                    q.terminate()           # exactly the PIDs started above
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,7 +130,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendezvous only (gloo, no GPU): every rank joins, one all-reduce, rank 0 prints a JSON line")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as plain `python bench.py --gpus N`: this process becomes the launcher and never touches
+        # the GPU (no torch.cuda / HIP call has happened yet); the ranks are its children.
+        sys.exit(launch_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -102,9 +145,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         args.gpus = world
+    if args.launch_check:
+        if os.environ.get("BENCH_FAIL_RANK") == str(rank):
+            sys.exit(3)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"launch_check": world, "sum": int(t.item())}))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     # BENCH_BACKEND=gloo + BENCH_SHARE_GPU=1 rehearse the multi-rank code path on a one-GPU box
     backend = os.environ.get("BENCH_BACKEND", "nccl")
     if os.environ.get("BENCH_SHARE_GPU"):

@@ -4,6 +4,7 @@ if len(sys.argv) > 1:
     import torch, ctypes as C
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import basebandboard_amd as bbb
+    bbb._lib.select_build("experiments")   # the knobs below exist only in that build
     nbits = 10_000_000_000
     p = bbb.PRBS(31); det = bbb.PRBSErrorDetector(31)
     buf = torch.empty((nbits + 63)//64, dtype=torch.int64, device="cuda")

@@ -61,7 +61,10 @@ typedef struct bbb_lutopt bbb_lutopt;
 int bbb_lutopt_load_matrix_file(const char *path, int *k, uint16_t **taps, uint32_t **row_off);
 
 /* LUTOPT(a, init) / LUTOPT.from_packed(packed, init): gateware/bbb/rng.py:21-55.
- * k must be a power of two in [16, 512] (CLTGRNG needs it: rng.py:72-76); every row 1..8 taps.
+ * Any k in [2, 512] (LUTOPT puts no constraint on k; gateware/bbb/rng_recurrences.py:105 ships n192,
+ * rnghunt searches n = 192: rnghunt.rs:14); every row 1..8 taps.  Only the CLTGRNG entry points
+ * (bbb_awgn_fill_*, bbb_tx_fill_i16 with noise) need k to be a power of two (rng.py:72-76) and
+ * return BBB_EUNSUP otherwise.
  * init_words = ceil(k/64) words; the reference default is 1 (bit 0 set, rng.py:21).
  * device = -1 makes a host-only handle: bbb_lutopt_state_at works (pure GF(2) algebra), every
  * compute call on it returns BBB_ENODEV. */
@@ -83,6 +86,16 @@ int bbb_lutopt_profile_read(bbb_lutopt *h, double *seed_ms, double *kernel_ms, u
 /* LUTOPT.x after `nsteps` clocks from reset (rng.py:38-40), by GF(2) jump-ahead
  * (the x' = A x algebra of software/rnghunt/src/binary_matrix.rs:53-76). Host result. */
 int bbb_lutopt_state_at(bbb_lutopt *h, uint64_t nsteps, uint64_t *state_words);
+
+/* LUTOPT.x in bulk -- the uniform word stream itself (rng.py:29-40: "outputs x ... on each clock"; the
+ * reference dumps it for dieharder in software/rnghunt/util/verify.py:37-52, 200 000 states as 32-bit
+ * words).  State A^(first_step + i + 1) init, 0 <= i < nstates, as k/32 consecutive words:
+ *   dst_dev[i * (k/32) + j] = state bits 32j .. 32j+31,
+ *   msb_first = 0: bit 32j is the LSB (the HDL integer of rng.py:135, little-endian words);
+ *   msb_first = 1: bit 32j is the MSB (verify.py:46-52 prints x[0] x[1] ... and reads 32 characters as a
+ *                  binary number) -- the words of its `outnums` file in order.
+ * k must be a multiple of 32.  Asynchronous on the handle's stream. */
+int bbb_lutopt_fill_words(bbb_lutopt *h, uint32_t *dst_dev, uint64_t nstates, uint64_t first_step, int msb_first);
 
 /* The CLTGRNG sample stream (gateware/bbb/rng.py:70-108; tx.py:70-71):
  *   dst_dev[i] = trunc_signed_log2k( tree( A^(first_step + i + 1) * init ) ),  0 <= i < nsamples

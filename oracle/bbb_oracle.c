@@ -84,6 +84,43 @@ void bbo_lutopt_run(const bbo_lutopt *m, const uint64_t *init, uint64_t nsteps, 
     memcpy(xout, x, sizeof(uint64_t) * (size_t)words_for(m->k));
 }
 
+/* Bulk forms used by the fixtures that were produced by running the reference's own Python
+ * (tests/golden/ref_*): the states A^(first_step+1+i) init, i < nstates, as ceil(k/64) words each. */
+void bbo_lutopt_states(const bbo_lutopt *m, const uint64_t *init, uint64_t first_step, uint64_t nstates,
+                       uint64_t *out)
+{
+    uint64_t x[BBO_WORDS] = {0};
+    int nw = words_for(m->k);
+    bbo_lutopt_run(m, init, first_step, x);
+    for (uint64_t i = 0; i < nstates; i++) {
+        bbo_lutopt_step(m, x, x);
+        memcpy(out + i * (uint64_t)nw, x, sizeof(uint64_t) * (size_t)nw);
+    }
+}
+
+/* The uniform word stream LUTOPT.x as 32-bit words, k/32 per state (k a multiple of 32).
+ * msb_first = 0: word j = state bits 32j .. 32j+31, bit 32j the LSB (the HDL integer, rng.py:135).
+ * msb_first = 1: the dieharder dump of software/rnghunt/util/verify.py:46-52 -- the state printed as
+ * a string x[0] x[1] ... and cut into 32-character binary numbers, so bit 32j is the MSB of word j. */
+int bbo_lutopt_words_u32(const bbo_lutopt *m, const uint64_t *init, uint64_t first_step, uint64_t nstates,
+                         int msb_first, uint32_t *out)
+{
+    if (m->k % 32) return -1;
+    uint64_t x[BBO_WORDS] = {0};
+    int wps = m->k / 32;
+    bbo_lutopt_run(m, init, first_step, x);
+    for (uint64_t i = 0; i < nstates; i++) {
+        bbo_lutopt_step(m, x, x);
+        for (int j = 0; j < wps; j++) {
+            uint32_t w = 0;
+            for (int b = 0; b < 32; b++)
+                w |= (uint32_t)get_bit(x, 32 * j + b) << (msb_first ? 31 - b : b);
+            out[i * (uint64_t)wps + (uint64_t)j] = w;
+        }
+    }
+    return 0;
+}
+
 /* ---- CLT tree ---------------------------------------------------------------- */
 
 /* rng.py:96-105 / clt-grng-evaluate.py:10-15: level 0 is x[2j]-x[2j+1] over the state
@@ -95,6 +132,13 @@ int bbo_clt_tree(const uint64_t *x, int n)
     for (int width = n; width > 1; width /= 2)
         for (int j = 0; j < width / 2; j++) v[j] = v[2 * j] - v[2 * j + 1];
     return v[0];
+}
+
+/* The tree over many caller-supplied words (stride ceil(n/64) u64), un-truncated values. */
+void bbo_clt_tree_bulk(const uint64_t *x, int n, uint64_t nstates, int16_t *out)
+{
+    int nw = words_for(n);
+    for (uint64_t i = 0; i < nstates; i++) out[i] = (int16_t)bbo_clt_tree(x + i * (uint64_t)nw, n);
 }
 
 int bbo_clt_popcount(const uint64_t *x, int n)

@@ -5,10 +5,15 @@
  * check in __graft_entry__.py and the `cpu_baseline` leg of bench.py may load it.
  * The product (basebandboard_amd/, libbbb_hip.so) never links, imports or calls it.
  *
- * Parity status: PINNED for LUTOPT / CLT tree / PRBS by tests/golden/{lutopt_clt,prbs,gf2}.json,
- * which tools/make_golden.py derives from the models embedded in the reference's own
- * tests (rng.py:134-135, rng.py:173-181, prbs.py:112-113) and from literal known-answer
- * strings in the reference's Rust tests.  The PRBSErrorDetector FSM has no literal
+ * Parity status: PINNED.  LUTOPT states (every shipped matrix n16..n512, all state bits), the uniform
+ * word stream and the CLT tree are held to outputs of the reference's own Python RUN in the build
+ * container (tests/golden/ref_*, made by tools/make_golden_ref.py from
+ * software/rnghunt/util/binarymatrix.py recur(), util/verify.py, util/pack.py and
+ * software/clt-grng/clt-grng-evaluate.py executed unchanged).  In addition
+ * tests/golden/{lutopt_clt,prbs,gf2}.json, which tools/make_golden.py derives from the models
+ * embedded in the reference's HDL tests (rng.py:134-135, rng.py:173-181, prbs.py:112-113; those
+ * files need migen and cannot be imported) and from literal known-answer strings in the
+ * reference's Rust tests, pin PRBS and the same LUTOPT/CLT values a second way.  The PRBSErrorDetector FSM has no literal
  * trace anywhere in the reference (its only test uses unseeded random errors and
  * needs migen): it is pinned by re-running the reference's test *protocol*
  * (prbs.py:124-163) as a property.  BER counters / Eb-N0 mapping do not exist in the
@@ -64,6 +69,14 @@ void bbo_awgn_stream_i8(const bbo_lutopt *m, const uint64_t *init, uint64_t firs
  * popcount closed form); used as the timed CPU baseline.  Must equal bbo_awgn_stream_i8. */
 void bbo_awgn_stream_i8_fast256(const bbo_lutopt *m, const uint64_t *init, uint64_t first_step,
                                 uint64_t nsamples, int8_t *out);
+/* Bulk forms: states A^(first_step+1+i) init as ceil(k/64) words each; the same as 32-bit words
+ * (msb_first = 1: the dieharder dump format of software/rnghunt/util/verify.py:46-52); the tree over
+ * caller-supplied words. */
+void bbo_lutopt_states(const bbo_lutopt *m, const uint64_t *init, uint64_t first_step, uint64_t nstates,
+                       uint64_t *out);
+int bbo_lutopt_words_u32(const bbo_lutopt *m, const uint64_t *init, uint64_t first_step, uint64_t nstates,
+                         int msb_first, uint32_t *out);
+void bbo_clt_tree_bulk(const uint64_t *x, int n, uint64_t nstates, int16_t *out);
 /* Final state after `nsteps` steps from init. */
 void bbo_lutopt_run(const bbo_lutopt *m, const uint64_t *init, uint64_t nsteps, uint64_t *xout);
 

@@ -65,6 +65,11 @@ def _bind(l):
     l.bbo_lutopt_run.argtypes = [LP, u64p, C.c_uint64, u64p]
     l.bbo_lutopt_run.restype = None
     l.bbo_clt_tree.argtypes = [u64p, C.c_int]
+    l.bbo_lutopt_states.argtypes = [LP, u64p, C.c_uint64, C.c_uint64, u64p]
+    l.bbo_lutopt_states.restype = None
+    l.bbo_lutopt_words_u32.argtypes = [LP, u64p, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_uint32)]
+    l.bbo_clt_tree_bulk.argtypes = [u64p, C.c_int, C.c_uint64, C.POINTER(C.c_int16)]
+    l.bbo_clt_tree_bulk.restype = None
     l.bbo_clt_popcount.argtypes = [u64p, C.c_int]
     l.bbo_clt_wrap.argtypes = [C.c_int, C.c_int]
     for f in (l.bbo_awgn_stream_i8, l.bbo_awgn_stream_i8_fast256):
@@ -143,6 +148,28 @@ class Lutopt:
         b = np.zeros(WORDS, dtype=np.uint64)
         self._l.bbo_lutopt_run(C.byref(self._m), _u64(a), nsteps, _u64(b))
         return words_to_int(b, self.k)
+
+    def states(self, init, first_step, nstates):
+        """uint64[nstates, ceil(k/64)]: A^(first_step+1+i) init."""
+        nw = (self.k + 63) // 64
+        out = np.zeros((nstates, nw), dtype=np.uint64)
+        self._l.bbo_lutopt_states(C.byref(self._m), _u64(int_to_words(init, self.k)), first_step, nstates, _u64(out))
+        return out
+
+    def words_u32(self, init, first_step, nstates, msb_first=False):
+        """uint32[nstates * k/32]; msb_first = the dieharder dump of software/rnghunt/util/verify.py:46-52."""
+        out = np.zeros(nstates * (self.k // 32), dtype=np.uint32)
+        if self._l.bbo_lutopt_words_u32(C.byref(self._m), _u64(int_to_words(init, self.k)), first_step, nstates,
+                                        int(msb_first), out.ctypes.data_as(C.POINTER(C.c_uint32))):
+            raise ValueError("k must be a multiple of 32")
+        return out
+
+    def clt_tree_bulk(self, words):
+        """Un-truncated tree values (int16) of uint64[nstates, k/64] caller-supplied words."""
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        out = np.zeros(words.shape[0], dtype=np.int16)
+        self._l.bbo_clt_tree_bulk(_u64(words), self.k, words.shape[0], out.ctypes.data_as(C.POINTER(C.c_int16)))
+        return out
 
     def clt_tree(self, x):
         return self._l.bbo_clt_tree(_u64(int_to_words(x, self.k)), self.k)

@@ -115,7 +115,10 @@ def test_matrix_file_loader(tmp_path):
     with pytest.raises(_lib.BbbError):
         bbb.LUTOPT.from_matrix_file(tmp_path / "missing.txt", device=-1)
     with pytest.raises(ValueError):
-        bbb.LUTOPT.from_packed([[0, 1]] * 24, device=-1)
+        bbb.LUTOPT.from_packed([[0, 30]] * 24, device=-1)            # tap index out of range
+    with pytest.raises(ValueError):
+        bbb.LUTOPT.from_packed([[0, 0]] * 24, device=-1)             # duplicate tap in a row
+    assert bbb.LUTOPT.from_packed([[0, 1]] * 24, device=-1).k == 24   # LUTOPT itself accepts any k (rng.py:21-40)
 
 
 def test_shipped_matrices_have_lut_friendly_weights():

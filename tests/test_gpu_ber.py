@@ -111,7 +111,8 @@ def test_trial_errors(gpu):
 def test_two_scan_form_of_the_grouped_kernel(oracle):
     """The grouped kernel has two forms: one scan per setting on X = bit ? ~T : T (taken whenever the two
     thresholds mirror each other, i.e. for every non-wrapping channel) and the plain two-scan form, which
-    BBB_BER_NO_FAST=1 forces.  Same counters, in a child process because the switch is read once."""
+    BBB_BER_NO_FAST=1 forces in the experiments build of the library (libbbb_hip_exp.so, -DBBB_EXPERIMENTS; the
+    product build ignores the environment).  Same counters, in child processes because the switch is read once."""
     import json
     import os
     import subprocess
@@ -119,6 +120,7 @@ def test_two_scan_form_of_the_grouped_kernel(oracle):
     from conftest import ROOT
     code = (
         "import json, basebandboard_amd as g\n"
+        "g._lib.select_build('experiments')\n"
         "u = g.LUTOPT.shipped(256)\n"
         "ts = [g.Trial(nbits=300_001, amp=a, noise_var=nv, prbs_k=k, warmup=16) for a, nv, k in"
         " [(100, 8, 31), (91, 8, 31), (37, 3, 31), (250, 15, 31), (64, 8, 31), (1, 1, 31), (77, 7, 31)]]\n"
