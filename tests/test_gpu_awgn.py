@@ -145,8 +145,11 @@ def test_lutopt_from_matrix_and_errors(gpu):
     a = gpu.LUTOPT.shipped(16).a
     u = gpu.LUTOPT(a, init=1)
     assert u.packed == gpu.recurrences.n16
+    v = gpu.LUTOPT.from_packed([[0]] * 24)          # LUTOPT takes any k (rng.py:21-40) ...
     with pytest.raises(ValueError):
-        gpu.LUTOPT.from_packed([[0]] * 24)          # k not a power of two
+        gpu.CLTGRNG(v)                              # ... CLTGRNG a power of two (rng.py:72-76)
+    with pytest.raises(ValueError):
+        gpu.LUTOPT.from_packed([[0]] * 600)         # beyond the 512 this library is built for
     with pytest.raises(ValueError):
         gpu.LUTOPT.from_packed([[99]] * 16)         # tap out of range
     with pytest.raises(ValueError):

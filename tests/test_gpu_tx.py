@@ -31,7 +31,10 @@ def test_shaper_golden_sets(gpu, golden_shaper, name):
 
 
 @pytest.mark.parametrize("k,setsel,n,first", [(31, 0, 1, 0), (31, 5, 7, 0), (9, 31, 8, 11), (7, 16, 100_003, 0),
-                                              (20, 3, 400_000, 123_457), (23, 20, 1_000_001, 10**12 + 3), (15, 8, 64, 17)])
+                                              (20, 3, 400_000, 123_457), (23, 20, 1_000_001, 10**12 + 3), (15, 8, 64, 17),
+                                              # windows that need NO data bit yet (the bit buffer is empty) or end inside the
+                                              # first bits: the kernel must not read past the bits it was given
+                                              (31, 10, 17, 0), (31, 10, 8, 8), (31, 10, 16, 1), (9, 4, 33, 0), (7, 2, 25, 16)])
 def test_shaper_matches_oracle(gpu, oracle, golden_shaper, k, setsel, n, first):
     sh = gpu.PRBSShaper.from_rcf(gpu.PRBS(k), setsel, golden_shaper["betas"])
     got = sh.generate(n, first_sample=first).cpu().numpy()
@@ -60,6 +63,16 @@ def test_tx_matches_oracle(gpu, oracle, golden_shaper, bit_en, noise_en, nv, src
     m = oracle.Lutopt(path=oracle.data_path(256))
     exp = oracle.tx(m, 1, golden_shaper["rcf_coeffs"][16], 31, n, first_sample=first, source=src, bit_en=bit_en,
                     noise_en=noise_en, noise_var=nv, warmup=16)
+    assert np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("n,first", [(17, 0), (8, 8), (16, 1), (40, 0), (26, 3)])
+def test_tx_short_windows_at_the_start(gpu, oracle, golden_shaper, n, first):
+    """The first call on a fresh handle with a window before / around the first data bit."""
+    tx = gpu.TX(31, 1, 0, 16, 1, 8)
+    got = tx.generate(n, first_sample=first).cpu().numpy()
+    m = oracle.Lutopt(path=oracle.data_path(256))
+    exp = oracle.tx(m, 1, golden_shaper["rcf_coeffs"][16], 31, n, first_sample=first, noise_var=8, warmup=16)
     assert np.array_equal(got, exp)
 
 
