@@ -9,6 +9,7 @@ import pathlib
 _HERE = pathlib.Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libbbb_hip.so"
 
+SHARD_TRIALS, SHARD_SEEDS, SHARD_BITS = 0, 1, 2
 BBB_OK, BBB_EINVAL, BBB_ENOMEM, BBB_EHIP, BBB_EIO, BBB_ENODEV, BBB_EUNSUP = 0, -1, -2, -3, -4, -5, -6
 
 # every symbol include/bbb.h declares (tests/test_abi.py checks the list against the header)
@@ -17,7 +18,7 @@ SYMBOLS = [
     "bbb_lutopt_load_matrix_file", "bbb_lutopt_create", "bbb_lutopt_destroy", "bbb_lutopt_set_stream",
     "bbb_lutopt_is_specialised", "bbb_lutopt_set_custom_fill", "bbb_lutopt_profile", "bbb_lutopt_profile_read", "bbb_lutopt_state_at", "bbb_lutopt_fill_words", "bbb_awgn_fill_i8", "bbb_awgn_fill_i16", "bbb_awgn_prefetch",
     "bbb_clt_tree_i16", "bbb_prbs_fill", "bbb_prbs_check", "bbb_prbs_check_dev", "bbb_prbs_state_at",
-    "bbb_prbs_detector_run", "bbb_prbs_detector_stream", "bbb_ber_trials", "bbb_ber_trials_dev", "bbb_shaper_fill_i16", "bbb_tx_fill_i16", "bbb_rx_slice", "bbb_rx_phase_search", "bbb_gf2_berlekamp_massey", "bbb_gf2_recur",
+    "bbb_prbs_detector_run", "bbb_prbs_detector_stream", "bbb_ber_trials", "bbb_ber_trials_dev", "bbb_ber_sweep_multi", "bbb_sweep_shard", "bbb_multi_release", "bbb_shaper_fill_i16", "bbb_tx_fill_i16", "bbb_rx_slice", "bbb_rx_phase_search", "bbb_gf2_berlekamp_massey", "bbb_gf2_recur",
     "bbb_gf2_dot", "bbb_gf2_poly_is_primitive", "bbb_gf2_poly_modexp", "bbb_lutopt_charpoly", "bbb_lutopt_is_full_period",
     "bbb_lutopt_save_matrix_file", "bbb_lutopt_search_candidate", "bbb_lutopt_search",
 ]
@@ -115,6 +116,9 @@ def lib():
     l.bbb_prbs_detector_stream.argtypes = [i32, vp, u64, vp, vp, C.POINTER(DetectorStats), u64, u64, i32, vp]
     l.bbb_ber_trials.argtypes = [vp, C.POINTER(TrialCfg), i32, C.POINTER(Ber)]
     l.bbb_ber_trials_dev.argtypes = [vp, C.POINTER(TrialCfg), i32, vp]
+    l.bbb_ber_sweep_multi.argtypes = [C.POINTER(vp), i32, C.POINTER(TrialCfg), i32, i32, C.POINTER(Ber)]
+    l.bbb_sweep_shard.argtypes = [C.POINTER(TrialCfg), i32, i32, i32, i32, C.POINTER(TrialCfg)]
+    l.bbb_multi_release.argtypes = []
     l.bbb_shaper_fill_i16.argtypes = [C.POINTER(TxCfg), vp, u64, u64, i32, vp]
     l.bbb_tx_fill_i16.argtypes = [vp, C.POINTER(TxCfg), vp, u64, u64]
     l.bbb_rx_slice.argtypes = [vp, u64, u64, u64, i32, vp, u64p, i32, vp]

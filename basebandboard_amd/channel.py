@@ -74,6 +74,34 @@ def run_trials_into(urng, trials, counters):
     return counters
 
 
+# ---- sharding a sweep over the GPUs of this process: the C ABI's own collective ----------------
+
+def shard_trials(trials, rank, world, mode=_lib.SHARD_TRIALS):
+    """What rank `rank` of `world` runs of `trials` under a sharding mode (bbb_sweep_shard; host arithmetic, no
+    GPU needed): a list as long as `trials`, entries with nbits = 0 are not run by that rank."""
+    n = len(trials)
+    cfgs = (_lib.TrialCfg * max(n, 1))(*[t.as_c() for t in trials])
+    mine = (_lib.TrialCfg * max(n, 1))()
+    _lib.check(_lib.lib().bbb_sweep_shard(cfgs, n, world, rank, mode, mine), "bbb_sweep_shard")
+    return [Trial(nbits=m.nbits, amp=m.amp, noise_var=m.noise_var, prbs_k=m.prbs_k, prbs_state=m.prbs_state,
+                  warmup=m.warmup, first_bit=m.first_bit) for m in mine[:n]]
+
+
+def sweep_multi(urngs, trials, mode=_lib.SHARD_BITS):
+    """One process, several GPUs: `urngs[r]` is a LUTOPT on device r.  bbb_ber_sweep_multi runs every device's
+    share on its own host thread and sums the counters with ONE RCCL all-reduce (uint64, sum).  Returns a list
+    of (bits, errors)."""
+    if not trials:
+        return []
+    cfgs = (_lib.TrialCfg * len(trials))(*[t.as_c() for t in trials])
+    out = (_lib.Ber * len(trials))()
+    hs = (C.c_void_p * len(urngs))(*[u._h for u in urngs])
+    for u in urngs:
+        u._bind_stream()
+    _lib.check(_lib.lib().bbb_ber_sweep_multi(hs, len(urngs), cfgs, len(trials), mode, out), "bbb_ber_sweep_multi")
+    return [(o.bits, o.errors) for o in out]
+
+
 # ---- sharding a sweep over ranks (one process per GPU) -----------------------------------------
 
 def shard(ntrials, rank, world):
@@ -96,6 +124,23 @@ def sweep(trials, runner, rank=0, world=1, group=None):
     total = torch.zeros((len(trials), 2), dtype=torch.int64, device=local.device)
     if mine:
         total[torch.tensor(mine, device=local.device)] = local
+    if world > 1:
+        if dist.get_backend(group) == "gloo" and total.is_cuda:      # CPU rehearsal of a GPU sweep
+            host = total.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            total.copy_(host)
+        else:
+            dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+    return total
+
+
+def sweep_bits(trials, runner, rank=0, world=1, group=None):
+    """Third form (BBB_SHARD_BITS): every rank runs all `trials` over ITS slice of each trial's bit range, same
+    reset state everywhere, ONE all-reduce.  The totals equal the single-rank counters of `trials` exactly, and
+    an Eb/N0 sweep keeps its one-pass-per-noise-stream grouping on every rank."""
+    import torch.distributed as dist
+    mine = shard_trials(trials, rank, world, _lib.SHARD_BITS)
+    total = runner(mine, len(mine)).clone()
     if world > 1:
         if dist.get_backend(group) == "gloo" and total.is_cuda:      # CPU rehearsal of a GPU sweep
             host = total.cpu()

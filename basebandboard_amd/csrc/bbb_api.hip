@@ -3,12 +3,15 @@
 #include "bbb_common.hpp"
 #include "awgn_launch.hpp"
 #include "gf2.hpp"
+#include "rccl_loader.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -883,6 +886,152 @@ int bbb_ber_trials(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, bbb_ber *
     for (int i = 0; i < ncfg; i++) {
         out[i].bits = host[2 * (size_t)i];
         out[i].errors = host[2 * (size_t)i + 1];
+    }
+    return BBB_OK;
+}
+
+/* ---- the path's one collective: a sweep sharded over the GPUs of this process ------------------------- */
+
+int bbb_sweep_shard(const bbb_trial_cfg *cfgs, int ncfg, int ndev, int rank, int mode, bbb_trial_cfg *mine) {
+    if (ncfg < 0 || (ncfg && (!cfgs || !mine)) || ndev < 1 || rank < 0 || rank >= ndev)
+        return fail(BBB_EINVAL, "bad shard arguments");
+    for (int i = 0; i < ncfg; i++) {
+        bbb_trial_cfg c = cfgs[i];
+        switch (mode) {
+        case BBB_SHARD_TRIALS:                        // trial i belongs to rank i % ndev
+            if (i % ndev != rank) c.nbits = 0;
+            break;
+        case BBB_SHARD_SEEDS:                         // every rank runs every trial (on its own reset state)
+            break;
+        case BBB_SHARD_BITS: {                        // rank r takes bits [r*nbits/ndev, (r+1)*nbits/ndev) of every trial
+            const unsigned __int128 nb = cfgs[i].nbits;
+            const uint64_t lo = (uint64_t)(nb * (unsigned)rank / (unsigned)ndev);
+            const uint64_t hi = (uint64_t)(nb * (unsigned)(rank + 1) / (unsigned)ndev);
+            if (c.first_bit + lo < c.first_bit) return fail(BBB_EINVAL, "first_bit + nbits overflows");
+            c.first_bit += lo;
+            c.nbits = hi - lo;
+            break;
+        }
+        default:
+            return fail(BBB_EINVAL, "mode must be BBB_SHARD_TRIALS, BBB_SHARD_SEEDS or BBB_SHARD_BITS");
+        }
+        mine[i] = c;
+    }
+    return BBB_OK;
+}
+
+namespace {
+
+// communicators of this process, one set per ordered device list (creation costs far more than a sweep)
+struct CommSet { std::vector<int> devs; std::vector<ncclComm_t> comms; };
+std::mutex g_comm_mu;
+std::vector<CommSet> g_comm_sets;
+
+int get_comms(const std::vector<int> &devs, std::vector<ncclComm_t> *out) {
+    const Rccl &r = rccl();
+    if (!r.ok) return fail(BBB_EUNSUP, r.error);
+    std::lock_guard<std::mutex> g(g_comm_mu);
+    for (const CommSet &c : g_comm_sets)
+        if (c.devs == devs) { *out = c.comms; return BBB_OK; }
+    CommSet c;
+    c.devs = devs;
+    c.comms.resize(devs.size());
+    const ncclResult_t e = r.CommInitAll(c.comms.data(), (int)devs.size(), devs.data());
+    if (e != ncclSuccess) return fail(BBB_EHIP, std::string("ncclCommInitAll: ") + r.GetErrorString(e));
+    g_comm_sets.push_back(c);
+    *out = c.comms;
+    return BBB_OK;
+}
+
+}  // namespace
+
+int bbb_multi_release(void) {
+    std::lock_guard<std::mutex> g(g_comm_mu);
+    const Rccl &r = rccl();
+    for (CommSet &c : g_comm_sets)
+        for (ncclComm_t comm : c.comms)
+            if (r.ok && comm) (void)r.CommDestroy(comm);
+    g_comm_sets.clear();
+    return BBB_OK;
+}
+
+int bbb_ber_sweep_multi(bbb_lutopt *const *handles, int ndev, const bbb_trial_cfg *cfgs, int ncfg, int mode, bbb_ber *out) {
+    if (!handles || ndev < 1 || ncfg < 0 || (ncfg && (!cfgs || !out))) return fail(BBB_EINVAL, "null argument");
+    if (ncfg == 0) return BBB_OK;
+    std::vector<int> devs((size_t)ndev);
+    for (int r = 0; r < ndev; r++) {
+        if (!handles[r]) return fail(BBB_EINVAL, "null handle");
+        if (handles[r]->device < 0) return fail(BBB_ENODEV, "host-only handle (device -1) cannot run trials");
+        devs[(size_t)r] = handles[r]->device;
+        for (int q = 0; q < r; q++)
+            if (devs[(size_t)q] == devs[(size_t)r]) return fail(BBB_EINVAL, "every handle must live on its own device");
+    }
+    {   // argument errors are found before any device is touched (and before a rank could miss the collective)
+        std::vector<bbb_trial_cfg> probe((size_t)ncfg);
+        const int e = bbb_sweep_shard(cfgs, ncfg, ndev, 0, mode, probe.data());
+        if (e) return e;
+    }
+    std::vector<ncclComm_t> comms;
+    int rc = get_comms(devs, &comms);
+    if (rc) return rc;
+    const Rccl &nccl = rccl();
+    const size_t nwords = 2 * (size_t)ncfg;
+    std::vector<int> rcs((size_t)ndev, BBB_OK);
+    std::vector<std::string> errs((size_t)ndev);
+    std::vector<std::vector<unsigned long long>> host((size_t)ndev, std::vector<unsigned long long>(nwords));
+    // one host thread per device launches that device's share of the trials
+    auto work = [&](int r) {
+        bbb_lutopt *h = handles[r];
+        auto body = [&]() -> int {
+            BBB_HIP(hipSetDevice(h->device));
+            std::vector<bbb_trial_cfg> mine((size_t)ncfg);
+            int e = bbb_sweep_shard(cfgs, ncfg, ndev, r, mode, mine.data());
+            if (e) return e;
+            if (h->counters_cap < nwords) {
+                if (h->d_counters) BBB_HIP(hipFree(h->d_counters));
+                h->d_counters = nullptr;
+                h->counters_cap = 0;
+                BBB_HIP(hipMalloc((void **)&h->d_counters, nwords * sizeof(unsigned long long)));
+                h->counters_cap = nwords;
+            }
+            BBB_HIP(hipMemsetAsync(h->d_counters, 0, nwords * sizeof(unsigned long long), h->stream));
+            return ber_run(h, mine.data(), ncfg, h->d_counters);
+        };
+        rcs[(size_t)r] = body();
+        if (rcs[(size_t)r]) errs[(size_t)r] = last_error();
+    };
+    {
+        std::vector<std::thread> th;
+        for (int r = 1; r < ndev; r++) th.emplace_back(work, r);
+        work(0);
+        for (auto &t : th) t.join();
+    }
+    for (int r = 0; r < ndev; r++)
+        if (rcs[(size_t)r]) return fail(rcs[(size_t)r], "device " + std::to_string(devs[(size_t)r]) + ": " + errs[(size_t)r]);
+    // The ONE collective of the path: all-reduce (sum) of the uint64 {bits, errors} counters over xGMI, queued on
+    // each device's stream behind its trials.  Every rank must enter it, so it is issued only after all shares
+    // were launched without error; one group call from this thread (the single-process multi-device form).
+    ncclResult_t e = nccl.GroupStart();
+    for (int r = 0; r < ndev && e == ncclSuccess; r++)
+        e = nccl.AllReduce(handles[r]->d_counters, handles[r]->d_counters, nwords, ncclUint64, ncclSum, comms[(size_t)r],
+                           handles[r]->stream);
+    const ncclResult_t e2 = nccl.GroupEnd();
+    if (e == ncclSuccess) e = e2;
+    if (e != ncclSuccess) return fail(BBB_EHIP, std::string("ncclAllReduce: ") + nccl.GetErrorString(e));
+    for (int r = 0; r < ndev; r++) {
+        BBB_HIP(hipSetDevice(handles[r]->device));
+        BBB_HIP(hipMemcpyAsync(host[(size_t)r].data(), handles[r]->d_counters, nwords * sizeof(unsigned long long),
+                               hipMemcpyDeviceToHost, handles[r]->stream));
+    }
+    for (int r = 0; r < ndev; r++) {
+        BBB_HIP(hipSetDevice(handles[r]->device));
+        BBB_HIP(hipStreamSynchronize(handles[r]->stream));
+    }
+    for (int r = 1; r < ndev; r++)
+        if (host[(size_t)r] != host[0]) return fail(BBB_EHIP, "ranks disagree after the all-reduce");
+    for (int i = 0; i < ncfg; i++) {
+        out[i].bits = host[0][2 * (size_t)i];
+        out[i].errors = host[0][2 * (size_t)i + 1];
     }
     return BBB_OK;
 }

@@ -208,6 +208,31 @@ int bbb_ber_trials(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, bbb_ber *
  * synchronising -- the buffer a multi-GPU host hands to one RCCL all-reduce (ncclUint64, sum). */
 int bbb_ber_trials_dev(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, uint64_t *counters_dev);
 
+/* The sweep sharded over the GPUs of ONE process (BASELINE.json configs[4]).  The
+ * reference's only multi-worker program has this shape -- workers plus one channel back,
+ * software/rnghunt/src/bin/rnghunt.rs:16-18,54-65 -- and no collective of its own; here the channel back is the
+ * path's single collective.  handles[r] is a generator created on device r's GPU (all on distinct devices, same
+ * matrix).  One host thread per device runs that device's share of the trials, then ONE
+ * ncclAllReduce(ncclUint64, ncclSum) of the uint64[2 * ncfg] {bits, errors} counters over xGMI (RCCL,
+ * ncclCommInitAll over the handles' devices; the communicators are cached per device list) leaves the totals on
+ * every device; out[i] (host) receives them.  Integer sums: the result does not depend on ndev or on the order
+ * of the reduction.  mode selects the share of rank r (bbb_sweep_shard computes it, host only):
+ *   BBB_SHARD_TRIALS  trial i runs on rank i % ndev (independent trials, round robin);
+ *   BBB_SHARD_SEEDS   every rank runs EVERY trial on its own handle -- give the handles different reset states
+ *                     (seeds): the points x seeds form, N times the bits per point in the time of one sweep;
+ *   BBB_SHARD_BITS    every rank runs every trial over ITS slice of the trial's bit range
+ *                     [first_bit + r nbits / ndev, first_bit + (r+1) nbits / ndev) -- same reset state on all
+ *                     handles; the totals equal the single-device counters of the same trials exactly. */
+#define BBB_SHARD_TRIALS 0
+#define BBB_SHARD_SEEDS 1
+#define BBB_SHARD_BITS 2
+int bbb_ber_sweep_multi(bbb_lutopt *const *handles, int ndev, const bbb_trial_cfg *cfgs, int ncfg, int mode,
+                        bbb_ber *out);
+/* The share of `rank` among `ndev`: mine[i] is trial i as that rank runs it (nbits = 0: not at all). */
+int bbb_sweep_shard(const bbb_trial_cfg *cfgs, int ncfg, int ndev, int rank, int mode, bbb_trial_cfg *mine);
+/* Destroy the cached RCCL communicators (optional; before unloading the library or resetting devices). */
+int bbb_multi_release(void);
+
 /* ---- pulse shaper and transmitter output (8 samples per data bit) -------------------------- */
 
 /* PRBSShaper (gateware/bbb/bitshaper.py:12-86) and TX (gateware/bbb/tx.py:33-81).

@@ -162,3 +162,77 @@ def test_cpp_caller_of_the_c_abi(gpu, oracle):
     amp = int(row[1])
     e = [m.ber_trial(s, 15, 1, amp, 7, 16, 0, 100_000) for s in (0xa5, 0xa6)]
     assert (int(row[2]), int(row[3])) == (e[0][0] + e[1][0], e[0][1] + e[1][1])
+
+
+def test_sweep_multi_on_one_device_equals_ber_trials(gpu):
+    """bbb_ber_sweep_multi (host thread per device, ncclCommInitAll, ONE ncclAllReduce of uint64 counters) with
+    ndev = 1: RCCL is loaded and the collective runs; all three sharding modes return bbb_ber_trials' counters
+    bit for bit."""
+    from basebandboard_amd import _lib
+    from basebandboard_amd.channel import sweep_multi
+    u = gpu.LUTOPT.shipped(256)
+    trials = [gpu.Trial(nbits=2_000_003, amp=gpu.channel.amp_for_ebn0(db, 8), noise_var=8) for db in range(0, 11, 2)]
+    trials += [gpu.Trial(nbits=77_777, amp=40, noise_var=5, prbs_k=9, first_bit=123)]
+    want = gpu.run_trials(u, trials)
+    assert all(b == t.nbits for (b, _), t in zip(want, trials)) and want[0][1] > 0
+    for mode in (_lib.SHARD_TRIALS, _lib.SHARD_SEEDS, _lib.SHARD_BITS):
+        assert sweep_multi([u], trials, mode) == want
+    assert sweep_multi([u], trials) == want                  # cached communicator, second use
+    with pytest.raises(ValueError):
+        sweep_multi([u, u], trials)                          # two handles on one device
+    assert _lib.lib().bbb_multi_release() == 0
+    assert sweep_multi([u], trials) == want                  # communicators are rebuilt on demand
+
+
+@pytest.mark.parametrize("world", (2, 8))
+def test_bit_sliced_shares_sum_to_the_whole_on_the_gpu(gpu, world):
+    """The shares bbb_ber_sweep_multi hands to `world` devices (bbb_sweep_shard, BBB_SHARD_BITS), run one after
+    the other on this GPU, add up to the undivided trials' counters exactly."""
+    from basebandboard_amd import _lib
+    from basebandboard_amd.channel import shard_trials
+    u = gpu.LUTOPT.shipped(256)
+    trials = [gpu.Trial(nbits=3_000_001, amp=gpu.channel.amp_for_ebn0(db, 8), noise_var=8) for db in (0, 3, 6)]
+    want = gpu.run_trials(u, trials)
+    tot = [[0, 0] for _ in trials]
+    for r in range(world):
+        for i, (b, e) in enumerate(gpu.run_trials(u, shard_trials(trials, r, world, _lib.SHARD_BITS))):
+            tot[i][0] += b
+            tot[i][1] += e
+    assert [tuple(t) for t in tot] == want
+
+
+def test_cli_json_multi_and_awgn_modes(gpu, oracle):
+    """examples/bbb_mc: --ebn0 A:B:STEP with --json, the bbb_ber_sweep_multi route (--multi 1: host thread per
+    device + RCCL all-reduce, here over one device) and the AWGN fill mode -- counters and samples equal the oracle's."""
+    import json
+    import subprocess
+    from conftest import ROOT
+    exe = ROOT / "examples" / "bbb_mc"
+    subprocess.check_call(["make", "-C", str(ROOT / "examples")], stdout=subprocess.DEVNULL)
+    m = oracle.Lutopt(path=oracle.data_path(256))
+    outs = []
+    for extra in ([], ["--multi", "1"], ["--multi", "1", "--shard", "trials"]):
+        r = subprocess.run([str(exe), "--bits", "300000", "--ebn0", "1:7:3", "--prbs", "31", "--nv", "8", "--json", "1",
+                            "--loopback", "5000000"] + extra, cwd=str(ROOT), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+        pts = [l for l in lines if "ebn0_db" in l]
+        assert len(pts) == 3
+        for p in pts:
+            assert (p["bits"], p["errors"]) == m.ber_trial(1, 31, 1, p["amp"], 8, 16, 0, 300_000)
+            assert p["ebn0_db_effective"] <= p["ebn0_db"] + 0.7
+        summ = [l for l in lines if l.get("mode") == "ber_sweep"][0]
+        assert summ["total_bits"] == 900_000 and summ["gbit_trials_s"] > 0
+        assert ("ncclAllReduce" in summ["reduce"]) == bool(extra)
+        lb = [l for l in lines if l.get("mode") == "prbs_loopback"][0]
+        assert lb["check_errors"] == 0 and lb["detector_errors"] == 0 and lb["bits"] == 5_000_000
+        outs.append(pts)
+    assert outs[0] == outs[1] == outs[2]
+    r = subprocess.run([str(exe), "--nsamples", "3000000", "--steps", "2", "--json", "1"], cwd=str(ROOT), capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    a = json.loads(r.stdout.strip().splitlines()[-1])
+    assert a["mode"] == "awgn_fill" and a["gsample_s"] > 0 and 0 < a["hbm_roofline_frac"] < 1
+    assert a["head"] == m.awgn(1, 16, 64, fast=True).tolist()
+    r = subprocess.run([str(exe), "--gpus", "64"], cwd=str(ROOT), capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "visible" in r.stderr

@@ -119,3 +119,67 @@ def test_two_rank_seed_sharded_sweep_sums_the_seeds():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert got[0] == got[1] == expect
+
+
+def _worker_bits(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from basebandboard_amd.channel import sweep_bits
+    total = sweep_bits(_trials(), _oracle_runner(), rank=rank, world=world)
+    q.put((rank, total.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_bit_sliced_sweep_equals_single_rank():
+    """BBB_SHARD_BITS: every rank runs all trials over its slice of each trial's bit range (bbb_sweep_shard, the
+    same arithmetic bbb_ber_sweep_multi uses); the reduced counters ARE the single-rank counters."""
+    from basebandboard_amd.channel import sweep_bits
+    single = sweep_bits(_trials(), _oracle_runner(), rank=0, world=1).tolist()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_bits, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0] == got[1] == single
+
+
+def test_c_abi_shard_arithmetic():
+    """bbb_sweep_shard (host only): the shares of the three modes are what include/bbb.h says, for ragged sizes."""
+    from basebandboard_amd import Trial, shard
+    from basebandboard_amd import _lib
+    from basebandboard_amd.channel import shard_trials
+    trials = [Trial(nbits=nb, amp=50 + i, noise_var=8, first_bit=fb)
+              for i, (nb, fb) in enumerate([(10**9 + 7, 0), (3, 5), (0, 9), (1, 0), (8, 10**15), (12345, 77), (2**40 + 1, 2**40)])]
+    for world in (1, 2, 3, 8):
+        shares = {m: [shard_trials(trials, r, world, m) for r in range(world)]
+                  for m in (_lib.SHARD_TRIALS, _lib.SHARD_SEEDS, _lib.SHARD_BITS)}
+        for r in range(world):
+            # round robin = the Python `shard` used by the process-per-GPU sweep
+            mine = [i for i, t in enumerate(shares[_lib.SHARD_TRIALS][r]) if t.nbits]
+            assert mine == [i for i in shard(len(trials), r, world) if trials[i].nbits]
+            for a, b in zip(shares[_lib.SHARD_SEEDS][r], trials):
+                assert (a.nbits, a.first_bit, a.amp) == (b.nbits, b.first_bit, b.amp)
+        for i, t in enumerate(trials):
+            assert sum(shares[_lib.SHARD_TRIALS][r][i].nbits for r in range(world)) == t.nbits
+            # bit slices: contiguous, in rank order, covering the trial exactly, sizes within one bit of each other
+            pos = t.first_bit
+            sizes = []
+            for r in range(world):
+                s = shares[_lib.SHARD_BITS][r][i]
+                assert s.first_bit == pos and (s.amp, s.noise_var, s.prbs_state, s.warmup) == (t.amp, t.noise_var, t.prbs_state, t.warmup)
+                pos += s.nbits
+                sizes.append(s.nbits)
+            assert pos == t.first_bit + t.nbits and max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_trials(trials, 2, 2)
+    with pytest.raises(ValueError):
+        shard_trials(trials, 0, 1, 7)
