@@ -319,6 +319,191 @@ prbs_stream_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwords,
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The checker, regions read from their END to their start.  Why: the generator's waves write their
+// regions in ascending order, so when a fill ends the 256 MiB memory-side cache holds the TAIL of
+// every region as dirty lines.  A checker that starts at the heads misses on every line, and each miss
+// evicts one of those dirty lines -- 0.25 GB of write-backs on top of the 1.25 GB it reads (measured:
+// 3.7-3.9 TB/s instead of 5.5).  Started at the tails, the first 256 MiB are hits on exactly those
+// lines and the write-backs replace reads instead of adding to them.  The count of mismatches does not
+// depend on the order.
+// The row recurrence runs backwards as well: row[p] = row[p+K] ^ row[p+K-TAP]; the window starts as
+// the K rows that FOLLOW the region and retreats K rows per pass (same in-place update, descending).
+// 8-byte lanes, register window.
+// ---------------------------------------------------------------------------------------------
+template <int K>
+__global__ void __launch_bounds__(64, 2)
+prbs_check_rev_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwords, u64 rows_per_wave,
+                      const u64 *__restrict buf, u64 *__restrict nerr) {
+    constexpr int TAP = tap_of(K);
+    constexpr int RW = 64;
+    constexpr int LEVELS = 6;
+    constexpr uint32_t SMASK = (uint32_t)((1ull << K) - 1ull);
+    __shared__ __attribute__((aligned(16))) u64 X[K * RW];
+    const int lane = threadIdx.x;
+    const u64 row0 = (u64)blockIdx.x * rows_per_wave;
+    const u64 word0 = row0 * RW;
+    if (word0 >= nwords) return;
+    const PrbsPowTable &pw = d_prbs_pow[ki];
+    const u64 rows_total = (nwords - word0 + RW - 1) / RW;
+    const long long nrows = (long long)(rows_total < rows_per_wave ? rows_total : rows_per_wave);
+
+    // 1. LFSR state at the first bit of the K rows that FOLLOW this region
+    constexpr u64 PERIOD = (1ull << K) - 1ull;
+    const u64 wtop = word0 + (u64)nrows * RW;
+    const u64 t0 = (first_bit % PERIOD) + ((wtop % PERIOD) * 64) % PERIOD;
+    uint32_t s = (uint32_t)init_state;
+#pragma unroll 1
+    for (int i0 = 0; i0 < 64; i0 += 16) {
+        if (((t0 >> i0) & 0xffffull) == 0) continue;
+        uint32_t myrow[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) myrow[i] = pw.rows[i0 + i][lane & 31];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            if ((t0 >> (i0 + i)) & 1) s = (uint32_t)__ballot(lane < K && (__builtin_popcount(myrow[i] & s) & 1));
+        }
+    }
+    // 2. lane i < K forms word i of the window, 3. the prefix grows K -> K*RW words (as in the ascending kernel)
+    if (lane < K) {
+        uint32_t si = s;
+#pragma unroll
+        for (int m = 0; m < 5; m++) {
+            const uint32_t sj = lfsr_matvec<K>(pw.rows[6 + m], si);
+            si = ((lane >> m) & 1) ? sj : si;
+        }
+        u64 w = 0;
+        for (int j = 0; j < 64; j++) {
+            const uint32_t bit = ((si >> (K - 1)) ^ (si >> (TAP - 1))) & 1u;
+            si = ((si << 1) | bit) & SMASK;
+            w |= (u64)bit << j;
+        }
+        X[lane] = w;
+    }
+    __syncthreads();
+    {
+        int known = K;
+#pragma unroll 1
+        for (int j = 0; j < LEVELS; j++) {
+            const int lagk = K << j, lagt = TAP << j, target = K << (j + 1);
+            while (known < target) {
+                const int cnt = min(lagt, target - known);
+                for (int base = 0; base < cnt; base += 64) {
+                    const int o = base + lane;
+                    if (o < cnt) X[known + o] = X[known + o - lagk] ^ X[known + o - lagt];
+                }
+                known += cnt;
+                __syncthreads();
+            }
+        }
+    }
+    u32x2 *Xv = reinterpret_cast<u32x2 *>(X);
+    u32x2 V[K];
+#pragma unroll
+    for (int q = 0; q < K; q++) V[q] = Xv[q * 64 + lane];
+
+    const u64 last_word = nwords - 1;
+    const u64 last_mask = (nbits & 63) ? ((1ull << (nbits & 63)) - 1ull) : ~0ull;
+    u64 errs = 0;
+    constexpr int DB = 16;
+    constexpr int NB = (K + DB - 1) / DB;
+    for (long long q0 = nrows - K; q0 > -(long long)K; q0 -= K) {       // the pass covers rows [q0, q0 + K)
+        // retreat the window: V[i] = row q0 + i
+#pragma unroll
+        for (int i = K - 1; i >= 0; i--) xor_inplace(V[i], V[(i - TAP + K) % K]);
+        if (q0 >= 0 && word0 + (u64)(q0 + K) * RW <= last_word) {
+            const u64 *rowp = buf + (word0 + (u64)q0 * RW);
+            u32x2 D[2][DB];
+#pragma unroll
+            for (int i = 0; i < DB && i < K; i++) D[0][i] = reinterpret_cast<const u32x2 *>(rowp + (u64)i * RW)[lane];
+            uint32_t e32 = 0;
+#pragma unroll
+            for (int bidx = 0; bidx < NB; bidx++) {
+                if (bidx + 1 < NB) {
+#pragma unroll
+                    for (int i = 0; i < DB; i++)
+                        if ((bidx + 1) * DB + i < K)
+                            D[(bidx + 1) & 1][i] = reinterpret_cast<const u32x2 *>(rowp + (u64)((bidx + 1) * DB + i) * RW)[lane];
+                }
+#pragma unroll
+                for (int i = 0; i < DB; i++) {
+                    const int r = bidx * DB + i;
+                    if (r < K) e32 += popc_words(D[bidx & 1][i] ^ V[r]);
+                }
+            }
+            errs += e32;
+            continue;
+        }
+        // partial pass (the bottom of the region, or rows at the very end of the stream): per-word bounds
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < K; q++) Xv[q * 64 + lane] = V[q];
+        __syncthreads();
+#pragma unroll 1
+        for (int i = 0; i < K; i++) {
+            const long long r = q0 + i;
+            if (r < 0 || r >= nrows) continue;
+            const u64 w = word0 + (u64)r * RW + (u64)lane;
+            if (w > last_word) continue;
+            u64 d = buf[w] ^ X[i * RW + lane];
+            if (w == last_word) d &= last_mask;
+            errs += (u64)__builtin_popcountll(d);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) errs += __shfl_xor(errs, off, 64);
+    if (lane == 0 && errs) atomicAdd(nerr, errs);
+}
+
+static int launch_check_rev(int k, int ki, u64 init_state, u64 first_bit, u64 nbits, const u64 *buf, u64 *nerr, hipStream_t st) {
+    const u64 nwords = (nbits + 63) / 64;
+    const u64 RW = 64;
+    const u64 rows = (nwords + RW - 1) / RW;
+    int dev = 0, ncu = 256, per_cu = 4;
+    BBB_HIP(hipGetDevice(&dev));
+    BBB_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    const void *fn = nullptr;
+#define BBB_PRBS_FN(KK) case KK: fn = (const void *)prbs_check_rev_kernel<KK>; break;
+    switch (k) { BBB_PRBS_FN(7) BBB_PRBS_FN(9) BBB_PRBS_FN(11) BBB_PRBS_FN(15) BBB_PRBS_FN(20) BBB_PRBS_FN(23) BBB_PRBS_FN(31) }
+#undef BBB_PRBS_FN
+    {
+        static std::mutex mu;
+        static int cached_per_cu[8] = {0};
+        std::lock_guard<std::mutex> g(mu);
+        int &slot = cached_per_cu[ki];
+        if (slot == 0) {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+            slot = per_cu;
+        }
+        per_cu = slot;
+    }
+    static const int cap_env = env_knob("BBB_PRBS_WAVES_PER_CU", -1);
+    // the SAME partition as the generator (4 waves per CU): only then is the end of a checker's region the end of a
+    // generator's region, i.e. what the memory-side cache still holds (same-box sweep, gpurun_out/r02_prbs_rev_sweep.log:
+    // check after fill 0.277 ms at 4 per CU, 0.287-0.293 at 3, 5, 6, 8; ascending 0.290-0.301)
+    const int cap = cap_env > 0 ? cap_env : 4;
+    if (per_cu > cap) per_cu = cap;
+    const u64 target_waves = (u64)ncu * (u64)per_cu;           // exactly one resident generation of waves
+    u64 rpw = (rows + target_waves - 1) / target_waves;
+    const u64 min_rpw = 8 * (u64)k;
+    if (rpw < min_rpw) rpw = min_rpw;
+    const u64 nblocks = (rows + rpw - 1) / rpw;
+    if (nblocks > 0x7fffffffull) return fail(BBB_EINVAL, "nbits too large");
+    dim3 grid((unsigned)nblocks), block(64);
+#define BBB_PRBS_CASE(KK)                                                                                          \
+    case KK:                                                                                                       \
+        hipLaunchKernelGGL((prbs_check_rev_kernel<KK>), grid, block, 0, st, ki, init_state, first_bit, nbits, nwords, \
+                           rpw, buf, nerr);                                                                        \
+        break;
+    switch (k) {
+        BBB_PRBS_CASE(7) BBB_PRBS_CASE(9) BBB_PRBS_CASE(11) BBB_PRBS_CASE(15)
+        BBB_PRBS_CASE(20) BBB_PRBS_CASE(23) BBB_PRBS_CASE(31)
+    }
+#undef BBB_PRBS_CASE
+    BBB_HIP(hipGetLastError());
+    return BBB_OK;
+}
+
 // words per lane: 1 (8-byte accesses, a 2K-register window, 15.5 KiB of LDS for K = 31) measured
 // faster than 2 for both directions (profiles/r01_prbs_sweep.log); overridable for experiments
 static int prbs_wpl(bool check) {
@@ -395,6 +580,9 @@ static int launch_stream(int k, u64 init_state, u64 first_bit, u64 nbits, u64 *b
     static const int lw_fill = env_knob("BBB_PRBS_FILL_LW", 0);
     static const int lw_chk = env_knob("BBB_PRBS_CHECK_LW", 0);
     const bool lw = CHECK ? lw_chk != 0 : lw_fill != 0;
+    // the checker reads every region from its end (see prbs_check_rev_kernel); the ascending form stays for A/B
+    static const int rev = env_knob("BBB_PRBS_CHECK_REV", 1);
+    if (CHECK && rev && !lw && prbs_wpl(true) == 1) return launch_check_rev(k, ki, init_state, first_bit, nbits, buf, nerr, st);
     if (prbs_wpl(CHECK) == 1)
         return lw ? launch_stream_w<CHECK, 1, true>(k, ki, init_state, first_bit, nbits, buf, nerr, st)
                   : launch_stream_w<CHECK, 1, false>(k, ki, init_state, first_bit, nbits, buf, nerr, st);
