@@ -185,16 +185,69 @@ bitslice_kernel(const uint32_t *__restrict S, unsigned long long G, unsigned lon
 // ---------------------------------------------------------------------------------------------
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+// The transmitter's output fused into the sample kernel (tx.py:60-81; bitshaper.py:25-86): instead of the
+// int8 noise stream the round end writes x = wrap12(bit_en * shaped + wrap12(g * noise_var)) as int16, 32
+// bytes per generator and round, and the noise never goes through HBM.
+//   * shaped[n] = T[ph][q] with ph = (n-17) & 7, q = data bits M-7..M, M = (n-17) >> 3 (tx_kernels.hip).  A
+//     generator's 16 samples of a round start at n = first_sample + g L + 16 r; L is a multiple of 16, so
+//     c0 = (n-17) & 7 is the same for every generator and round: sample e has phase (c0+e) & 7 and window
+//     shift (c0+e) >> 3 in {0,1,2}.  The LDS table TT[q][j] = T[(c0+j) & 7][q] (16 bytes per q) gives the 8
+//     phases of one window by ONE ds_read_b128; rows q0, q1, q2 of the three shifts and a per-dword select
+//     (V_BFI with wave-uniform masks) give the 16 shaped samples as 8 packed pairs.
+//   * |g * noise_var| <= 128 * 15 < 2048: the inner wrap12 never acts.  The outer one is done in 16-bit
+//     arithmetic scaled by 16: TT holds 16 * (shaped - 128 noise_var) mod 2^16, the sample enters as the
+//     unsigned byte u = g + 128, and (u * 16 noise_var + TT) mod 2^16, shifted right arithmetically by 4, is
+//     wrap12(shaped + g noise_var) sign-extended to int16: V_PK_MAD_U16 + V_PK_ASHRREV_I16 per pair.
+//   * the data bits come packed from the PRBS generator (or the pulse pattern); a generator's 10-bit window
+//     moves by two bits per round and is re-read from the L1/L2-resident bit buffer.
+struct TxFuse {
+    int16_t coeffs[64];
+    const uint32_t *bits;     // packed data bits, bit 0 of the buffer = data bit m0v (64 zero bits lead when the stream starts)
+    uint32_t rel_base;        // window bit offset of the sample at output position 0: (F >> 3) - 7 - m0v, F = first_sample - 17
+    uint32_t c0;              // F & 7
+    int32_t noise_var;
+    int32_t bit_en;           // 0: shaped = 0 (tx.py:65-66)
+    int32_t use_bits;         // 0: every data bit reads as 0
+    uint32_t last_word;       // index of the last 32-bit word of the buffer that may be read
+};
+
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+typedef int16_t i16x2 __attribute__((ext_vector_type(2)));
+
+template <bool TX>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
-awgn256_kernel(const uint32_t *__restrict planes, int8_t *__restrict dst, unsigned long long nsamples,
-               unsigned L, unsigned long long G, unsigned nlanes) {
+awgn256_kernel(const uint32_t *__restrict planes, void *__restrict dst_, unsigned long long nsamples,
+               unsigned L, unsigned long long G, unsigned nlanes, TxFuse tx) {
     __shared__ uint32_t Z[16 * 8 * 64];
+    __shared__ __attribute__((aligned(16))) uint16_t TT[TX ? 256 * 8 : 8];
     const unsigned lane = threadIdx.x;
     const unsigned long long wave = blockIdx.x;
     const unsigned long long LG = wave * 64 + lane;
     // highest wave priority: when the seeding of the next fill (bbb_awgn_prefetch) shares the SIMD it gets the
     // issue slots this wave leaves free instead of every other one
     __builtin_amdgcn_s_setprio(3);
+
+    uint32_t selmask[4] = {0, 0, 0, 0};
+    if (TX) {
+        // TT[q][j] = 16 * (T[(c0+j) & 7][q] - 128 nv) mod 2^16;  T[ph][q] = wrap12(sum_idx +-coeffs[8 idx + ph]), the
+        // sign by data bit M - idx = bit (7 - idx) of q (bitshaper.py:52-58,74)
+        for (int e = (int)lane; e < 256 * 8; e += 64) {
+            const int q = e >> 3, j = e & 7, ph = (int)((tx.c0 + (unsigned)j) & 7u);
+            int sum = 0;
+#pragma unroll
+            for (int idx = 0; idx < 8; idx++) {
+                const int c = tx.coeffs[8 * idx + ph];
+                sum += ((q >> (7 - idx)) & 1) ? c : -c;
+            }
+            const int shaped = tx.bit_en ? ((int)((unsigned)sum << 20) >> 20) : 0;
+            TT[e] = (uint16_t)((unsigned)((shaped - 128 * tx.noise_var) * 16) & 0xffffu);
+        }
+        // pair d of a group of eight holds samples 2d, 2d+1: window shift 0 while c0 + e < 8
+#pragma unroll
+        for (int d = 0; d < 4; d++)
+            selmask[d] = (tx.c0 + 2u * (unsigned)d < 8u ? 0x0000ffffu : 0u) | (tx.c0 + 2u * (unsigned)d + 1u < 8u ? 0xffff0000u : 0u);
+        __syncthreads();
+    }
 
     // lutopt256_step yields the sample of the state it is GIVEN (and its successor): the planes hold
     // the state before the first sample, so advance once
@@ -222,6 +275,22 @@ awgn256_kernel(const uint32_t *__restrict planes, int8_t *__restrict dst, unsign
         }
 #pragma unroll 1
         for (unsigned i = 0; i < 8; i++) {
+            // TX: the data-bit windows of this iteration's four generators, issued before the LDS work
+            uint32_t wlo[4] = {0, 0, 0, 0}, whi[4] = {0, 0, 0, 0}, wsh[4] = {0, 0, 0, 0};
+            if (TX) {
+#pragma unroll
+                for (unsigned q = 0; q < 4; q++) {
+                    const unsigned long long g = gen_index(wave, lane, 8 * q + i);
+                    if (g < G && tx.use_bits) {
+                        const uint32_t off = (uint32_t)g * L + r * 16u;                 // fits 32 bits (host check)
+                        const uint32_t rel = (off >> 3) + tx.rel_base;
+                        const uint32_t wi = min(rel >> 5, tx.last_word - 1u);           // (rounds past the end of the request)
+                        wlo[q] = tx.bits[wi];
+                        whi[q] = tx.bits[wi + 1];
+                        wsh[q] = rel & 31u;
+                    }
+                }
+            }
             uint32_t o[4][4];                 // o[w][q] after the transposes
 #pragma unroll
             for (int w = 0; w < 4; w++) {
@@ -236,13 +305,46 @@ awgn256_kernel(const uint32_t *__restrict planes, int8_t *__restrict dst, unsign
             for (unsigned q = 0; q < 4; q++) {
                 const unsigned long long g = gen_index(wave, lane, 8 * q + i);
                 const unsigned long long off = g * L + (unsigned long long)r * 16;
-                if (g < G && off < nsamples) {
+                if (!(g < G && off < nsamples)) continue;
+                if (!TX) {
+                    int8_t *dst = (int8_t *)dst_;
                     const u32x4 v = {o[0][q], o[1][q], o[2][q], o[3][q]};
                     if (off + 16 <= nsamples) {
                         *reinterpret_cast<u32x4 *>(dst + off) = v;
                     } else {
                         const unsigned n = (unsigned)(nsamples - off);
                         for (unsigned e = 0; e < n; e++) dst[off + e] = (int8_t)((o[e >> 2][q] >> (8 * (e & 3))) & 0xff);
+                    }
+                } else {
+                    int16_t *dst = (int16_t *)dst_;
+                    // 10-bit window: bit j = data bit M0 - 7 + j; rows of the three window shifts (16 bytes each)
+                    const uint32_t Q4 = (__builtin_amdgcn_alignbit(whi[q], wlo[q], wsh[q]) & 0x3ffu) << 4;
+                    const u32x4 A = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(TT) + (Q4 & 0xff0u));
+                    const u32x4 B = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(TT) + ((Q4 >> 1) & 0xff0u));
+                    const u32x4 C = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(TT) + ((Q4 >> 2) & 0xff0u));
+                    const u16x2 nv16 = {(uint16_t)(tx.noise_var * 16), (uint16_t)(tx.noise_var * 16)};
+                    uint32_t x[8];
+#pragma unroll
+                    for (int w = 0; w < 4; w++) {
+                        const uint32_t u = o[w][q] ^ 0x80808080u;                       // bytes g + 128 of samples 4w .. 4w+3
+                        const uint32_t u01 = __builtin_amdgcn_perm(0u, u, 0x0c010c00u);  // [u0, 0, u1, 0]
+                        const uint32_t u23 = __builtin_amdgcn_perm(0u, u, 0x0c030c02u);
+                        // shaped pairs of samples 4w, 4w+1 and 4w+2, 4w+3 (pair d = (2w) & 3, (2w+1) & 3 of their group of eight)
+                        const int d0 = (2 * w) & 3, d1 = (2 * w + 1) & 3;
+                        const uint32_t s01 = w < 2 ? bit_select(selmask[d0], A[d0], B[d0]) : bit_select(selmask[d0], B[d0], C[d0]);
+                        const uint32_t s23 = w < 2 ? bit_select(selmask[d1], A[d1], B[d1]) : bit_select(selmask[d1], B[d1], C[d1]);
+                        const u16x2 m01 = __builtin_bit_cast(u16x2, u01) * nv16 + __builtin_bit_cast(u16x2, s01);
+                        const u16x2 m23 = __builtin_bit_cast(u16x2, u23) * nv16 + __builtin_bit_cast(u16x2, s23);
+                        x[2 * w] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(i16x2, m01) >> 4);
+                        x[2 * w + 1] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(i16x2, m23) >> 4);
+                    }
+                    if (off + 16 <= nsamples) {
+                        const u32x4 lo = {x[0], x[1], x[2], x[3]}, hi = {x[4], x[5], x[6], x[7]};
+                        reinterpret_cast<u32x4 *>(dst + off)[0] = lo;
+                        reinterpret_cast<u32x4 *>(dst + off)[1] = hi;
+                    } else {
+                        const unsigned n = (unsigned)(nsamples - off);
+                        for (unsigned e = 0; e < n; e++) dst[off + e] = (int16_t)((x[e >> 1] >> (16 * (e & 1))) & 0xffff);
                     }
                 }
             }
@@ -437,8 +539,47 @@ int awgn_seed_launch(int k, const uint32_t *d_tabs, const uint32_t *s16, uint64_
 int awgn256_fill_launch(const uint32_t *d_planes, int8_t *dst, uint64_t nsamples, unsigned L, uint64_t G,
                         unsigned nlanes, hipStream_t st) {
     const unsigned nwaves = nlanes / 64;
-    hipLaunchKernelGGL(awgn256_kernel, dim3(nwaves), dim3(64), 0, st, d_planes, dst, (unsigned long long)nsamples, L,
-                       (unsigned long long)G, nlanes);
+    hipLaunchKernelGGL(awgn256_kernel<false>, dim3(nwaves), dim3(64), 0, st, d_planes, (void *)dst, (unsigned long long)nsamples, L,
+                       (unsigned long long)G, nlanes, TxFuse{});
+    BBB_HIP(hipGetLastError());
+    return BBB_OK;
+}
+
+// data bits of the pulse source (tx.py:20-30: a 1 every 256 bit periods), packed like the PRBS generator's
+__global__ void __launch_bounds__(256)
+pulse_bits_kernel(unsigned long long *__restrict dst, long long m_first, unsigned long long nwords) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nwords) return;
+    unsigned long long w = 0;
+    for (int j = 0; j < 64; j++) {
+        const long long m = m_first + (long long)(64 * i) + j;
+        if (m >= 0 && (m & 255) == 0) w |= 1ull << j;
+    }
+    dst[i] = w;
+}
+
+int pulse_bits_launch(uint64_t *dst, int64_t m_first, uint64_t nwords, hipStream_t st) {
+    if (!nwords) return BBB_OK;
+    hipLaunchKernelGGL(pulse_bits_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, st, (unsigned long long *)dst,
+                       (long long)m_first, (unsigned long long)nwords);
+    BBB_HIP(hipGetLastError());
+    return BBB_OK;
+}
+
+int awgn256_tx_launch(const uint32_t *d_planes, int16_t *dst, uint64_t nsamples, unsigned L, uint64_t G, unsigned nlanes,
+                      const int16_t *coeffs, const uint32_t *d_bits, uint32_t nwords32, uint32_t rel_base, uint32_t c0, int noise_var,
+                      int bit_en, int use_bits, hipStream_t st) {
+    TxFuse tx;
+    for (int i = 0; i < 64; i++) tx.coeffs[i] = coeffs[i];
+    tx.bits = d_bits;
+    tx.rel_base = rel_base;
+    tx.c0 = c0;
+    tx.noise_var = noise_var;
+    tx.bit_en = bit_en;
+    tx.use_bits = use_bits && nwords32 >= 2;
+    tx.last_word = nwords32 ? nwords32 - 1 : 1;
+    hipLaunchKernelGGL(awgn256_kernel<true>, dim3(nlanes / 64), dim3(64), 0, st, d_planes, (void *)dst, (unsigned long long)nsamples, L,
+                       (unsigned long long)G, nlanes, tx);
     BBB_HIP(hipGetLastError());
     return BBB_OK;
 }

@@ -12,6 +12,12 @@ int awgn_seed_launch(int k, const uint32_t *d_tabs, const uint32_t *s16, uint64_
                      uint64_t stride, unsigned nlanes, uint32_t *d_planes, hipStream_t st);
 int awgn256_fill_launch(const uint32_t *d_planes, int8_t *dst, uint64_t nsamples, unsigned L, uint64_t G,
                         unsigned nlanes, hipStream_t st);
+// the transmitter's output fused into the sample kernel: x = wrap12(bit_en * shaped + g * noise_var) as int16.
+// d_bits: packed data bits (32-bit words); rel_base = window bit offset of output position 0; c0 = (first_sample - 17) & 7
+int awgn256_tx_launch(const uint32_t *d_planes, int16_t *dst, uint64_t nsamples, unsigned L, uint64_t G, unsigned nlanes,
+                      const int16_t *coeffs, const uint32_t *d_bits, uint32_t nwords32, uint32_t rel_base, uint32_t c0, int noise_var,
+                      int bit_en, int use_bits, hipStream_t st);
+int pulse_bits_launch(uint64_t *dst, int64_t m_first, uint64_t nwords, hipStream_t st);
 int widen_i8_i16_launch(const int8_t *src, int16_t *dst, uint64_t n, hipStream_t st);   // n rounded up to 16 by the caller's buffers
 int awgn_generic_fill_launch(int k, const uint16_t *d_taps, const uint32_t *d_row_off, uint32_t *d_planes2,
                              void *dst, int elem_size, uint64_t nsamples, unsigned L, uint64_t G, unsigned nlanes,

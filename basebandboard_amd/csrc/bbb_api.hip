@@ -263,6 +263,22 @@ int prepare_planes(bbb_lutopt *h, uint64_t first, uint64_t L, uint64_t G, unsign
     return BBB_OK;
 }
 
+// the start states of (first_step, L, G): those an announced prefetch seeded on the side stream, or seeded now
+int acquire_planes(bbb_lutopt *h, uint64_t first_step, uint64_t L, uint64_t G, unsigned nlanes, bool may_use_prefetch) {
+    if (may_use_prefetch && h->pf.valid && h->pf.first == first_step && h->pf.L == L && h->pf.G == G) {
+        // the announced fill: its start states were seeded on the side stream -- swap them in
+        BBB_HIP(hipStreamWaitEvent(h->stream, h->pf.seeded, 0));
+        std::swap(h->d_states, h->pf.d_states); std::swap(h->states_cap, h->pf.states_cap);
+        std::swap(h->d_planes, h->pf.d_planes); std::swap(h->planes_cap, h->pf.planes_cap);
+        std::swap(h->cur_last_read, h->pf.last_read); std::swap(h->cur_read_pending, h->pf.read_pending);
+        h->pf.valid = false;
+        h->planes_valid = true;
+        h->planes_first = first_step; h->planes_L = L; h->planes_G = G;
+        return BBB_OK;
+    }
+    return prepare_planes(h, first_step, L, G, nlanes);
+}
+
 int awgn_fill(bbb_lutopt *h, void *dst, int elem_size, uint64_t nsamples, uint64_t first_step) {
     if (!h) return fail(BBB_EINVAL, "null handle");
     if (nsamples == 0) return BBB_OK;
@@ -281,19 +297,7 @@ int awgn_fill(bbb_lutopt *h, void *dst, int elem_size, uint64_t nsamples, uint64
         BBB_HIP(hipEventCreate(&ev.e0)); BBB_HIP(hipEventCreate(&ev.e1)); BBB_HIP(hipEventCreate(&ev.e2));
         BBB_HIP(hipEventRecord(ev.e0, h->stream));
     }
-    int rc = BBB_OK;
-    if (h->specialised && elem_size == 1 && h->pf.valid && h->pf.first == first_step && h->pf.L == L && h->pf.G == G) {
-        // the announced fill: its start states were seeded on the side stream -- swap them in
-        BBB_HIP(hipStreamWaitEvent(h->stream, h->pf.seeded, 0));
-        std::swap(h->d_states, h->pf.d_states); std::swap(h->states_cap, h->pf.states_cap);
-        std::swap(h->d_planes, h->pf.d_planes); std::swap(h->planes_cap, h->pf.planes_cap);
-        std::swap(h->cur_last_read, h->pf.last_read); std::swap(h->cur_read_pending, h->pf.read_pending);
-        h->pf.valid = false;
-        h->planes_valid = true;
-        h->planes_first = first_step; h->planes_L = L; h->planes_G = G;
-    } else {
-        rc = prepare_planes(h, first_step, L, G, nlanes);
-    }
+    int rc = acquire_planes(h, first_step, L, G, nlanes, h->specialised && elem_size == 1);
     if (rc) return rc;
     if (h->specialised && elem_size == 1) {
         if (h->profiling) BBB_HIP(hipEventRecord(ev.e1, h->stream));
@@ -799,6 +803,31 @@ int bbb_tx_fill_i16(bbb_lutopt *h, const bbb_tx_cfg *cfg, int16_t *out_dev, uint
     int64_t m0;
     uint64_t nbits;
     tx_bit_range(first_sample, nsamples, &m0, &nbits);
+    if (cfg->noise_en && h->specialised && first_sample + nsamples < (1ull << 62) && nsamples < (1ull << 31)) {
+        // the shaper fused into the sample kernel: the int8 noise stream never goes through HBM
+        if (cfg->warmup + first_sample + nsamples < nsamples) return fail(BBB_EINVAL, "warmup + first_sample + nsamples overflows");
+        uint64_t L, G;
+        unsigned nlanes;
+        partition(h, nsamples, 16, &L, &G, &nlanes);
+        const int64_t F = (int64_t)first_sample - 17, FM = F >> 3;            // arithmetic shift = floor
+        const bool use_bits = cfg->bit_en && nbits;
+        // buffer: two zero 64-bit words (data bits before the first read as 0, the shaper's reset shift register), the
+        // bits m0 .. m0+nbits-1, slack for the windows of rounds past the end of the request
+        const uint64_t words64 = 2 + (nbits + 63) / 64 + (L / 8 + 63) / 64 + 2;
+        if ((rc = grow(&h->d_txbits, &h->txbits_cap, (size_t)words64 * 2))) return rc;
+        if (use_bits) {
+            BBB_HIP(hipMemsetAsync(h->d_txbits, 0, 16, h->stream));
+            uint64_t *bits64 = (uint64_t *)h->d_txbits + 2;
+            if (cfg->source == 0) rc = prbs_fill_launch(cfg->prbs_k, cfg->prbs_state, (uint64_t)m0, nbits, bits64, h->stream);
+            else rc = pulse_bits_launch(bits64, m0, (nbits + 63) / 64, h->stream);
+            if (rc) return rc;
+        }
+        if ((rc = acquire_planes(h, cfg->warmup + first_sample, L, G, nlanes, true))) return rc;      // tx.py:70-71
+        const uint32_t rel_base = (uint32_t)(FM - 7 - (m0 - 128));
+        rc = awgn256_tx_launch(h->d_planes, out_dev, nsamples, (unsigned)L, G, nlanes, cfg->coeffs, h->d_txbits, (uint32_t)(words64 * 2),
+                               rel_base, (uint32_t)(F & 7), cfg->noise_var, cfg->bit_en, use_bits ? 1 : 0, h->stream);
+        return rc ? rc : mark_planes_read(h);
+    }
     const bool have_bits = cfg->source == 0 && nbits && cfg->bit_en;
     if (have_bits) {
         if ((rc = grow(&h->d_txbits, &h->txbits_cap, (size_t)((nbits + 63) / 64 + 2) * 2))) return rc;
