@@ -33,6 +33,36 @@ def ber_theory(db):
     return 0.5 * math.erfc(math.sqrt(10.0 ** (db / 10.0)))
 
 
+def ber_lattice(amp, noise_var):
+    """What a Gaussian of variance 64 predicts for THIS integer channel: the CLT sample g is an integer, so bit 0
+    errs when g >= ceil(amp / nv) and bit 1 when g <= -(floor(amp / nv) + 1) (tx.py:75-81, rx.py:29 without
+    12-bit wrap); with the continuity correction of half a lattice step that is
+    (Q((k0 - 1/2) / 8) + Q((k1 - 1/2) / 8)) / 2.  Comparable with the counters, unlike Q(sqrt(2 Eb/N0)) of the
+    nominal label, which ignores the lattice (the two differ by -7 % ... +12 % over 0-10 dB)."""
+    if noise_var == 0:
+        return 0.0
+    k0 = -(-amp // noise_var)
+    k1 = amp // noise_var + 1
+    q = lambda x: 0.5 * math.erfc(x / math.sqrt(2.0))
+    return 0.5 * (q((k0 - 0.5) / SIGMA_G) + q((k1 - 0.5) / SIGMA_G))
+
+
+def ebn0_db_effective(amp, noise_var):
+    """The Eb/N0 at which Q(sqrt(2 Eb/N0)) equals ber_lattice(amp, noise_var): the label to plot the counters
+    against a theoretical BPSK curve."""
+    target = ber_lattice(amp, noise_var)
+    if target <= 0.0:
+        return math.inf
+    lo, hi = -30.0, 40.0
+    for _ in range(200):
+        mid = 0.5 * (lo + hi)
+        if ber_theory(mid) > target:
+            lo = mid
+        else:
+            hi = mid
+    return 0.5 * (lo + hi)
+
+
 class Trial:
     """One (Eb/N0 point, seed-offset) trial; field meaning as bbb_trial_cfg in include/bbb.h."""
 

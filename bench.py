@@ -2,7 +2,10 @@
 """Headline benchmark: CLT Gaussian noise (AWGN) sample generation on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+  N > 1: either under a launcher (python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...,
+  RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) or plainly as above -- then this process
+  starts the N ranks itself as child processes before touching any GPU (launch_ranks) and passes rank 0's
+  JSON line through.
 
 One step = one pass of the hot path over one batch: 1e9 int8 CLT samples of the reference's
 LUTOPT-256 -> CLTGRNG generator (BASELINE.json configs[1]; the reference has no "CLT-12 /
@@ -18,9 +21,12 @@ The JSON line also carries
                launch time from hipEvents on the launch stream) against the 8 TB/s HBM peak.
                The kernel is integer-VALU bound (~1250 lane-ops per 32 samples), so this fraction
                is expected to be far below 1; `valu_*` fields give the bound that applies.
-  cpu_baseline the CPU oracle (k=256 fast path, 1 thread, -march=native) timed on this host
-               on a bounded sample (rank 0, N = 1 only).
-  extra        PRBS-31 generate+check loopback and a BER sweep, measured after the timed region.
+               `roofline_other` holds the same record for the PRBS fill / check, detector and TX kernels.
+  cpu_baseline the CPU oracle (k=256 fast path, -march=native) timed on this host on a bounded
+               sample (rank 0, N = 1 only): all host cores this process may use (count stated), and
+               one core beside it.
+  extra        PRBS-31 generate+check loopback (per pass), the exact detector, the TX waveform, the
+               matrix search and the BER sweep, measured after the timed region.
 """
 import argparse
 import json
@@ -40,9 +46,10 @@ VALU_OPS_PER_SAMPLE = None       # filled from the generated network's op count
 
 
 def cpu_baseline():
-    """Time the oracle's k=256 fast path on this host (checker code used as the reported CPU
-    baseline only).  Bounded sample: ~2e8 samples (10-30 s)."""
-    import numpy as np
+    """Time the oracle's k=256 fast path on this host (checker code used as the reported CPU baseline only).
+    Bounded sample: every core this process may use generates 2e7 samples of the stream at its own offset
+    (a few seconds), and one core alone for the single-core figure."""
+    import concurrent.futures
     import oracle as O
     so = O.build(native=True, out="/tmp/libbbb_oracle_native.so", force=True)
     lib = O.lib(path=so)
@@ -50,24 +57,25 @@ def cpu_baseline():
     n = 20_000_000
     t0 = time.perf_counter()
     m.awgn(1, WARM_STATE, n, fast=True)
-    dt = time.perf_counter() - t0
-    reps = max(1, min(10, int(15.0 / max(dt, 1e-3))))
+    dt1 = time.perf_counter() - t0
+    reps = max(1, min(4, int(6.0 / max(dt1, 1e-3))))
     t0 = time.perf_counter()
     for i in range(reps):
         m.awgn(1 + i, WARM_STATE, n, fast=True)      # same length, different seed each repetition
     dt = time.perf_counter() - t0
-    # the same restatement on a share of the host's cores (one stream offset per thread via a different seed;
-    # ctypes releases the GIL around the call).  Reported beside the single-core figure, not instead of it.
-    import concurrent.futures
-    nthr = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+    # all cores: one piece of the stream per thread (ctypes releases the GIL around the call)
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    nthr = max(1, min(ncores, 512))
+    per = 2 if nthr <= 64 else 1                    # pieces per thread: ~10-20 s of CPU work in total, bounded wall time
     with concurrent.futures.ThreadPoolExecutor(nthr) as ex:
         t1 = time.perf_counter()
-        list(ex.map(lambda i: m.awgn(100 + i, WARM_STATE, n, fast=True), range(nthr)))
+        list(ex.map(lambda i: m.awgn(100 + i, WARM_STATE, n, fast=True), range(nthr * per)))
         dtn = time.perf_counter() - t1
-    return {"value": round(reps * n / dt / 1e9, 5), "unit": "Gsample/s", "cores": 1, "kind": "port",
-            "sample": f"{reps} x {n} samples of the same stream (oracle k=256 byte-table path, gcc -O3 -march=native, "
-                      f"host has {os.cpu_count()} logical cores)",
-            "threads_value": round(nthr * n / dtn / 1e9, 5), "threads": nthr}
+    return {"value": round(nthr * per * n / dtn / 1e9, 5), "unit": "Gsample/s", "cores": nthr, "kind": "port",
+            "sample": f"{nthr * per} x {n} samples of the same stream, one piece per thread on {nthr} threads (all the cores this "
+                      f"process may use; the host reports {os.cpu_count()} logical cores); oracle k=256 byte-table path, "
+                      f"gcc -O3 -march=native",
+            "single_core_value": round(reps * n / dt / 1e9, 5), "single_core_sample": f"{reps} x {n} samples on one core"}
 
 
 def cpu_baseline_other():
@@ -238,14 +246,19 @@ def main():
         fill_gbs = 5 * NSAMP / f0.elapsed_time(f1) / 1e6
         del fb
 
-    # PMC-measured HBM write bytes per launch, if a profile summary of this command is committed
-    traffic = None
-    pmc = ROOT / "profiles" / "r01_awgn256_pmc.json"
-    if pmc.exists():
-        try:
-            traffic = json.load(open(pmc)).get("awgn256_kernel_hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    # HBM bytes per launch from the PMC counters: they need their own rocprofv3 passes (--pmc WRITE_SIZE /
+    # --pmc FETCH_SIZE, profiles/README.md), so the line carries the committed summary of this round's pass and
+    # says which file it came from (stale if the kernel changed since)
+    traffic = traffic_src = None
+    for name in ("r02_awgn256_pmc.json", "r01_awgn256_pmc.json"):
+        pmc = ROOT / "profiles" / name
+        if pmc.exists():
+            try:
+                traffic = json.load(open(pmc)).get("awgn256_kernel_hbm_bytes_per_launch")
+                traffic_src = f"profiles/{name} (separate --pmc WRITE_SIZE / FETCH_SIZE passes over this command; stale if the kernel changed since)"
+                break
+            except Exception:
+                traffic = None
     ops_per_step = 1002
     try:
         inc = (ROOT / "basebandboard_amd" / "csrc" / "gen" / "lutopt256_gen.inc").read_text()
@@ -255,32 +268,68 @@ def main():
         pass
 
     extra = {}
+    other = []            # roofline records of the other kernels on the path
     if not args.no_extra:
-        # PRBS-31 loopback (BASELINE configs[2]): 1e10 bits written then read back and checked
+        import ctypes as C
+        from basebandboard_amd import _lib
+        L = _lib.lib()
+        dev = f"cuda:{local_rank}"
+        sp = C.c_void_p(torch.cuda.current_stream(local_rank).cuda_stream)
+        ev = lambda: torch.cuda.Event(enable_timing=True)
+
+        def hbm(kernel, nbytes, ms, what):
+            gbs = nbytes / ms / 1e6
+            return {"kernel": kernel, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": int(nbytes), "kernel_ms_avg": round(ms, 4),
+                    "what": what}
+
+        # PRBS-31 loopback (BASELINE configs[2]): 1e10 bits written, then read back and checked.  Per pass, device
+        # time between hipEvents on the launch stream: the fill, the check right after the fill (the loopback order:
+        # it also pays for the write-backs of the fill's last 256 MiB, which are still dirty in the memory-side cache),
+        # the check repeated on the now clean buffer; and the loopback cut into pieces that fit that cache.
         nbits = 10_000_000_000
-        p = bbb.PRBS(31, device=local_rank)
-        det = bbb.PRBSErrorDetector(31, device=local_rank)
-        pbuf = torch.empty((nbits + 63) // 64, dtype=torch.int64, device=f"cuda:{local_rank}")
-        p.generate(nbits, out=pbuf)
+        nbytes = nbits / 8
+        pbuf = torch.empty((nbits + 63) // 64, dtype=torch.int64, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+        fill = lambda first, n: _lib.check(L.bbb_prbs_fill(31, 1, first, n, C.c_void_p(pbuf.data_ptr() + first // 8), local_rank, sp), "bbb_prbs_fill")
+        check = lambda first, n: _lib.check(L.bbb_prbs_check_dev(31, 1, first, n, C.c_void_p(pbuf.data_ptr() + first // 8),
+                                                                C.c_void_p(cnt.data_ptr()), local_rank, sp), "bbb_prbs_check_dev")
+        for _ in range(2):
+            fill(0, nbits); check(0, nbits)
         torch.cuda.synchronize()
-        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         reps = 5
-        nerr = None
-        gen_ms = chk_ms = 0.0
+        f_ms = c_ms = c2_ms = p_ms = 0.0
+        piece = 1 << 31                                  # 256 MiB
         for _ in range(reps):
-            e0.record(); p.generate(nbits, out=pbuf); e1.record()
-            nerr = det.count_errors(pbuf, nbits); e2.record()
+            e = [ev() for _ in range(6)]
+            e[0].record(); fill(0, nbits); e[1].record(); check(0, nbits); e[2].record(); check(0, nbits); e[3].record()
+            e[4].record()
+            for first in range(0, nbits, piece):
+                n = min(piece, nbits - first)
+                fill(first, n); check(first, n)
+            e[5].record()
             torch.cuda.synchronize()
-            gen_ms += e0.elapsed_time(e1); chk_ms += e1.elapsed_time(e2)
+            f_ms += e[0].elapsed_time(e[1]) / reps; c_ms += e[1].elapsed_time(e[2]) / reps
+            c2_ms += e[2].elapsed_time(e[3]) / reps; p_ms += e[4].elapsed_time(e[5]) / reps
+        nerr = int(cnt.item())
+        tb = lambda ms: round(nbytes / ms / 1e9, 3)
         extra["prbs31_loopback"] = {
-            "bits": nbits, "errors": int(nerr),
-            "gen_gbit_s": round(nbits * reps / gen_ms / 1e6, 1), "check_gbit_s": round(nbits * reps / chk_ms / 1e6, 1),
-            "gen_hbm_write_gb_s": round(nbits / 8 * reps / gen_ms / 1e6, 1),
-            "check_hbm_read_gb_s": round(nbits / 8 * reps / chk_ms / 1e6, 1),
-            "hbm_frac_write": round(nbits / 8 * reps / gen_ms / 1e6 / HBM_PEAK_GBS, 4),
-            "hbm_frac_read": round(nbits / 8 * reps / chk_ms / 1e6 / HBM_PEAK_GBS, 4)}
+            "bits": nbits, "errors": nerr,
+            "fill_ms": round(f_ms, 4), "check_after_fill_ms": round(c_ms, 4), "check_clean_ms": round(c2_ms, 4),
+            "fill_tb_s": tb(f_ms), "check_after_fill_tb_s": tb(c_ms), "check_clean_tb_s": tb(c2_ms),
+            "loopback_ms": round(f_ms + c_ms, 4), "loopback_tb_s": round(2 * nbytes / (f_ms + c_ms) / 1e9, 3),
+            "loopback_hbm_frac": round(2 * nbytes / (f_ms + c_ms) / 1e6 / HBM_PEAK_GBS, 4),
+            "pieced_256MiB_loopback_ms": round(p_ms, 4), "pieced_256MiB_loopback_tb_s": round(2 * nbytes / p_ms / 1e9, 3),
+            "gen_gbit_s": round(nbits / f_ms / 1e6, 1), "check_gbit_s": round(nbits / c_ms / 1e6, 1),
+            "note": "whole-buffer passes; the checker reads every region from its end on the generator's partition (what the "
+                    "memory-side cache still holds); fill beside check on two streams does not overlap (profiles/README.md)"}
+        other.append(hbm("prbs_stream_kernel<31,false> (fill)", nbytes, f_ms, "1/8 B per bit written"))
+        other.append(hbm("prbs_check_rev_kernel<31> (check right after the fill)", nbytes, c_ms, "1/8 B per bit read"))
+        other.append(hbm("prbs_check_rev_kernel<31> (check of a clean buffer)", nbytes, c2_ms, "1/8 B per bit read"))
+        del cnt
         # exact self-synchronising detector over the same 1e10-bit stream, with 1e-3 injected errors
         # (chunked FSM with state hand-off)
+        det = bbb.PRBSErrorDetector(31, device=local_rank)
         noise = torch.randint(0, 1000, (pbuf.numel(),), device=pbuf.device) == 0
         pbuf ^= noise.to(torch.int64) << 13
         del noise
@@ -293,21 +342,29 @@ def main():
         extra["detector_stream"] = {"bits": nbits, "errors": ds["errors"], "resyncs": ds["resyncs"], "chunks": ds["chunks"],
                                     "chunks_rerun": ds["chunks_rerun"], "gbit_s": round(nbits / td / 1e9, 1),
                                     "note": "bbb_prbs_detector_stream, totals only, includes its verify passes and host syncs"}
+        r = hbm("det_chunk_kernel<31> + verify passes (whole call, wall clock)", nbytes, td * 1e3, "1/8 B per bit read")
+        r["true_bound"] = "integer VALU (~45 instructions per 64-bit word for a locked detector), not HBM"
+        other.append(r)
         del pbuf
         # TX output stream: shaped PRBS-31 + scaled CLT noise, int16, 8 samples/bit
         ntx = 1 << 29
         tx = bbb.TX(31, 1, 0, 16, 1, 8, device=local_rank)
-        txbuf = torch.empty(ntx, dtype=torch.int16, device=f"cuda:{local_rank}")
+        txbuf = torch.empty(ntx, dtype=torch.int16, device=dev)
         tx.generate(ntx, out=txbuf)
         torch.cuda.synchronize()
-        t0e, t1e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0e, t1e = ev(), ev()
         t0e.record()
         for i in range(3):
             tx.generate(ntx, first_sample=(i + 1) * ntx, out=txbuf)
         t1e.record()
         torch.cuda.synchronize()
-        extra["tx_waveform"] = {"samples": ntx, "gsample_s": round(3 * ntx / t0e.elapsed_time(t1e) / 1e6, 1),
-                                "note": "bbb_tx_fill_i16: PRBS fill + CLT noise fill + shaper/combine kernel, int16 out"}
+        tx_ms = t0e.elapsed_time(t1e) / 3
+        extra["tx_waveform"] = {"samples": ntx, "gsample_s": round(ntx / tx_ms / 1e6, 1), "ms_per_call": round(tx_ms, 4),
+                                "note": "bbb_tx_fill_i16: PRBS fill + the sample kernel with the shaper fused into its round end "
+                                        "(int16 out, the int8 noise never goes through HBM)"}
+        r = hbm("awgn256_kernel<true> (whole bbb_tx_fill_i16 call)", 2.0 * ntx, tx_ms, "2 B per sample written")
+        r["true_bound"] = "integer VALU of the noise generator, then the rate of scattered 32-byte store pieces (one per generator per 16 samples)"
+        other.append(r)
         del txbuf
         # the reference's matrix search (software/rnghunt) on the GPU: candidates per second for k = 256
         from basebandboard_amd import gf2 as _gf2
@@ -321,27 +378,40 @@ def main():
                                        "call_ms": round(tsr * 1e3, 2),
                                        "note": "bbb_lutopt_search: build + 512 steps + Berlekamp-Massey + primitivity per wavefront; "
                                                "kcand_s from the kernel's duration, call_ms includes the host re-check of the hit"}
-        # BER sweep (BASELINE configs[3]/[4]): Eb/N0 0..10 dB, 1e9 bits/point, sharded over ranks
-        # (point i -> rank i % world), ONE all-reduce (RCCL) of the uint64 counters.
+        # BER sweep (BASELINE configs[3]/[4]): Eb/N0 0..10 dB, 1e9 bits/point.
         # N > 1 (BASELINE configs[4]): points x seeds -- every rank runs all 11 points on its own seed (one noise
-        # pass per rank), the counters are summed over ranks: N times the bits per point in the same time.
+        # pass per rank), ONE all-reduce (RCCL) sums the uint64 counters: N times the bits per point in the same time.
         nv = 8
         trials = [channel.Trial(nbits=1_000_000_000, amp=channel.amp_for_ebn0(db, nv), noise_var=nv) for db in range(11)]
         us = u if world == 1 else bbb.LUTOPT.shipped(256, init=1 + rank, device=local_rank)
         channel.sweep_seeds(trials, channel.gpu_runner(us), world=world)       # untimed: builds the jump plans
         torch.cuda.synchronize(); barrier()
-        tb = time.perf_counter()
+        tb0 = time.perf_counter()
         total = channel.sweep_seeds(trials, channel.gpu_runner(us), world=world)
         torch.cuda.synchronize(); barrier()
-        tber = time.perf_counter() - tb
+        tber = time.perf_counter() - tb0
         tot = total.cpu().tolist()
         extra["ber_sweep"] = {
-            "points": [{"ebn0_db": round(channel.ebn0_db(t.amp, nv), 3), "amp": t.amp, "noise_var": nv, "bits": b, "errors": e,
-                        "ber": e / b if b else None, "q_theory": channel.ber_theory(channel.ebn0_db(t.amp, nv))}
-                       for t, (b, e) in zip(trials, tot)],
-            "gbit_s": round(sum(b for b, _ in tot) / tber / 1e9, 2), "seconds": round(tber, 4),
+            "points": [{"ebn0_db": round(channel.ebn0_db(t.amp, nv), 3), "ebn0_db_effective": round(channel.ebn0_db_effective(t.amp, nv), 3),
+                        "amp": t.amp, "noise_var": nv, "bits": b_, "errors": e_, "ber": e_ / b_ if b_ else None,
+                        "q_theory": channel.ber_theory(channel.ebn0_db(t.amp, nv)), "q_lattice": channel.ber_lattice(t.amp, nv)}
+                       for t, (b_, e_) in zip(trials, tot)],
+            "gbit_s": round(sum(b_ for b_, _ in tot) / tber / 1e9, 2), "seconds": round(tber, 4),
             "seeds": world,
+            "labels": "ebn0_db = amp^2 / (2 (8 nv)^2), ignores that the sample is an integer; ebn0_db_effective / q_lattice account for "
+                      "the integer decision threshold (channel.ber_lattice) and are the ones comparable with Q(sqrt(2 Eb/N0))",
             "reduce": "torch.distributed.all_reduce(int64[11,2], SUM) over RCCL, one seed per rank" if world > 1 else "single rank"}
+        if world == 1:
+            # the same sweep through the C ABI's own multi-device entry (host thread per device + ONE ncclAllReduce),
+            # here over this one device
+            from basebandboard_amd.channel import sweep_multi
+            sweep_multi([u], trials)
+            tm = time.perf_counter()
+            got = sweep_multi([u], trials)
+            tm = time.perf_counter() - tm
+            extra["ber_sweep_multi_c_abi"] = {"n_devices": 1, "equals_single_device_counters": [list(x) for x in got] == tot,
+                                              "gbit_s": round(sum(b_ for b_, _ in got) / tm / 1e9, 2),
+                                              "reduce": "ncclAllReduce(ncclUint64, ncclSum) of uint64[22] inside bbb_ber_sweep_multi"}
 
     if rank == 0:
         out = {
@@ -356,7 +426,7 @@ def main():
                        "seeding_overlapped_by_prefetch_hint": bool(prefetch),
                        "verified_vs_oracle": verified},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "awgn256_kernel", "kernel_ms_avg": round(kern_avg_ms, 4),
                          "seed_ms_avg": round(seed_ms / max(calls, 1), 4), "launches_timed": int(calls),
                          "algorithmic_bytes_per_launch": NSAMP,
@@ -365,17 +435,22 @@ def main():
                          "true_bound": "integer VALU (bit-sliced XOR/majority network), not HBM",
                          "valu_lane_ops_per_sample": round(ops_per_step / 32.0, 2),
                          "valu_net_tlaneops_s": round(ops_per_step / 32.0 * achieved / 1e3, 2),
-                         # issue ceiling at ONE wave per SIMD (the kernel needs the whole register file): one VALU
-                         # instruction per 4 cycles per SIMD (SQ_ACTIVE_INST_VALU = SQ_INSTS_VALU quad-cycles,
-                         # profiles/r01_d_pmc_sq.json) = 256 CUs x 4 SIMDs x 64 lanes x 2.4 GHz / 4; the shader clock
-                         # observed under this kernel is 2.16 GHz (GRBM_GUI_ACTIVE), i.e. 35.4 at the real clock
+                         # the chip's VALU issue peak: 256 CUs x 4 SIMD-32 x 32 lanes x 2.4 GHz (one wave-instruction
+                         # per 2 cycles per SIMD, reachable with >= 2 waves per SIMD) -- the honest denominator
+                         "valu_peak_tlaneops_s": 78.64,
+                         "valu_frac": round(ops_per_step / 32.0 * achieved / 1e3 / 78.64, 3),
+                         # this kernel holds the whole register file (256 state planes), i.e. ONE wave per SIMD, and a
+                         # single wave issues one VALU instruction per 4 cycles (SQ_ACTIVE_INST_VALU = SQ_INSTS_VALU
+                         # quad-cycles, profiles/r01_d_pmc_sq.json): half the peak above is its structural ceiling
                          "valu_peak_1wave_tlaneops_s": 39.32,
-                         "valu_frac_net": round(ops_per_step / 32.0 * achieved / 1e3 / 39.32, 3)},
+                         "valu_frac_of_1wave_ceiling": round(ops_per_step / 32.0 * achieved / 1e3 / 39.32, 3)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             if extra:
                 extra["cpu_baseline_other"] = cpu_baseline_other()
+        if other:
+            out["roofline_other"] = other
         if extra:
             out["extra"] = extra
         print(json.dumps(out))

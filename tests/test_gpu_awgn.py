@@ -226,9 +226,10 @@ def test_baseline_configs_2_and_4_at_full_size(gpu, oracle):
     """BASELINE.json configs[1] at its full size, every byte: 1e9 samples of the sequential reference stream
     (init = 1, 16 warm-up steps as the reference's test skips, rng.py:161-162) against the oracle's single
     sequential pass (~25 s of one host core).  Covers every segment seam, every round and the ragged tail.
-    The same oracle stream then prices three points of configs[3] (1e9 bits each, PRBS-31, one sample per
-    bit): the channel of tx.py:75-81 / rx.py:29 evaluated with numpy on the host must give the fused kernel's
-    error counts exactly."""
+    The same oracle stream then prices ALL ELEVEN points of configs[3] (Eb/N0 0..10 dB, 1e9 bits each, PRBS-31,
+    one sample per bit): the channel of tx.py:75-81 / rx.py:29 evaluated on the host over the joint histogram of
+    (oracle sample, oracle PRBS bit) must give the fused kernel's error counts exactly; one of the points is also
+    priced sample by sample."""
     n = 1_000_000_000
     u = gpu.LUTOPT.shipped(256)
     got = gpu.CLTGRNG(u).generate(n, first_step=16).cpu().numpy()
@@ -243,14 +244,28 @@ def test_baseline_configs_2_and_4_at_full_size(gpu, oracle):
     words, _ = oracle.prbs_packed(31, n, fast=True)
     bits = np.unpackbits(words.view(np.uint8), bitorder="little")[:n].astype(bool)
     nv = 8
-    trials = [gpu.Trial(nbits=n, amp=gpu.channel.amp_for_ebn0(db, nv), noise_var=nv, prbs_k=31, warmup=16) for db in (0, 5, 10)]
+    trials = [gpu.Trial(nbits=n, amp=gpu.channel.amp_for_ebn0(db, nv), noise_var=nv, prbs_k=31, warmup=16) for db in range(11)]
     counts = gpu.run_trials(u, trials)
-    noise = exp.astype(np.int16) * np.int16(nv)                    # |g * nv| <= 1024: no 12-bit wrap here
+    # joint histogram: hist[b][g + 128] = number of positions with PRBS bit b and CLT sample g
+    idx = exp.view(np.uint8) ^ np.uint8(0x80)
+    hist = [np.bincount(idx[~bits], minlength=256).astype(np.int64), np.bincount(idx[bits], minlength=256).astype(np.int64)]
+    assert hist[0].sum() + hist[1].sum() == n
+    g = np.arange(-128, 128, dtype=np.int64)
+    wrap12 = lambda v: ((v + 2048) & 4095) - 2048
     for t, (nb, ne) in zip(trials, counts):
-        lvl = np.where(bits, np.int16(t.amp), np.int16(-t.amp))
-        rx = ((lvl + noise + 2048) & 4095) - 2048                  # 12-bit signed register (tx.py:80-81)
-        errors = int(np.count_nonzero((rx >= 0) != bits))          # rx.py:29
+        errors = 0
+        for b in (0, 1):
+            rx = wrap12((t.amp if b else -t.amp) + wrap12(g * nv))     # tx.py:75-81
+            errors += int(hist[b][(rx >= 0) != bool(b)].sum())          # rx.py:29
         assert (nb, ne) == (n, errors), (t.amp, ne, errors)
+        # the Gaussian prediction for this integer channel (the CLT tails are slightly lighter)
+        assert 0.8 < (ne / nb) / gpu.channel.ber_lattice(t.amp, nv) < 1.05, (t.amp, ne / nb, gpu.channel.ber_lattice(t.amp, nv))
+    # one point sample by sample as well (12-bit registers written out)
+    t, (nb, ne) = trials[5], counts[5]
+    noise = exp.astype(np.int16) * np.int16(nv)
+    lvl = np.where(bits, np.int16(t.amp), np.int16(-t.amp))
+    rx = ((lvl + noise + 2048) & 4095) - 2048
+    assert ne == int(np.count_nonzero((rx >= 0) != bits))
 
 
 @pytest.mark.parametrize("n", (16, 4096, 1_000_000 - 64, 1_000_003))
