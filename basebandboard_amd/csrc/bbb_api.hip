@@ -63,6 +63,7 @@ struct bbb_lutopt {
     int k = 0, W64 = 0, W32 = 0, device = 0;
     bool specialised = false;
     bbb_custom_fill_fn custom_fill = nullptr;   // a kernel built for this very matrix (bbb_lutopt_set_custom_fill)
+    bbb_custom_ber_fn custom_ber = nullptr;     // the BER kernels built for it (bbb_lutopt_set_custom_ber)
     int small_fast = 0;          // 16 / 32 / 64 / 128 when (k, taps) is the shipped matrix a generated small kernel exists for
     hipStream_t stream = nullptr;
     std::vector<uint16_t> taps;
@@ -350,7 +351,9 @@ int channel_thresholds(int amp, int noise_var, TrialDev *t) {
 }
 
 int ber_run(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, unsigned long long *counters_dev) {
-    if (!h->specialised) return fail(BBB_EUNSUP, "BER trials need the n256 generator");
+    if (!h->specialised && !h->custom_ber)
+        return fail(BBB_EUNSUP, "BER trials need the shipped n256 matrix, or a k = 256 matrix with its own kernels attached "
+                                "(bbb_lutopt_attach_custom_library / LUTOPT.specialise)");
     std::vector<TrialDev> td((size_t)ncfg);
     for (int i = 0; i < ncfg; i++) {
         const bbb_trial_cfg &c = cfgs[i];
@@ -410,7 +413,12 @@ int ber_run(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, unsigned long lo
         uint32_t ps16[256];
         first16(*pp, ps64, ps16);
         if ((rc = awgn_seed_launch(c.prbs_k, pp->d_cols, ps16, G, h->d_pstates, G, nlanes, h->d_pplanes, h->stream))) return rc;
-        if ((rc = ber256_launch(h->d_planes, h->d_pplanes, &td[(size_t)i], n, nlanes, counters_dev + 2 * (size_t)i, h->stream))) return rc;
+        if (h->specialised) {
+            if ((rc = ber256_launch(h->d_planes, h->d_pplanes, &td[(size_t)i], n, nlanes, counters_dev + 2 * (size_t)i, h->stream))) return rc;
+        } else {
+            const int e = h->custom_ber(h->d_planes, h->d_pplanes, &td[(size_t)i], n, nlanes, (uint64_t *)(counters_dev + 2 * (size_t)i), (void *)h->stream);
+            if (e) return fail(e < 0 ? e : BBB_EHIP, "custom BER kernel failed");
+        }
         if ((rc = mark_planes_read(h))) return rc;
         i += n;
     }
@@ -566,6 +574,28 @@ int bbb_lutopt_set_custom_fill(bbb_lutopt *h, bbb_custom_fill_fn fn) {
     h->custom_fill = fn;
     h->planes_valid = false;
     return BBB_OK;
+}
+
+int bbb_lutopt_set_custom_ber(bbb_lutopt *h, bbb_custom_ber_fn fn) {
+    if (!h) return fail(BBB_EINVAL, "null handle");
+    if (fn && h->k != 256) return fail(BBB_EUNSUP, "the fused BER kernels exist for k = 256");
+    h->custom_ber = fn;
+    return BBB_OK;
+}
+
+int bbb_lutopt_attach_custom_library(bbb_lutopt *h, const char *path) {
+    if (!h || !path) return fail(BBB_EINVAL, "null argument");
+    void *lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!lib) return fail(BBB_EIO, std::string("cannot load ") + path + ": " + dlerror());
+    auto order = reinterpret_cast<int (*)(void)>(dlsym(lib, "bbb_custom_order"));
+    auto fill = reinterpret_cast<bbb_custom_fill_fn>(dlsym(lib, "bbb_custom_fill"));
+    if (!order || !fill) return fail(BBB_EIO, std::string(path) + " does not export bbb_custom_order / bbb_custom_fill");
+    if (order() != h->k) return fail(BBB_EINVAL, std::string(path) + " was built for another order");
+    int rc = bbb_lutopt_set_custom_fill(h, fill);
+    if (rc) return rc;
+    auto ber = reinterpret_cast<bbb_custom_ber_fn>(dlsym(lib, "bbb_custom_ber"));
+    if (ber && h->k == 256) rc = bbb_lutopt_set_custom_ber(h, ber);
+    return rc;
 }
 
 int bbb_lutopt_is_specialised(const bbb_lutopt *h) { return h && h->specialised ? 1 : 0; }

@@ -104,3 +104,22 @@ extern "C" int bbb_custom_fill(const uint32_t *planes_dev, int8_t *dst_dev, uint
     return (int)hipGetLastError();
 }
 extern "C" int bbb_custom_order(void) { return BBB_N; }
+
+#if BBB_N == 256
+// the fused BER trial kernels over this matrix's network (the signature of bbb_custom_ber_fn, include/bbb.h)
+#include "bbb_common.hpp"
+#include "awgn_launch.hpp"
+namespace bbb {
+std::string &last_error() {
+    static thread_local std::string s;
+    return s;
+}
+}  // namespace bbb
+#include "ber_kernels_impl.hpp"
+extern "C" int bbb_custom_ber(const uint32_t *planes_dev, const uint32_t *prbs_planes_dev, const void *trials, int ncfg,
+                              uint32_t nlanes, uint64_t *counters_dev, void *hip_stream) {
+    return bbb::ber256_launch(planes_dev, prbs_planes_dev, (const bbb::TrialDev *)trials, ncfg, nlanes,
+                              (unsigned long long *)counters_dev, (hipStream_t)hip_stream);
+}
+extern "C" const char *bbb_custom_last_error(void) { return bbb::last_error().c_str(); }
+#endif

@@ -1,0 +1,373 @@
+#!/usr/bin/env python3
+"""Emit the straight-line bit-sliced LUTOPT step + CLT vertical counter for one matrix.
+
+Input : a recurrence matrix in the reference's text format (software/rnghunt/matrices/N,
+        shipped as packed tap lists in basebandboard_amd/data/lutopt_N.taps).
+Output: a C++ include for the HIP kernels with
+
+  lutoptN_step(a, b, cnt)   b = A*a over GF(2) on 32 generators per lane
+                            (gateware/bbb/rng.py:38-40: row r = XOR of its taps, all rows
+                            from the OLD state), and cnt[0..7] = the bit planes of the int8
+                            CLTGRNG sample of the OLD state a (rng.py:96-108).
+  lutoptN_advance(a, b)     b = A*a only.
+  lutoptN_step_new(a,b,cnt) b = A*a and cnt = sample of the NEW state b.
+  lutopt256_step_parked(a, pa, b, pb, cnt)   lutopt256_step with a chosen set of planes travelling in AGPRs.
+
+The counter reads the OLD state so that it can share work with the update: a first-level full
+adder over y_a, y_b, y_c has the sum output x_a ^ x_b ^ x_c (possibly complemented) -- exactly the
+partial XOR of a row whose taps include a, b, c.  A set of disjoint triples, each inside the tap
+list of a distinct row, is chosen (`shared_triples`); for those the row's V_BITOP3(0x96) IS the
+adder's sum and only the carry costs an extra instruction.
+
+Bit-sliced arithmetic.  Register p holds state bit p of 32 independent generators.
+The adder tree of rng.py:96-105 equals sum_i (-1)^popcount(i) x[i]; with
+y_i = x_i (popcount(i) even) or 1 - x_i (odd), T = sum_i y_i lies in [0, n] and the
+log2(n)-bit signed output is (T - n/2) mod n: for n = 256 the low 8 bits of T with bit 7
+flipped.  T is formed by a carry-save adder network whose cells are single gfx950
+V_BITOP3_B32 instructions (sum = 3-input XOR, carry = majority), with the input
+inversions folded into the truth tables.
+
+Usage: gen_lutopt_kernel.py <matrix.txt> <out.inc>
+"""
+import sys
+import zlib
+
+
+def load(path):
+    """Packed tap lists (one row per line) or the reference's 0/1 text matrix."""
+    rows = [l.strip() for l in open(path) if l.strip()]
+    n = len(rows)
+    if n > 1 and all(set(r) <= {"0", "1"} and len(r) == n for r in rows):
+        return n, [[c for c, ch in enumerate(r) if ch == "1"] for r in rows]
+    return n, [[int(x) for x in r.split()] for r in rows]
+
+
+def tt3(f, inv):
+    """8-bit truth table of f(a^inv0, b^inv1, c^inv2) in BITOP3 order (a=0xF0, b=0xCC, c=0xAA)."""
+    t = 0
+    for idx in range(8):
+        a, b, c = (idx >> 2) & 1, (idx >> 1) & 1, idx & 1
+        if f(a ^ inv[0], b ^ inv[1], c ^ inv[2]):
+            t |= 1 << idx
+    return t
+
+
+def row_order(n, taps):
+    """Greedy order of row evaluation that retires old planes early (register pressure)."""
+    uses = [0] * n
+    for r in range(n):
+        for c in taps[r]:
+            uses[c] += 1
+    remaining = set(range(n))
+    left = uses[:]
+    order = []
+    while remaining:
+        best, best_key = None, None
+        for r in remaining:
+            kills = sum(1 for c in taps[r] if left[c] == 1)
+            near = sum(1.0 / left[c] for c in taps[r])
+            key = (kills, near, -r)
+            if best_key is None or key > best_key:
+                best, best_key = r, key
+        order.append(best)
+        remaining.remove(best)
+        for c in taps[best]:
+            left[c] -= 1
+    return order
+
+
+def shared_triples(n, taps, tries=40, seed=1):
+    """Disjoint state-bit triples, each a subset of the taps of a distinct row: {row: triple}.
+    Greedy, most constrained first (smallest number of still-possible triples over its three bits),
+    random tie-breaking, best of `tries` (84 of the 85 possible for n256)."""
+    import itertools
+    import random
+    cands = [(r, tr) for r in range(n) for tr in itertools.combinations(taps[r], 3)]
+    by_bit = [[] for _ in range(n)]
+    for i, (_, tr) in enumerate(cands):
+        for b in tr:
+            by_bit[b].append(i)
+    best = []
+    for t in range(tries):
+        rnd = random.Random(seed * 1000003 + t)
+        alive = [True] * len(cands)
+        deg = [len(x) for x in by_bit]
+        m = []
+        while True:
+            pick, pick_key = None, None
+            for i, (_, tr) in enumerate(cands):
+                if alive[i]:
+                    key = deg[tr[0]] + deg[tr[1]] + deg[tr[2]] + 3 * rnd.random()
+                    if pick_key is None or key < pick_key:
+                        pick, pick_key = i, key
+            if pick is None:
+                break
+            r, tr = cands[pick]
+            m.append((r, tr))
+            for i, (r2, tr2) in enumerate(cands):
+                if alive[i] and (r2 == r or set(tr2) & set(tr)):
+                    alive[i] = False
+                    for b in tr2:
+                        deg[b] -= 1
+        if len(m) > len(best):
+            best = m
+    return {r: tr for r, tr in best}
+
+
+def parking_set(n, taps, order, budget):
+    """Planes to keep in AGPRs between their birth and their first reader in the next step, so
+    that at most `budget` planes are VGPR-resident at any row position.  Model of one steady-state
+    step in row order: a plane that is not parked is resident from its birth to the end of the
+    step (new) and from the start to its last reader (old); a parked plane only from its first to
+    its last reader.  Greedy: park the plane that removes the most excess."""
+    pos = {r: i for i, r in enumerate(order)}
+    rd = [[] for _ in range(n)]
+    for r in range(n):
+        for c in taps[r]:
+            rd[c].append(pos[r])
+    first = [min(x) for x in rd]
+    last = [max(x) for x in rd]
+    born = [pos[p] for p in range(n)]
+
+    def resident(p, t, parked):
+        if parked:
+            return 1 if first[p] <= t <= last[p] else 0
+        return (1 if last[p] >= t else 0) + (1 if born[p] <= t else 0)
+
+    parked = set()
+    while True:
+        prof = [sum(resident(p, t, p in parked) for p in range(n)) for t in range(n)]
+        exc = [max(0, x - budget) for x in prof]
+        if not any(exc):
+            return parked
+        best, gain = None, 0
+        for p in range(n):
+            if p in parked:
+                continue
+            g = sum(resident(p, t, False) - resident(p, t, True) for t in range(n) if exc[t])
+            if g > gain:
+                best, gain = p, g
+        if best is None:
+            return parked
+        parked.add(best)
+
+
+class StepEmitter:
+    """Emits one straight-line function body.  mode: 'advance' (update only), 'step' (update +
+    sample of the old state).  parked: planes whose old value arrives in pa[] (AGPR) and whose new
+    value leaves in pb[] (AGPR) through BBB_ACC_READ / BBB_ACC_WRITE."""
+
+    def __init__(self, n, taps, order, share, mode, parked=()):
+        self.n, self.taps, self.order, self.share = n, taps, order, share
+        self.mode, self.parked = mode, set(parked)
+        self.logn = n.bit_length() - 1
+        self.out = []
+        self.nops = 0
+        self.nmoves = 0
+        self.tmp_id = 0
+        self.levels = [[] for _ in range(self.logn + 2)]
+        self.inv_of = [bin(c).count("1") & 1 for c in range(n)]   # weight -1 positions enter complemented
+        self.loaded = {}                                          # parked plane -> expression of its VGPR copy
+
+    def emit(self, s):
+        self.out.append(s)
+
+    def tmp(self):
+        self.tmp_id += 1
+        return f"t{self.tmp_id}"
+
+    def old(self, c):
+        if c not in self.parked:
+            return f"a[{c}]"
+        if c not in self.loaded:
+            v = self.tmp()
+            self.emit(f"  uint32_t {v}; BBB_ACC_READ({v}, pa[{c}]);")
+            self.nmoves += 1
+            self.loaded[c] = v
+        return self.loaded[c]
+
+    def push(self, level, item):
+        nlev = self.logn
+        if level >= nlev:
+            return       # carries out of the top output bit are never needed
+        lv = self.levels[level]
+        lv.append(item)
+        while len(lv) >= 3:
+            (a, ia), (b, ib), (c, ic) = lv[:3]
+            del lv[:3]
+            s = self.tmp()
+            self.emit(f"  const uint32_t {s} = __builtin_amdgcn_bitop3_b32({a}, {b}, {c}, 0x{tt3(lambda x, y, z: x ^ y ^ z, (ia, ib, ic)):02x});")
+            self.nops += 1
+            if level + 1 < nlev:
+                cy = self.tmp()
+                self.emit(f"  const uint32_t {cy} = __builtin_amdgcn_bitop3_b32({a}, {b}, {c}, 0x{tt3(lambda x, y, z: (x & y) | (x & z) | (y & z), (ia, ib, ic)):02x});")
+                self.nops += 1
+                self.push(level + 1, (cy, 0))
+            lv.append((s, 0))
+
+    def assign_new(self, r, terms):
+        """new plane r = XOR of `terms` (expressions), three at a time"""
+        dst = f"b[{r}]"
+        if r in self.parked:
+            dst = self.tmp()
+        decl = "const uint32_t " if r in self.parked else ""
+        while len(terms) > 3 or (len(terms) == 3 and False):
+            x, terms = terms[:3], terms[3:]
+            v = self.tmp()
+            self.emit(f"  const uint32_t {v} = __builtin_amdgcn_bitop3_b32({x[0]}, {x[1]}, {x[2]}, 0x96);")
+            self.nops += 1
+            terms.insert(0, v)
+        if len(terms) == 3:
+            self.emit(f"  {decl}{dst} = __builtin_amdgcn_bitop3_b32({terms[0]}, {terms[1]}, {terms[2]}, 0x96);")
+            self.nops += 1
+        elif len(terms) == 2:
+            self.emit(f"  {decl}{dst} = {terms[0]} ^ {terms[1]};")
+            self.nops += 1
+        else:
+            self.emit(f"  {decl}{dst} = {terms[0]};")
+        if r in self.parked:
+            self.emit(f"  BBB_ACC_WRITE(pb[{r}], {dst});")
+            self.nmoves += 1
+
+    def body(self):
+        n, taps, share = self.n, self.taps, self.share
+        nlev = self.logn
+        counting = self.mode == "step"
+        covered = set(c for tr in share.values() for c in tr) if counting else set()
+        pushed = set()
+        for r in self.order:
+            t = taps[r]
+            assert 1 <= len(t) <= 8
+            if self.mode == "step_new":
+                self.assign_new(r, [self.old(c) for c in t])
+                self.push(0, (f"b[{r}]", self.inv_of[r]))
+                continue
+            if counting and r in share:
+                tr = share[r]
+                iv = tuple(self.inv_of[c] for c in tr)
+                x = [self.old(c) for c in tr]
+                v = self.tmp()
+                self.emit(f"  const uint32_t {v} = __builtin_amdgcn_bitop3_b32({x[0]}, {x[1]}, {x[2]}, 0x96);   // row {r} partial = adder sum")
+                self.nops += 1
+                cy = None
+                if nlev > 1:
+                    cy = self.tmp()
+                    self.emit(f"  const uint32_t {cy} = __builtin_amdgcn_bitop3_b32({x[0]}, {x[1]}, {x[2]}, 0x{tt3(lambda p, q, z: (p & q) | (p & z) | (q & z), iv):02x});")
+                    self.nops += 1
+                self.assign_new(r, [v] + [self.old(c) for c in t if c not in tr])
+                if cy is not None:
+                    self.push(1, (cy, 0))
+                self.push(0, (v, iv[0] ^ iv[1] ^ iv[2]))
+            else:
+                self.assign_new(r, [self.old(c) for c in t])
+            if counting:
+                for c in t:              # state bits outside every shared triple enter the counter singly
+                    if c not in covered and c not in pushed:
+                        pushed.add(c)
+                        self.push(0, (self.old(c), self.inv_of[c]))
+        if self.mode == "advance":
+            return
+        if counting:
+            assert len(pushed) + len(covered) == n, "a state bit that no row reads is not summed"
+        # ---- finish the counter: ripple the leftovers up ------------------------------------
+        for lev in range(nlev):
+            lv = self.levels[lev]
+            while len(lv) > 1:
+                assert len(lv) == 2
+                (a, ia), (b, ib) = lv
+                del lv[:]
+                s = self.tmp()
+                self.emit(f"  const uint32_t {s} = __builtin_amdgcn_bitop3_b32({a}, {b}, {b}, 0x{tt3(lambda x, y, z: x ^ y, (ia, ib, ib)):02x});")
+                self.nops += 1
+                if lev + 1 < nlev:
+                    cy = self.tmp()
+                    self.emit(f"  const uint32_t {cy} = __builtin_amdgcn_bitop3_b32({a}, {b}, {b}, 0x{tt3(lambda x, y, z: x & y, (ia, ib, ib)):02x});")
+                    self.nops += 1
+                    self.push(lev + 1, (cy, 0))
+                lv.append((s, 0))
+            (x, ix), = lv
+            assert ix == 0
+            if lev == nlev - 1:
+                self.emit(f"  cnt[{lev}] = ~{x};   // (T - n/2) mod n: flip the top output bit")
+                self.nops += 1
+            else:
+                self.emit(f"  cnt[{lev}] = {x};")
+
+
+# (suffix, planes resident in VGPRs at any point) of the parked variants (n = 256 only).  180 is the
+# measured optimum for the sample kernel: above it hipcc adds its own AGPR spills on top
+PARK_VARIANTS = (("", 180),)
+
+
+def generate(n, taps):
+    logn = n.bit_length() - 1
+    assert 1 << logn == n and n >= 16
+    out = []
+    emit = out.append
+    emit(f"// GENERATED by tools/gen_lutopt_kernel.py from lutopt_{n}.taps -- do not edit.")
+    flat = ",".join(",".join(map(str, t)) for t in taps)
+    emit(f"#define LUTOPT{n}_TAPS_CRC 0x{zlib.crc32(flat.encode()) & 0xffffffff:08x}u")
+    order = row_order(n, taps)
+    share = shared_triples(n, taps)
+
+    e = StepEmitter(n, taps, order, share, "advance")
+    e.body()
+    emit(f"static __device__ __forceinline__ void lutopt{n}_advance(const uint32_t (&a)[{n}], uint32_t (&b)[{n}])")
+    emit("{")
+    out.extend(e.out)
+    emit("}")
+    emit(f"// {e.nops} VALU ops")
+
+    e = StepEmitter(n, taps, order, share, "step")
+    e.body()
+    nops = e.nops
+    emit(f"static __device__ __forceinline__ void lutopt{n}_step(const uint32_t (&a)[{n}], uint32_t (&b)[{n}], uint32_t (&cnt)[{logn}])")
+    emit("{")
+    out.extend(e.out)
+    emit("}")
+    emit(f"// {nops} VALU ops per step for 32 samples per lane")
+
+    e = StepEmitter(n, taps, order, share, "step_new")
+    e.body()
+    emit(f"// b = A*a and cnt = sample of the NEW state b (no sharing with the update: {e.nops} ops); for kernels with many")
+    emit("// other live values, where hipcc allocates this form better")
+    emit(f"static __device__ __forceinline__ void lutopt{n}_step_new(const uint32_t (&a)[{n}], uint32_t (&b)[{n}], uint32_t (&cnt)[{logn}])")
+    emit("{")
+    out.extend(e.out)
+    emit("}")
+
+    if n == 256:
+        emit("// Variants with explicit register-file placement: planes in LUTOPT256_PARKED* live in AGPRs (pa/pb) from")
+        emit("// birth to their first reader of the next step; BBB_ACC_READ / BBB_ACC_WRITE are v_accvgpr moves.")
+        emit("#ifndef BBB_ACC_WRITE   // (a host build of this text defines them as plain assignments)")
+        emit('#define BBB_ACC_WRITE(dst, src) asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(dst) : "v"(src))')
+        emit('#define BBB_ACC_READ(dst, src) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(dst) : "a"(src))')
+        emit("#endif")
+        for suffix, budget in PARK_VARIANTS:
+            parked = sorted(parking_set(n, taps, order, budget))
+            e = StepEmitter(n, taps, order, share, "step", parked)
+            e.body()
+            S = suffix.upper()
+            emit(f"#define LUTOPT{n}_NPARKED{S} {len(parked)}")
+            emit(f"static const uint16_t LUTOPT{n}_PARKED{S}[{len(parked)}] = {{{','.join(map(str, parked))}}};")
+            emit(f"#define LUTOPT{n}_FOR_PARKED{S}(F) " + " ".join(f"F({p})" for p in parked))
+            emit(f"static __device__ __forceinline__ void lutopt{n}_step_parked{suffix}(const uint32_t (&a)[{n}], const uint32_t (&pa)[{n}], uint32_t (&b)[{n}], uint32_t (&pb)[{n}], uint32_t (&cnt)[{logn}])")
+            emit("{")
+            out.extend(e.out)
+            emit("}")
+            emit(f"// {e.nops} VALU ops + {e.nmoves} AGPR moves per step (at most {budget} planes in VGPRs)")
+    # packed taps for the host-side identity check
+    emit(f"static const uint16_t LUTOPT{n}_NTAPS[{n}] = {{{','.join(str(len(t)) for t in taps)}}};")
+    emit(f"static const uint16_t LUTOPT{n}_TAPS[{sum(len(t) for t in taps)}] = {{{flat}}};")
+    return "\n".join(out) + "\n", nops
+
+
+def main():
+    n, taps = load(sys.argv[1])
+    text, nops = generate(n, taps)
+    open(sys.argv[2], "w").write(text)
+    print(f"n={n}: {nops} ops/step -> {sys.argv[2]}")
+
+
+if __name__ == "__main__":
+    main()

@@ -95,8 +95,9 @@ class LUTOPT:
 
     def specialise(self, build_dir=None, hipcc="/opt/rocm/bin/hipcc"):
         """Build and attach a sample kernel for THIS matrix (for matrices that are not among the shipped ones,
-        e.g. a result of gf2.search): tools/gen_lutopt_kernel.py emits the straight-line network, hipcc compiles
-        csrc/custom_fill_template.hip around it for gfx950, bbb_lutopt_set_custom_fill attaches the result.
+        e.g. a result of gf2.search): basebandboard_amd/gen_lutopt_kernel.py emits the straight-line network, hipcc
+        compiles csrc/custom_fill_template.hip around it for gfx950, bbb_lutopt_attach_custom_library attaches the
+        result: the sample kernel and, for k = 256, the fused BER trial kernels.
         Cached under `build_dir` (default ~/.cache/basebandboard_amd) by the hash of the tap lists.  Needs hipcc
         on this machine; power-of-two k <= 256.  Returns the path of the library."""
         import hashlib
@@ -114,17 +115,14 @@ class LUTOPT:
             work.mkdir(parents=True, exist_ok=True)
             taps = work / f"lutopt_{self.k}.taps"
             taps.write_text("".join(" ".join(map(str, r)) + "\n" for r in self.packed))
-            subprocess.check_call([sys.executable, str(root.parent / "tools" / "gen_lutopt_kernel.py"), str(taps), str(work / "custom_gen.inc")])
+            subprocess.check_call([sys.executable, str(root / "gen_lutopt_kernel.py"), str(taps), str(work / "custom_gen.inc")])
             tmp = work / (so.name + ".tmp")
             subprocess.check_call([hipcc, "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", f"-DBBB_N={self.k}",
-                                   f"-DBBB_LOG={self.k.bit_length() - 1}", f"-I{work}", f"-I{root / 'csrc'}",
+                                   f"-DBBB_LOG={self.k.bit_length() - 1}", f"-I{work}", f"-I{root / 'csrc'}", "-Wno-unused-function",
                                    str(root / "csrc" / "custom_fill_template.hip"), "-o", str(tmp)])
             tmp.replace(so)
-        lib = C.CDLL(str(so))
-        if lib.bbb_custom_order() != self.k:
-            raise RuntimeError(f"{so} was built for another order")
-        _lib.check(_lib.lib().bbb_lutopt_set_custom_fill(self._h, C.cast(lib.bbb_custom_fill, C.c_void_p)), "bbb_lutopt_set_custom_fill")
-        self._custom = lib                   # keeps the code object loaded as long as the handle lives
+        _lib.check(_lib.lib().bbb_lutopt_attach_custom_library(self._h, str(so).encode()), "bbb_lutopt_attach_custom_library")
+        self._custom = so
         return so
 
     def state_at(self, nsteps):

@@ -179,6 +179,17 @@ int bbb_prbs_detector_stream(int k, const uint64_t *bits_packed_dev, uint64_t nb
 typedef int (*bbb_custom_fill_fn)(const uint32_t *planes_dev, int8_t *dst_dev, uint64_t nsamples, uint32_t L, uint64_t G,
                                   uint32_t nlanes, void *hip_stream);
 int bbb_lutopt_set_custom_fill(bbb_lutopt *h, bbb_custom_fill_fn fn);
+/* The same for the fused BER trial (k = 256 only): `trials` points at the library's internal per-trial records
+ * (csrc/awgn_launch.hpp, TrialDev) and is passed through unchanged; returns 0 or a BBB_E* code. */
+typedef int (*bbb_custom_ber_fn)(const uint32_t *planes_dev, const uint32_t *prbs_planes_dev, const void *trials, int ncfg,
+                                 uint32_t nlanes, uint64_t *counters_dev, void *hip_stream);
+int bbb_lutopt_set_custom_ber(bbb_lutopt *h, bbb_custom_ber_fn fn);
+/* Load a library built from csrc/custom_fill_template.hip for THIS handle's matrix (basebandboard_amd/
+ * gen_lutopt_kernel.py <taps> custom_gen.inc; hipcc --offload-arch=gfx950 -shared -DBBB_N=k -DBBB_LOG=log2 k ...)
+ * and attach what it exports: the sample kernel (bbb_custom_fill) and, for k = 256, the BER kernels
+ * (bbb_custom_ber).  The C-ABI form of LUTOPT.specialise(): a host without Python generates and compiles the
+ * library at build time and attaches it here.  The library stays loaded for the life of the process. */
+int bbb_lutopt_attach_custom_library(bbb_lutopt *h, const char *path);
 
 /* ---- fused Monte-Carlo trial: PRBS -> BPSK + scaled CLT noise -> slicer -> error count --- */
 

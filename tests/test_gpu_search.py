@@ -102,3 +102,32 @@ def test_found_matrix_gets_its_own_kernel(gpu, oracle, tmp_path, k):
     u2 = bbb.LUTOPT.from_packed(rows, init=5)
     u2.specialise(build_dir=tmp_path)
     assert np.array_equal(bbb.CLTGRNG(u2).generate(10_000).cpu().numpy(), m.awgn(5, 0, 10_000))
+
+
+def test_found_k256_matrix_runs_ber_trials_and_tx(gpu, oracle, tmp_path):
+    """Search -> use, for the Monte-Carlo loop as well: a k = 256 matrix that is NOT the shipped one gets, through
+    LUTOPT.specialise() (= bbb_lutopt_attach_custom_library), its own sample kernel AND its own fused BER kernels;
+    counters equal the oracle's for that matrix.  Before, bbb_ber_trials refused every matrix but the shipped n256."""
+    bbb = gpu
+    # a permuted copy of the shipped matrix: conjugation by a permutation keeps the period, changes every tap list
+    import random
+    rnd = random.Random(7)
+    perm = list(range(256))
+    rnd.shuffle(perm)
+    inv = [0] * 256
+    for i, p in enumerate(perm):
+        inv[p] = i
+    base = bbb.recurrences.load_packed(bbb.recurrences.matrix_path(256))
+    rows = [sorted(perm[c] for c in base[inv[r]]) for r in range(256)]
+    assert rows != base
+    u = bbb.LUTOPT.from_packed(rows, init=0xABCDEF)
+    assert not u.specialised
+    t = [bbb.Trial(nbits=200_003, amp=a, noise_var=nv, prbs_k=k) for a, nv, k in ((100, 8, 31), (64, 8, 31), (37, 3, 9))]
+    with pytest.raises(bbb._lib.BbbError) as e:
+        bbb.run_trials(u, t)
+    assert e.value.code == bbb._lib.BBB_EUNSUP
+    u.specialise(build_dir=tmp_path)
+    m = oracle.Lutopt(packed=rows)
+    got = bbb.run_trials(u, t)
+    assert got == [m.ber_trial(0xABCDEF, x.prbs_k, 1, x.amp, x.noise_var, 16, 0, x.nbits) for x in t]
+    assert np.array_equal(bbb.CLTGRNG(u).generate(100_000, first_step=16).cpu().numpy(), m.awgn(0xABCDEF, 16, 100_000))
