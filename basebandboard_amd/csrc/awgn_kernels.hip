@@ -209,12 +209,18 @@ struct TxFuse {
     int32_t bit_en;           // 0: shaped = 0 (tx.py:65-66)
     int32_t use_bits;         // 0: every data bit reads as 0
     uint32_t last_word;       // index of the last 32-bit word of the buffer that may be read
+    int32_t low_prio;         // (experiments) run at the default wave priority instead of the highest
 };
 
 typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
 typedef int16_t i16x2 __attribute__((ext_vector_type(2)));
 
-template <bool TX>
+// STAGED: the pieces go to a staging buffer laid out [round][generator slot][piece] instead of their final place
+// g L + 16 r: a store instruction then writes 64 consecutive pieces (full lines) where the final layout makes it
+// touch 64 different lines, L bytes apart -- 62.5 M scattered 16-byte pieces per 1e9 samples, which cost one DRAM
+// row activation each and bound the kernel together with its arithmetic.  unstage_kernel moves the pieces to
+// their final place with full-line reads AND writes, beside the next fill's arithmetic (bbb_api.hip).
+template <bool TX, bool STAGED>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 awgn256_kernel(const uint32_t *__restrict planes, void *__restrict dst_, unsigned long long nsamples,
                unsigned L, unsigned long long G, unsigned nlanes, TxFuse tx) {
@@ -225,7 +231,8 @@ awgn256_kernel(const uint32_t *__restrict planes, void *__restrict dst_, unsigne
     const unsigned long long LG = wave * 64 + lane;
     // highest wave priority: when the seeding of the next fill (bbb_awgn_prefetch) shares the SIMD it gets the
     // issue slots this wave leaves free instead of every other one
-    __builtin_amdgcn_s_setprio(3);
+    if (tx.low_prio) __builtin_amdgcn_s_setprio(0);
+    else __builtin_amdgcn_s_setprio(3);
 
     uint32_t selmask[4] = {0, 0, 0, 0};
     if (TX) {
@@ -273,24 +280,25 @@ awgn256_kernel(const uint32_t *__restrict planes, void *__restrict dst_, unsigne
 #pragma unroll
             for (int i = 0; i < 8; i++) Z[((2 * tt + 1) * 8 + i) * 64 + lane] = cnt[i];
         }
-#pragma unroll 1
-        for (unsigned i = 0; i < 8; i++) {
-            // TX: the data-bit windows of this iteration's four generators, issued before the LDS work
-            uint32_t wlo[4] = {0, 0, 0, 0}, whi[4] = {0, 0, 0, 0}, wsh[4] = {0, 0, 0, 0};
-            if (TX) {
+        // TX: the data-bit windows of this lane's generators, ONE load each (32 bits from the byte that holds the window's
+        // first bit), 16 of them issued together ahead of the four iterations that use them -- their latency, which the
+        // piece mover's and the stores' traffic stretches to microseconds, is exposed twice per round and not eight times
+        auto load_windows = [&](const unsigned ihalf, uint32_t (&win)[16]) {
 #pragma unroll
-                for (unsigned q = 0; q < 4; q++) {
-                    const unsigned long long g = gen_index(wave, lane, 8 * q + i);
-                    if (g < G && tx.use_bits) {
-                        const uint32_t off = (uint32_t)g * L + r * 16u;                 // fits 32 bits (host check)
-                        const uint32_t rel = (off >> 3) + tx.rel_base;
-                        const uint32_t wi = min(rel >> 5, tx.last_word - 1u);           // (rounds past the end of the request)
-                        wlo[q] = tx.bits[wi];
-                        whi[q] = tx.bits[wi + 1];
-                        wsh[q] = rel & 31u;
-                    }
+            for (unsigned e = 0; e < 16; e++) {
+                const unsigned j = 8 * (e >> 2) + 4 * ihalf + (e & 3);                  // generator j = 8 q + i, q = e >> 2
+                const unsigned long long g = gen_index(wave, lane, j);
+                win[e] = 0;
+                if (g < G && tx.use_bits) {
+                    const uint32_t off = (uint32_t)g * L + r * 16u;                     // fits 32 bits (host check)
+                    const uint32_t rel = (off >> 3) + tx.rel_base;
+                    const uint32_t byte = min(rel >> 3, tx.last_word * 4u - 4u);        // (rounds past the end of the request)
+                    typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+                    win[e] = *reinterpret_cast<const u32_unaligned *>(reinterpret_cast<const char *>(tx.bits) + byte);
                 }
             }
+        };
+        auto round_end = [&](const unsigned i, const uint32_t (&w4)[4]) {
             uint32_t o[4][4];                 // o[w][q] after the transposes
 #pragma unroll
             for (int w = 0; w < 4; w++) {
@@ -305,11 +313,14 @@ awgn256_kernel(const uint32_t *__restrict planes, void *__restrict dst_, unsigne
             for (unsigned q = 0; q < 4; q++) {
                 const unsigned long long g = gen_index(wave, lane, 8 * q + i);
                 const unsigned long long off = g * L + (unsigned long long)r * 16;
-                if (!(g < G && off < nsamples)) continue;
+                if (!(g < G && off < nsamples)) continue;   // (the q loop)
+                const unsigned long long slot = (unsigned long long)r * ((unsigned long long)nlanes * 32) + g;   // STAGED
                 if (!TX) {
                     int8_t *dst = (int8_t *)dst_;
                     const u32x4 v = {o[0][q], o[1][q], o[2][q], o[3][q]};
-                    if (off + 16 <= nsamples) {
+                    if (STAGED) {
+                        reinterpret_cast<u32x4 *>(dst_)[slot] = v;
+                    } else if (off + 16 <= nsamples) {
                         *reinterpret_cast<u32x4 *>(dst + off) = v;
                     } else {
                         const unsigned n = (unsigned)(nsamples - off);
@@ -318,7 +329,8 @@ awgn256_kernel(const uint32_t *__restrict planes, void *__restrict dst_, unsigne
                 } else {
                     int16_t *dst = (int16_t *)dst_;
                     // 10-bit window: bit j = data bit M0 - 7 + j; rows of the three window shifts (16 bytes each)
-                    const uint32_t Q4 = (__builtin_amdgcn_alignbit(whi[q], wlo[q], wsh[q]) & 0x3ffu) << 4;
+                    const uint32_t rel_q = (((uint32_t)g * L + r * 16u) >> 3) + tx.rel_base;
+                    const uint32_t Q4 = ((w4[q] >> (rel_q & 7u)) & 0x3ffu) << 4;
                     const u32x4 A = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(TT) + (Q4 & 0xff0u));
                     const u32x4 B = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(TT) + ((Q4 >> 1) & 0xff0u));
                     const u32x4 C = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(TT) + ((Q4 >> 2) & 0xff0u));
@@ -338,7 +350,11 @@ awgn256_kernel(const uint32_t *__restrict planes, void *__restrict dst_, unsigne
                         x[2 * w] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(i16x2, m01) >> 4);
                         x[2 * w + 1] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(i16x2, m23) >> 4);
                     }
-                    if (off + 16 <= nsamples) {
+                    if (STAGED) {
+                        const u32x4 lo = {x[0], x[1], x[2], x[3]}, hi = {x[4], x[5], x[6], x[7]};
+                        reinterpret_cast<u32x4 *>(dst_)[2 * slot] = lo;
+                        reinterpret_cast<u32x4 *>(dst_)[2 * slot + 1] = hi;
+                    } else if (off + 16 <= nsamples) {
                         const u32x4 lo = {x[0], x[1], x[2], x[3]}, hi = {x[4], x[5], x[6], x[7]};
                         reinterpret_cast<u32x4 *>(dst + off)[0] = lo;
                         reinterpret_cast<u32x4 *>(dst + off)[1] = hi;
@@ -348,8 +364,123 @@ awgn256_kernel(const uint32_t *__restrict planes, void *__restrict dst_, unsigne
                     }
                 }
             }
+        };
+        if (TX) {
+#pragma unroll 1
+            for (unsigned ihalf = 0; ihalf < 2; ihalf++) {
+                uint32_t win[16];
+                load_windows(ihalf, win);
+#pragma unroll
+                for (unsigned ii = 0; ii < 4; ii++) {
+                    const uint32_t w4[4] = {win[ii], win[4 + ii], win[8 + ii], win[12 + ii]};
+                    round_end(4 * ihalf + ii, w4);
+                }
+            }
+        } else {
+            const uint32_t none[4] = {0, 0, 0, 0};
+#pragma unroll 1
+            for (unsigned i = 0; i < 8; i++) round_end(i, none);
         }
     }
+}
+
+// Staging buffer [round][generator slot][PIECE bytes] -> the sequential stream (generator g owns bytes [g Lb, (g+1) Lb)).
+// A wave moves a tile of 8 generators x RT rounds, 16 bytes per lane: lanes that share a round read 128+ consecutive
+// bytes of the staging buffer, lanes that share a generator write 128 consecutive bytes of its segment -- full lines on
+// both sides.  One wave per group of 8 generators, looping over the rounds.
+// Residency: this kernel runs beside the NEXT fill's sample kernel, whose waves need 416 of a SIMD's 512 registers and
+// 32 of a CU's 160 KiB of LDS each and must ALL be resident at once (one generation, static partition).  A grid of many
+// small blocks would keep refilling every freed slot and starve those big waves (measured: the two kernels then run one
+// after the other).  So the mover is persistent and narrow: one block of four waves per CU (<= 96 registers per lane, and
+// an unused 32 KiB of dynamic LDS so that no second block fits beside four sample-kernel waves), each wave looping over
+// its share of the generator groups with 16 loads of 16 bytes in flight per lane.
+template <int PIECE>
+__global__ void __launch_bounds__(256, 5)
+unstage_kernel(const char *__restrict stg, char *__restrict dst, unsigned long long nbytes, unsigned Lb,
+               unsigned long long G, unsigned long long Gpad, unsigned rounds) {
+    constexpr unsigned CP = PIECE / 16;          // 16-byte chunks per piece
+    constexpr unsigned RT = 8 / CP;              // rounds per tile
+    constexpr unsigned NG = 4;                   // groups of 8 generators per trip: with 4 round tiles, 16 loads in flight per lane
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned long long wave0 = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned long long nwaves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
+    const unsigned c = lane % CP, m = lane / CP, gl = m & 7, rl = m >> 3;
+    const unsigned long long sstride = (unsigned long long)RT * Gpad * PIECE;
+    constexpr unsigned dstride = RT * PIECE;
+    const unsigned long long gstride_src = 8ull * PIECE, gstride_dst = 8ull * Lb;
+    const unsigned long long ntrips = (G + 8 * NG - 1) / (8 * NG);
+    for (unsigned long long trip = wave0; trip < ntrips; trip += nwaves) {
+        const unsigned long long g0 = trip * (8 * NG) + gl;
+        if (g0 >= G) continue;
+        // all 64-bit address arithmetic once per trip; the loops below only add (wave-uniform) strides
+        const char *src0 = stg + ((unsigned long long)rl * Gpad + g0) * PIECE + c * 16;
+        const unsigned long long seg0 = g0 * (unsigned long long)Lb;
+        char *out0 = dst + seg0 + rl * PIECE + c * 16;
+        // fast path: all NG groups exist and end inside the request -- no bounds inside the loops
+        if (g0 + 8 * (NG - 1) < G && seg0 + (NG - 1) * gstride_dst + Lb <= nbytes) {
+            unsigned r = rl;
+            for (; r + 3 * RT < rounds; r += 4 * RT) {
+                u32x4 v[NG][4];
+#pragma unroll
+                for (unsigned k = 0; k < NG; k++)
+#pragma unroll
+                    for (unsigned t = 0; t < 4; t++) v[k][t] = *reinterpret_cast<const u32x4 *>(src0 + k * gstride_src + t * sstride);
+#pragma unroll
+                for (unsigned k = 0; k < NG; k++)
+#pragma unroll
+                    for (unsigned t = 0; t < 4; t++) *reinterpret_cast<u32x4 *>(out0 + k * gstride_dst + t * dstride) = v[k][t];
+                src0 += 4 * sstride;
+                out0 += 4 * dstride;
+            }
+            for (; r < rounds; r += RT) {
+                u32x4 v[NG];
+#pragma unroll
+                for (unsigned k = 0; k < NG; k++) v[k] = *reinterpret_cast<const u32x4 *>(src0 + k * gstride_src);
+#pragma unroll
+                for (unsigned k = 0; k < NG; k++) *reinterpret_cast<u32x4 *>(out0 + k * gstride_dst) = v[k];
+                src0 += sstride;
+                out0 += dstride;
+            }
+            continue;
+        }
+        for (unsigned k = 0; k < NG; k++) {       // the last groups: generators may be missing, the request may end inside
+            const unsigned long long g = g0 + 8ull * k;
+            if (g >= G) break;
+            const unsigned long long seg = g * (unsigned long long)Lb;
+            const char *src = src0 + k * gstride_src;
+            for (unsigned r = rl; r < rounds; r += RT, src += sstride) {
+                const unsigned long long off = seg + (unsigned long long)r * PIECE + c * 16;
+                if (off >= nbytes) break;
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(src);
+                if (off + 16 <= nbytes) {
+                    *reinterpret_cast<u32x4 *>(dst + off) = v;
+                } else {
+                    const unsigned n = (unsigned)(nbytes - off);
+                    for (unsigned e = 0; e < n; e++) dst[off + e] = (char)((v[e >> 2] >> (8 * (e & 3))) & 0xff);
+                }
+            }
+        }
+    }
+}
+
+int unstage_launch(const void *stg, void *dst, uint64_t nbytes, unsigned Lb, uint64_t G, uint64_t Gpad, unsigned rounds,
+                   int piece, hipStream_t st) {
+    int dev = 0, ncu = 256;
+    BBB_HIP(hipGetDevice(&dev));
+    BBB_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    const uint64_t ntrips = (G + 31) / 32;
+    uint64_t blocks = (uint64_t)ncu * (uint64_t)env_knob("BBB_UNSTAGE_BLOCKS_PER_CU", 1);
+    if (env_knob("BBB_UNSTAGE_BLOCKS", 0) > 0) blocks = (uint64_t)env_knob("BBB_UNSTAGE_BLOCKS", 0);
+    if (blocks > (ntrips + 3) / 4) blocks = (ntrips + 3) / 4;
+    const size_t lds = static_cast<size_t>(env_knob("BBB_UNSTAGE_LDS_KB", 0)) * 1024;
+    if (piece == 16)
+        hipLaunchKernelGGL(unstage_kernel<16>, dim3((unsigned)blocks), dim3(256), lds, st, (const char *)stg, (char *)dst,
+                           (unsigned long long)nbytes, Lb, (unsigned long long)G, (unsigned long long)Gpad, rounds);
+    else
+        hipLaunchKernelGGL(unstage_kernel<32>, dim3((unsigned)blocks), dim3(256), lds, st, (const char *)stg, (char *)dst,
+                           (unsigned long long)nbytes, Lb, (unsigned long long)G, (unsigned long long)Gpad, rounds);
+    BBB_HIP(hipGetLastError());
+    return BBB_OK;
 }
 
 // int8 -> int16 (sign extension), 16 samples per lane: the int16 form of the k = 256 stream is the fast
@@ -537,10 +668,16 @@ int awgn_seed_launch(int k, const uint32_t *d_tabs, const uint32_t *s16, uint64_
 }
 
 int awgn256_fill_launch(const uint32_t *d_planes, int8_t *dst, uint64_t nsamples, unsigned L, uint64_t G,
-                        unsigned nlanes, hipStream_t st) {
+                        unsigned nlanes, bool staged, hipStream_t st) {
     const unsigned nwaves = nlanes / 64;
-    hipLaunchKernelGGL(awgn256_kernel<false>, dim3(nwaves), dim3(64), 0, st, d_planes, (void *)dst, (unsigned long long)nsamples, L,
-                       (unsigned long long)G, nlanes, TxFuse{});
+    TxFuse none{};
+    none.low_prio = env_knob("BBB_AWGN_LOW_PRIO", 0);
+    if (staged)
+        hipLaunchKernelGGL((awgn256_kernel<false, true>), dim3(nwaves), dim3(64), 0, st, d_planes, (void *)dst, (unsigned long long)nsamples, L,
+                           (unsigned long long)G, nlanes, none);
+    else
+        hipLaunchKernelGGL((awgn256_kernel<false, false>), dim3(nwaves), dim3(64), 0, st, d_planes, (void *)dst, (unsigned long long)nsamples, L,
+                           (unsigned long long)G, nlanes, none);
     BBB_HIP(hipGetLastError());
     return BBB_OK;
 }
@@ -568,7 +705,7 @@ int pulse_bits_launch(uint64_t *dst, int64_t m_first, uint64_t nwords, hipStream
 
 int awgn256_tx_launch(const uint32_t *d_planes, int16_t *dst, uint64_t nsamples, unsigned L, uint64_t G, unsigned nlanes,
                       const int16_t *coeffs, const uint32_t *d_bits, uint32_t nwords32, uint32_t rel_base, uint32_t c0, int noise_var,
-                      int bit_en, int use_bits, hipStream_t st) {
+                      int bit_en, int use_bits, bool staged, hipStream_t st) {
     TxFuse tx;
     for (int i = 0; i < 64; i++) tx.coeffs[i] = coeffs[i];
     tx.bits = d_bits;
@@ -576,10 +713,15 @@ int awgn256_tx_launch(const uint32_t *d_planes, int16_t *dst, uint64_t nsamples,
     tx.c0 = c0;
     tx.noise_var = noise_var;
     tx.bit_en = bit_en;
+    tx.low_prio = env_knob("BBB_AWGN_LOW_PRIO", 0);
     tx.use_bits = use_bits && nwords32 >= 2;
     tx.last_word = nwords32 ? nwords32 - 1 : 1;
-    hipLaunchKernelGGL(awgn256_kernel<true>, dim3(nlanes / 64), dim3(64), 0, st, d_planes, (void *)dst, (unsigned long long)nsamples, L,
-                       (unsigned long long)G, nlanes, tx);
+    if (staged)
+        hipLaunchKernelGGL((awgn256_kernel<true, true>), dim3(nlanes / 64), dim3(64), 0, st, d_planes, (void *)dst, (unsigned long long)nsamples, L,
+                           (unsigned long long)G, nlanes, tx);
+    else
+        hipLaunchKernelGGL((awgn256_kernel<true, false>), dim3(nlanes / 64), dim3(64), 0, st, d_planes, (void *)dst, (unsigned long long)nsamples, L,
+                           (unsigned long long)G, nlanes, tx);
     BBB_HIP(hipGetLastError());
     return BBB_OK;
 }

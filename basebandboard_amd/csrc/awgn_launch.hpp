@@ -10,13 +10,17 @@ namespace bbb {
 // s16: the first 16 start states, [16][16] words (host computed)
 int awgn_seed_launch(int k, const uint32_t *d_tabs, const uint32_t *s16, uint64_t G, uint32_t *d_states,
                      uint64_t stride, unsigned nlanes, uint32_t *d_planes, hipStream_t st);
+// staged: dst is a staging buffer [L/16 rounds][nlanes * 32 generator slots][16 bytes], to be moved by unstage_launch
 int awgn256_fill_launch(const uint32_t *d_planes, int8_t *dst, uint64_t nsamples, unsigned L, uint64_t G,
-                        unsigned nlanes, hipStream_t st);
+                        unsigned nlanes, bool staged, hipStream_t st);
+// staging buffer [rounds][Gpad][piece bytes] -> sequential stream of nbytes, generator g owning [g Lb, (g+1) Lb)
+int unstage_launch(const void *stg, void *dst, uint64_t nbytes, unsigned Lb, uint64_t G, uint64_t Gpad, unsigned rounds,
+                   int piece, hipStream_t st);
 // the transmitter's output fused into the sample kernel: x = wrap12(bit_en * shaped + g * noise_var) as int16.
 // d_bits: packed data bits (32-bit words); rel_base = window bit offset of output position 0; c0 = (first_sample - 17) & 7
 int awgn256_tx_launch(const uint32_t *d_planes, int16_t *dst, uint64_t nsamples, unsigned L, uint64_t G, unsigned nlanes,
                       const int16_t *coeffs, const uint32_t *d_bits, uint32_t nwords32, uint32_t rel_base, uint32_t c0, int noise_var,
-                      int bit_en, int use_bits, hipStream_t st);
+                      int bit_en, int use_bits, bool staged, hipStream_t st);
 int pulse_bits_launch(uint64_t *dst, int64_t m_first, uint64_t nwords, hipStream_t st);
 int widen_i8_i16_launch(const int8_t *src, int16_t *dst, uint64_t n, hipStream_t st);   // n rounded up to 16 by the caller's buffers
 int awgn_generic_fill_launch(int k, const uint16_t *d_taps, const uint32_t *d_row_off, uint32_t *d_planes2,

@@ -99,6 +99,19 @@ struct bbb_lutopt {
         bool read_pending = false;
     } pf;
     hipStream_t side = nullptr;
+    // The stream the library's plane-touching work of the current call goes to: the caller's stream, or -- for the
+    // two-kernel ("staged") form of the sample stream -- an internal one, so that the next fill's arithmetic does
+    // not queue behind the caller-visible completion of this one (see staged_fill).
+    hipStream_t cs = nullptr;
+    bool cs_valid = false;
+    hipEvent_t handover = nullptr;
+    bool staged_mode = false;             // bbb_lutopt_set_staged
+    hipStream_t xs = nullptr, ys = nullptr;            // internal: arithmetic / piece mover
+    uint32_t *d_stage[2] = {nullptr, nullptr}; size_t stage_cap[2] = {0, 0};
+    hipEvent_t stage_free[2] = {nullptr, nullptr};     // recorded on ys after the mover that read the buffer
+    bool stage_busy[2] = {false, false};
+    int stage_slot = 0;
+    hipEvent_t ev_arith = nullptr, ev_user = nullptr;
     hipEvent_t cur_last_read = nullptr;   // same, for the buffers currently in d_states / d_planes
     bool cur_read_pending = false;
     // optional per-call device timing of the generator kernels (bbb_lutopt_profile)
@@ -234,11 +247,34 @@ void partition(const bbb_lutopt *h, uint64_t n, unsigned granule, uint64_t *L, u
     *nlanes = (unsigned)(waves * 64);
 }
 
+// Choose the stream this call's plane-touching work goes to.  When it differs from the previous call's (the staged
+// fills use an internal stream; the caller may also have re-bound the handle), the new one first waits for
+// everything the library queued on the old one.
+int begin_op(bbb_lutopt *h, bool internal) {
+    if (internal && !h->xs) {
+        // the arithmetic gets the highest stream priority, the piece mover the lowest: when both have blocks waiting,
+        // the sample kernel's waves (which need a whole SIMD's registers) are placed first and the mover takes what is left
+        int lo = 0, hi = 0;
+        BBB_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        BBB_HIP(hipStreamCreateWithPriority(&h->xs, hipStreamNonBlocking, hi));
+        BBB_HIP(hipStreamCreateWithPriority(&h->ys, hipStreamNonBlocking, lo));
+    }
+    hipStream_t want = internal ? h->xs : h->stream;
+    if (h->cs_valid && h->cs != want) {
+        if (!h->handover) BBB_HIP(hipEventCreateWithFlags(&h->handover, hipEventDisableTiming));
+        BBB_HIP(hipEventRecord(h->handover, h->cs));
+        BBB_HIP(hipStreamWaitEvent(want, h->handover, 0));
+    }
+    h->cs = want;
+    h->cs_valid = true;
+    return BBB_OK;
+}
+
 // Every kernel that touches d_states / d_planes on the main stream is followed by this: after a prefetch swap
 // these buffers become the side stream's, which must not seed into them while such a kernel is still running.
 int mark_planes_read(bbb_lutopt *h) {
     if (!h->cur_last_read) BBB_HIP(hipEventCreateWithFlags(&h->cur_last_read, hipEventDisableTiming));
-    BBB_HIP(hipEventRecord(h->cur_last_read, h->stream));
+    BBB_HIP(hipEventRecord(h->cur_last_read, h->cs));
     h->cur_read_pending = true;
     return BBB_OK;
 }
@@ -256,7 +292,7 @@ int prepare_planes(bbb_lutopt *h, uint64_t first, uint64_t L, uint64_t G, unsign
     uint32_t s16[256];
     first16(*plan, s0, s16);
     h->planes_valid = false;
-    rc = awgn_seed_launch(h->k, plan->d_cols, s16, G, h->d_states, G, nlanes, h->d_planes, h->stream);
+    rc = awgn_seed_launch(h->k, plan->d_cols, s16, G, h->d_states, G, nlanes, h->d_planes, h->cs);
     if (rc) return rc;
     if ((rc = mark_planes_read(h))) return rc;
     h->planes_valid = true;
@@ -268,7 +304,7 @@ int prepare_planes(bbb_lutopt *h, uint64_t first, uint64_t L, uint64_t G, unsign
 int acquire_planes(bbb_lutopt *h, uint64_t first_step, uint64_t L, uint64_t G, unsigned nlanes, bool may_use_prefetch) {
     if (may_use_prefetch && h->pf.valid && h->pf.first == first_step && h->pf.L == L && h->pf.G == G) {
         // the announced fill: its start states were seeded on the side stream -- swap them in
-        BBB_HIP(hipStreamWaitEvent(h->stream, h->pf.seeded, 0));
+        BBB_HIP(hipStreamWaitEvent(h->cs, h->pf.seeded, 0));
         std::swap(h->d_states, h->pf.d_states); std::swap(h->states_cap, h->pf.states_cap);
         std::swap(h->d_planes, h->pf.d_planes); std::swap(h->planes_cap, h->pf.planes_cap);
         std::swap(h->cur_last_read, h->pf.last_read); std::swap(h->cur_read_pending, h->pf.read_pending);
@@ -278,6 +314,46 @@ int acquire_planes(bbb_lutopt *h, uint64_t first_step, uint64_t L, uint64_t G, u
         return BBB_OK;
     }
     return prepare_planes(h, first_step, L, G, nlanes);
+}
+
+// The two-kernel form of a fill (bbb_lutopt_set_staged).  `launch_arith(stage_buffer)` queues the sample kernel,
+// which leaves its pieces in a staging buffer as full lines; the piece mover then writes `dst`.  Streams:
+//   arithmetic      internal stream xs  -- ordered after the previous library work, NOT after the caller's stream
+//   piece mover     internal stream ys  -- after the arithmetic, and after everything the caller had queued before
+//                                          this call (it may still be reading `dst`)
+//   caller's stream waits for the mover: whatever the caller queues next sees `dst` complete, as with one kernel.
+// Since the next call's arithmetic does not wait for this call's mover, the mover (HBM-bound, a few registers per
+// lane) runs beside it (integer-issue bound, one wave per SIMD).  Two staging buffers alternate.
+template <typename LaunchArith>
+int staged_fill(bbb_lutopt *h, void *dst, uint64_t nbytes, int piece, uint64_t L, uint64_t G, unsigned nlanes,
+                bbb_lutopt::ProfEv *ev, LaunchArith launch_arith) {
+    const uint64_t Gpad = (uint64_t)nlanes * 32;
+    const unsigned rounds = (unsigned)(L / 16);
+    const size_t need_words = (size_t)(Gpad * rounds * (uint64_t)piece / 4);
+    const int slot = h->stage_slot ^= 1;
+    for (hipEvent_t *e : {&h->stage_free[slot], &h->ev_arith, &h->ev_user})
+        if (!*e) BBB_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    if (h->stage_cap[slot] < need_words) {
+        if (h->stage_busy[slot]) BBB_HIP(hipEventSynchronize(h->stage_free[slot]));     // growing frees the old buffer
+        h->stage_busy[slot] = false;
+        int rc = grow(&h->d_stage[slot], &h->stage_cap[slot], need_words);
+        if (rc) return rc;
+    }
+    if (h->stage_busy[slot]) BBB_HIP(hipStreamWaitEvent(h->cs, h->stage_free[slot], 0));   // its last mover has read it
+    if (ev) BBB_HIP(hipEventRecord(ev->e1, h->cs));
+    int rc = launch_arith((void *)h->d_stage[slot]);
+    if (rc) return rc;
+    if ((rc = mark_planes_read(h))) return rc;
+    if (ev) BBB_HIP(hipEventRecord(ev->e2, h->cs));
+    BBB_HIP(hipEventRecord(h->ev_arith, h->cs));
+    BBB_HIP(hipEventRecord(h->ev_user, h->stream));
+    BBB_HIP(hipStreamWaitEvent(h->ys, h->ev_user, 0));
+    BBB_HIP(hipStreamWaitEvent(h->ys, h->ev_arith, 0));
+    if ((rc = unstage_launch(h->d_stage[slot], dst, nbytes, (unsigned)(L * (uint64_t)piece / 16), G, Gpad, rounds, piece, h->ys))) return rc;
+    BBB_HIP(hipEventRecord(h->stage_free[slot], h->ys));
+    h->stage_busy[slot] = true;
+    BBB_HIP(hipStreamWaitEvent(h->stream, h->stage_free[slot], 0));
+    return BBB_OK;
 }
 
 int awgn_fill(bbb_lutopt *h, void *dst, int elem_size, uint64_t nsamples, uint64_t first_step) {
@@ -293,35 +369,47 @@ int awgn_fill(bbb_lutopt *h, void *dst, int elem_size, uint64_t nsamples, uint64
     unsigned nlanes;
     partition(h, nsamples, 16, &L, &G, &nlanes);
     if (L > 0xffffff00ull) return fail(BBB_EINVAL, "nsamples too large for one call (segment length must fit 32 bits): split it");
+    const bool fast256 = h->specialised && elem_size == 1;
+    const bool staged = fast256 && h->staged_mode && nsamples >= (1ull << 24);
+    int rc = begin_op(h, staged);
+    if (rc) return rc;
     bbb_lutopt::ProfEv ev{};
     if (h->profiling) {
         BBB_HIP(hipEventCreate(&ev.e0)); BBB_HIP(hipEventCreate(&ev.e1)); BBB_HIP(hipEventCreate(&ev.e2));
-        BBB_HIP(hipEventRecord(ev.e0, h->stream));
+        BBB_HIP(hipEventRecord(ev.e0, h->cs));
     }
-    int rc = acquire_planes(h, first_step, L, G, nlanes, h->specialised && elem_size == 1);
+    rc = acquire_planes(h, first_step, L, G, nlanes, fast256);
     if (rc) return rc;
-    if (h->specialised && elem_size == 1) {
-        if (h->profiling) BBB_HIP(hipEventRecord(ev.e1, h->stream));
-        rc = awgn256_fill_launch(h->d_planes, (int8_t *)dst, nsamples, (unsigned)L, G, nlanes, h->stream);
+    if (staged) {
+        rc = staged_fill(h, dst, nsamples, 16, L, G, nlanes, h->profiling ? &ev : nullptr, [&](void *stage) {
+            return awgn256_fill_launch(h->d_planes, (int8_t *)stage, nsamples, (unsigned)L, G, nlanes, true, h->cs);
+        });
+        if (h->profiling) h->prof_pending.push_back(ev);
+        return rc;
+    }
+    if (fast256) {
+        if (h->profiling) BBB_HIP(hipEventRecord(ev.e1, h->cs));
+        rc = awgn256_fill_launch(h->d_planes, (int8_t *)dst, nsamples, (unsigned)L, G, nlanes, false, h->cs);
         if (!rc) rc = mark_planes_read(h);
         if (h->profiling) {
-            BBB_HIP(hipEventRecord(ev.e2, h->stream));
+            BBB_HIP(hipEventRecord(ev.e2, h->cs));
             h->prof_pending.push_back(ev);
         }
         return rc;
     }
+    if (h->profiling) { (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); (void)hipEventDestroy(ev.e2); }
     if (h->custom_fill && elem_size == 1) {
-        const int e = h->custom_fill(h->d_planes, (int8_t *)dst, nsamples, (uint32_t)L, G, nlanes, (void *)h->stream);
+        const int e = h->custom_fill(h->d_planes, (int8_t *)dst, nsamples, (uint32_t)L, G, nlanes, (void *)h->cs);
         if (e) return fail(BBB_EHIP, std::string("custom sample kernel: ") + hipGetErrorString((hipError_t)e));
         return mark_planes_read(h);
     }
     if (h->small_fast && elem_size == 1) {
-        rc = awgn_small_fill_launch(h->small_fast, h->d_planes, (int8_t *)dst, nsamples, (unsigned)L, G, nlanes, h->stream);
+        rc = awgn_small_fill_launch(h->small_fast, h->d_planes, (int8_t *)dst, nsamples, (unsigned)L, G, nlanes, h->cs);
         return rc ? rc : mark_planes_read(h);
     }
     h->planes_valid = false;    // the table-driven kernel advances the planes in place
     rc = awgn_generic_fill_launch(h->k, h->d_taps, h->d_row_off, h->d_planes, dst, elem_size, nsamples, (unsigned)L, G,
-                                  nlanes, h->stream);
+                                  nlanes, h->cs);
     return rc ? rc : mark_planes_read(h);
 }
 
@@ -351,6 +439,10 @@ int channel_thresholds(int amp, int noise_var, TrialDev *t) {
 }
 
 int ber_run(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, unsigned long long *counters_dev) {
+    {
+        const int rc0 = begin_op(h, false);
+        if (rc0) return rc0;
+    }
     if (!h->specialised && !h->custom_ber)
         return fail(BBB_EUNSUP, "BER trials need the shipped n256 matrix, or a k = 256 matrix with its own kernels attached "
                                 "(bbb_lutopt_attach_custom_library / LUTOPT.specialise)");
@@ -412,11 +504,11 @@ int ber_run(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, unsigned long lo
         uint64_t ps64[8] = {ps0};
         uint32_t ps16[256];
         first16(*pp, ps64, ps16);
-        if ((rc = awgn_seed_launch(c.prbs_k, pp->d_cols, ps16, G, h->d_pstates, G, nlanes, h->d_pplanes, h->stream))) return rc;
+        if ((rc = awgn_seed_launch(c.prbs_k, pp->d_cols, ps16, G, h->d_pstates, G, nlanes, h->d_pplanes, h->cs))) return rc;
         if (h->specialised) {
-            if ((rc = ber256_launch(h->d_planes, h->d_pplanes, &td[(size_t)i], n, nlanes, counters_dev + 2 * (size_t)i, h->stream))) return rc;
+            if ((rc = ber256_launch(h->d_planes, h->d_pplanes, &td[(size_t)i], n, nlanes, counters_dev + 2 * (size_t)i, h->cs))) return rc;
         } else {
-            const int e = h->custom_ber(h->d_planes, h->d_pplanes, &td[(size_t)i], n, nlanes, (uint64_t *)(counters_dev + 2 * (size_t)i), (void *)h->stream);
+            const int e = h->custom_ber(h->d_planes, h->d_pplanes, &td[(size_t)i], n, nlanes, (uint64_t *)(counters_dev + 2 * (size_t)i), (void *)h->cs);
             if (e) return fail(e < 0 ? e : BBB_EHIP, "custom BER kernel failed");
         }
         if ((rc = mark_planes_read(h))) return rc;
@@ -555,9 +647,13 @@ int bbb_lutopt_destroy(bbb_lutopt *h) {
                     (void *)h->d_taps, (void *)h->d_row_off, (void *)h->d_counters, (void *)h->d_txnoise,
                     (void *)h->d_txbits, (void *)h->pf.d_states, (void *)h->pf.d_planes})
         (void)hipFree(p);
-    for (hipEvent_t e : {h->pf.seeded, h->pf.last_read, h->cur_last_read})
+    for (hipEvent_t e : {h->pf.seeded, h->pf.last_read, h->cur_last_read, h->handover, h->stage_free[0], h->stage_free[1],
+                         h->ev_arith, h->ev_user})
         if (e) (void)hipEventDestroy(e);
-    if (h->side) (void)hipStreamDestroy(h->side);
+    for (hipStream_t st : {h->side, h->xs, h->ys})
+        if (st) (void)hipStreamDestroy(st);
+    (void)hipFree(h->d_stage[0]);
+    (void)hipFree(h->d_stage[1]);
     delete h;
     return BBB_OK;
 }
@@ -596,6 +692,12 @@ int bbb_lutopt_attach_custom_library(bbb_lutopt *h, const char *path) {
     auto ber = reinterpret_cast<bbb_custom_ber_fn>(dlsym(lib, "bbb_custom_ber"));
     if (ber && h->k == 256) rc = bbb_lutopt_set_custom_ber(h, ber);
     return rc;
+}
+
+int bbb_lutopt_set_staged(bbb_lutopt *h, int enable) {
+    if (!h) return fail(BBB_EINVAL, "null handle");
+    h->staged_mode = enable != 0;
+    return BBB_OK;
 }
 
 int bbb_lutopt_is_specialised(const bbb_lutopt *h) { return h && h->specialised ? 1 : 0; }
@@ -645,9 +747,14 @@ int bbb_awgn_prefetch(bbb_lutopt *h, uint64_t nsamples, uint64_t first_step) {
     bbb_lutopt::Prefetch &pf = h->pf;
     pf.valid = false;
     if (!h->side) BBB_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    // staged handles: the running sample kernel (fill s) shares its CUs with ONE guest kernel at a time -- with two, its
+    // waves, 416 registers each, wait for a SIMD.  The guests of fill s are the piece mover of fill s-1 and this seeding
+    // (for fill s+1): the seeding waits for that mover.  (The mover of fill s itself starts when fill s has finished.)
+    const hipStream_t side = h->side;
+    if (h->staged_mode && h->stage_busy[h->stage_slot ^ 1]) BBB_HIP(hipStreamWaitEvent(side, h->stage_free[h->stage_slot ^ 1], 0));
     if (!pf.seeded) BBB_HIP(hipEventCreateWithFlags(&pf.seeded, hipEventDisableTiming));
     // the buffers may still be read by the sample kernel that used them last (main stream)
-    if (pf.read_pending) BBB_HIP(hipStreamWaitEvent(h->side, pf.last_read, 0));
+    if (pf.read_pending) BBB_HIP(hipStreamWaitEvent(side, pf.last_read, 0));
     if (pf.states_cap < (size_t)G * h->W32 || pf.planes_cap < (size_t)2 * h->k * nlanes) {
         if (pf.read_pending) BBB_HIP(hipEventSynchronize(pf.last_read));     // growing frees the old buffers
         if ((rc = grow(&pf.d_states, &pf.states_cap, (size_t)G * h->W32))) return rc;
@@ -658,8 +765,8 @@ int bbb_awgn_prefetch(bbb_lutopt *h, uint64_t nsamples, uint64_t first_step) {
     h->pw->apply(first_step, h->init, s0);
     uint32_t s16[256];
     first16(*plan, s0, s16);
-    if ((rc = awgn_seed_launch(h->k, plan->d_cols, s16, G, pf.d_states, G, nlanes, pf.d_planes, h->side))) return rc;
-    BBB_HIP(hipEventRecord(pf.seeded, h->side));
+    if ((rc = awgn_seed_launch(h->k, plan->d_cols, s16, G, pf.d_states, G, nlanes, pf.d_planes, side))) return rc;
+    BBB_HIP(hipEventRecord(pf.seeded, side));
     pf.valid = true;
     pf.first = first_step; pf.L = L; pf.G = G; pf.nlanes = nlanes;
     return BBB_OK;
@@ -693,11 +800,13 @@ int bbb_lutopt_fill_words(bbb_lutopt *h, uint32_t *dst_dev, uint64_t nstates, ui
     uint64_t L, G;
     unsigned nlanes;
     partition(h, nstates, 1, &L, &G, &nlanes);
-    int rc = prepare_planes(h, first_step, L, G, nlanes);
+    int rc = begin_op(h, false);
+    if (rc) return rc;
+    rc = prepare_planes(h, first_step, L, G, nlanes);
     if (rc) return rc;
     h->planes_valid = false;    // the table-driven kernel advances the planes in place
     rc = lutopt_words_launch(h->k, h->d_taps, h->d_row_off, h->d_planes, dst_dev, nstates, (unsigned)L, G, nlanes,
-                             msb_first != 0, h->stream);
+                             msb_first != 0, h->cs);
     if (!rc) rc = mark_planes_read(h);
     return rc;
 }
@@ -839,25 +948,36 @@ int bbb_tx_fill_i16(bbb_lutopt *h, const bbb_tx_cfg *cfg, int16_t *out_dev, uint
         uint64_t L, G;
         unsigned nlanes;
         partition(h, nsamples, 16, &L, &G, &nlanes);
+        const bool staged = h->staged_mode && nsamples >= (1ull << 24);
+        if ((rc = begin_op(h, staged))) return rc;
         const int64_t F = (int64_t)first_sample - 17, FM = F >> 3;            // arithmetic shift = floor
         const bool use_bits = cfg->bit_en && nbits;
         // buffer: two zero 64-bit words (data bits before the first read as 0, the shaper's reset shift register), the
         // bits m0 .. m0+nbits-1, slack for the windows of rounds past the end of the request
         const uint64_t words64 = 2 + (nbits + 63) / 64 + (L / 8 + 63) / 64 + 2;
-        if ((rc = grow(&h->d_txbits, &h->txbits_cap, (size_t)words64 * 2))) return rc;
+        if (h->txbits_cap < (size_t)words64 * 2) {
+            BBB_HIP(hipStreamSynchronize(h->cs));                                // an earlier call's kernel may still read it
+            if ((rc = grow(&h->d_txbits, &h->txbits_cap, (size_t)words64 * 2))) return rc;
+        }
         if (use_bits) {
-            BBB_HIP(hipMemsetAsync(h->d_txbits, 0, 16, h->stream));
+            BBB_HIP(hipMemsetAsync(h->d_txbits, 0, 16, h->cs));
             uint64_t *bits64 = (uint64_t *)h->d_txbits + 2;
-            if (cfg->source == 0) rc = prbs_fill_launch(cfg->prbs_k, cfg->prbs_state, (uint64_t)m0, nbits, bits64, h->stream);
-            else rc = pulse_bits_launch(bits64, m0, (nbits + 63) / 64, h->stream);
+            if (cfg->source == 0) rc = prbs_fill_launch(cfg->prbs_k, cfg->prbs_state, (uint64_t)m0, nbits, bits64, h->cs);
+            else rc = pulse_bits_launch(bits64, m0, (nbits + 63) / 64, h->cs);
             if (rc) return rc;
         }
         if ((rc = acquire_planes(h, cfg->warmup + first_sample, L, G, nlanes, true))) return rc;      // tx.py:70-71
         const uint32_t rel_base = (uint32_t)(FM - 7 - (m0 - 128));
-        rc = awgn256_tx_launch(h->d_planes, out_dev, nsamples, (unsigned)L, G, nlanes, cfg->coeffs, h->d_txbits, (uint32_t)(words64 * 2),
-                               rel_base, (uint32_t)(F & 7), cfg->noise_var, cfg->bit_en, use_bits ? 1 : 0, h->stream);
+        auto arith = [&](void *dst, bool to_stage) {
+            return awgn256_tx_launch(h->d_planes, (int16_t *)dst, nsamples, (unsigned)L, G, nlanes, cfg->coeffs, h->d_txbits,
+                                     (uint32_t)(words64 * 2), rel_base, (uint32_t)(F & 7), cfg->noise_var, cfg->bit_en, use_bits ? 1 : 0,
+                                     to_stage, h->cs);
+        };
+        if (staged) return staged_fill(h, out_dev, nsamples * 2, 32, L, G, nlanes, nullptr, [&](void *stage) { return arith(stage, true); });
+        rc = arith(out_dev, false);
         return rc ? rc : mark_planes_read(h);
     }
+    if ((rc = begin_op(h, false))) return rc;
     const bool have_bits = cfg->source == 0 && nbits && cfg->bit_en;
     if (have_bits) {
         if ((rc = grow(&h->d_txbits, &h->txbits_cap, (size_t)((nbits + 63) / 64 + 2) * 2))) return rc;

@@ -125,6 +125,11 @@ class LUTOPT:
         self._custom = so
         return so
 
+    def set_staged(self, enable=True):
+        """Two-kernel form of the large k = 256 fills of this handle (bbb_lutopt_set_staged): same samples; the output
+        is written as full lines by a second kernel that overlaps the next fill's arithmetic."""
+        _lib.check(_lib.lib().bbb_lutopt_set_staged(self._h, int(bool(enable))), "bbb_lutopt_set_staged")
+
     def state_at(self, nsteps):
         """Integer value of `x` after nsteps clocks from reset."""
         out = (C.c_uint64 * ((self.k + 63) // 64))()

@@ -110,6 +110,16 @@ int bbb_awgn_fill_i8(bbb_lutopt *h, int8_t *dst_dev, uint64_t nsamples, uint64_t
  * 32 KiB of LDS per CU unused) -- and the matching fill only waits for them.  A fill with other
  * arguments ignores the hint.  Results are identical with or without it. */
 int bbb_awgn_prefetch(bbb_lutopt *h, uint64_t nsamples, uint64_t first_step);
+/* Choose the two-kernel ("staged") form of the k = 256 sample stream for this handle's large fills
+ * (bbb_awgn_fill_i8, bbb_tx_fill_i16 of 2^24 samples and more).  Results are identical; what changes is how the
+ * bytes reach HBM.  The one-kernel form writes every generator's 16 new bytes straight to their place: 62.5 M
+ * scattered pieces per 1e9 samples, one DRAM row activation each.  The staged form has the sample kernel leave its
+ * pieces in an internal buffer as full lines and a second kernel move them with full-line reads and writes.  That
+ * second kernel runs on an internal stream: the caller's stream waits for it (anything queued after the call sees the
+ * output complete, as before), but the NEXT fill's arithmetic does not -- the mover (memory bound) and the next
+ * arithmetic (integer-issue bound) share the machine.  Worth it for back-to-back fills; a single isolated fill
+ * finishes later than in the one-kernel form.  Costs two staging buffers of the fill's size. */
+int bbb_lutopt_set_staged(bbb_lutopt *h, int enable);
 /* Same stream as int16 (needed for k = 512, whose CLTGRNG output is 9 bits: rng.py:78). */
 int bbb_awgn_fill_i16(bbb_lutopt *h, int16_t *dst_dev, uint64_t nsamples, uint64_t first_step);
 

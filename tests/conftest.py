@@ -40,6 +40,11 @@ def golden_gf2():
 
 
 @pytest.fixture(scope="session")
+def golden_shaper():
+    return json.load(open(GOLDEN / "shaper.json"))
+
+
+@pytest.fixture(scope="session")
 def oracle():
     import oracle as O
     O.lib()
