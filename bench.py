@@ -182,6 +182,11 @@ def main():
     from basebandboard_amd import channel
     u = bbb.LUTOPT.shipped(256, init=1, device=local_rank)
     assert u.specialised, "bench must run the generated gfx950 kernel"
+    # the two-kernel form of the stream (bbb_lutopt_set_staged): the sample kernel writes full lines into a staging
+    # buffer, a piece mover puts them in place beside the NEXT step's arithmetic; same bytes (tests/test_gpu_staged.py).
+    # BENCH_ONE_KERNEL=1 times the one-kernel form instead (it is also reported in `extra`).
+    staged = not os.environ.get("BENCH_ONE_KERNEL")
+    u.set_staged(staged)
     g = bbb.CLTGRNG(u)
     buf = torch.empty(NSAMP, dtype=torch.int8, device=f"cuda:{local_rank}")
 
@@ -283,6 +288,21 @@ def main():
                     "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": int(nbytes), "kernel_ms_avg": round(ms, 4),
                     "what": what}
 
+        # the other form of the same stream, a few steps outside the timed region
+        u2 = bbb.LUTOPT.shipped(256, init=1, device=local_rank)
+        u2.set_staged(not staged)
+        g2 = bbb.CLTGRNG(u2)
+        for s_ in range(2):
+            g2.generate(NSAMP, first_step=first_step(s_), out=buf); g2.prefetch(NSAMP, first_step=first_step(s_ + 1))
+        u2.profile(True); u2.profile_read(reset=True)
+        torch.cuda.synchronize(); t_o = time.perf_counter()
+        for s_ in range(2, 8):
+            g2.generate(NSAMP, first_step=first_step(s_), out=buf); g2.prefetch(NSAMP, first_step=first_step(s_ + 1))
+        torch.cuda.synchronize(); t_o = (time.perf_counter() - t_o) / 6
+        _, k_o, c_o = u2.profile_read(reset=True)
+        extra["awgn_other_form"] = {"form": "one kernel" if staged else "two kernels (staged)", "ms_per_step": round(t_o * 1e3, 4),
+                                    "gsample_s": round(NSAMP / t_o / 1e9, 1), "sample_kernel_ms_avg": round(k_o / max(c_o, 1), 4)}
+        del u2, g2
         # PRBS-31 loopback (BASELINE configs[2]): 1e10 bits written, then read back and checked.  Per pass, device
         # time between hipEvents on the launch stream: the fill, the check right after the fill (the loopback order:
         # it also pays for the write-backs of the fill's last 256 MiB, which are still dirty in the memory-side cache),
@@ -423,11 +443,13 @@ def main():
                                    "warm-up 16, sequential reference stream (BASELINE configs[1]; reference-faithful "
                                    "generator, no xorshift/CLT-12 exists in the reference)",
                        "samples_per_step_per_gpu": NSAMP, "seeding_in_timed_region": True,
+                       "form": "two kernels: sample kernel -> staging buffer (full lines), piece mover -> output, the mover of step s "
+                               "beside the arithmetic of step s+1; all of it inside the timed region" if staged else "one kernel",
                        "seeding_overlapped_by_prefetch_hint": bool(prefetch),
                        "verified_vs_oracle": verified},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "awgn256_kernel", "kernel_ms_avg": round(kern_avg_ms, 4),
+                         "kernel": "awgn256_kernel<false, staged>" if staged else "awgn256_kernel<false, false>", "kernel_ms_avg": round(kern_avg_ms, 4),
                          "seed_ms_avg": round(seed_ms / max(calls, 1), 4), "launches_timed": int(calls),
                          "algorithmic_bytes_per_launch": NSAMP,
                          "streaming_fill_gb_s": round(fill_gbs, 1) if fill_gbs else None,
