@@ -27,6 +27,7 @@
 
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 #include "gen/lutopt256_gen.inc"
 
 namespace bbb {
@@ -212,6 +213,14 @@ struct TxFuse {
     int32_t low_prio;         // (experiments) run at the default wave priority instead of the highest
 };
 
+// (mask & a) | (~mask & b) with a wave-uniform mask: ONE V_BFI_B32 (left to itself hipcc turns the uniform mask into
+// s_not + v_and + v_and_or)
+__device__ __forceinline__ uint32_t bfi_uniform(uint32_t mask, uint32_t a, uint32_t b) {
+    uint32_t d;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "s"(mask), "v"(a), "v"(b));
+    return d;
+}
+
 typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
 typedef int16_t i16x2 __attribute__((ext_vector_type(2)));
 
@@ -267,6 +276,7 @@ awgn256_kernel(const uint32_t *__restrict planes, void *__restrict dst_, unsigne
 #undef BBB_PARK
 
     const unsigned rounds = L / 16;
+    const bool wave_full = (wave * 32 + 31) * 64 + 63 < G && ((wave * 32 + 32) * 64) * (unsigned long long)L <= nsamples;
 #pragma unroll 1
     for (unsigned r = 0; r < rounds; r++) {
 #pragma unroll 1
@@ -298,7 +308,10 @@ awgn256_kernel(const uint32_t *__restrict planes, void *__restrict dst_, unsigne
                 }
             }
         };
-        auto round_end = [&](const unsigned i, const uint32_t (&w4)[4]) {
+        // FULL: every generator of this wave exists and its whole segment lies inside the request (all waves but the
+        // last): no per-generator bounds, no divergent branches
+        auto round_end = [&](auto full_c, const unsigned i, const uint32_t (&w4)[4]) {
+            constexpr bool FULL = decltype(full_c)::value;
             uint32_t o[4][4];                 // o[w][q] after the transposes
 #pragma unroll
             for (int w = 0; w < 4; w++) {
@@ -309,18 +322,32 @@ awgn256_kernel(const uint32_t *__restrict planes, void *__restrict dst_, unsigne
 #pragma unroll
                 for (int q = 0; q < 4; q++) o[w][q] = z[q];
             }
+            // TX: the table rows of all four generators, twelve LDS reads issued together (10-bit window: bit j = data
+            // bit M0 - 7 + j; one 16-byte row per window shift)
+            u32x4 RA[TX ? 4 : 1], RB[TX ? 4 : 1], RC[TX ? 4 : 1];
+            if (TX) {
+#pragma unroll
+                for (unsigned q = 0; q < 4; q++) {
+                    const uint32_t gq = (uint32_t)gen_index(wave, lane, 8 * q + i);
+                    const uint32_t rel_q = ((gq * L + r * 16u) >> 3) + tx.rel_base;
+                    const uint32_t Q4 = ((w4[q] >> (rel_q & 7u)) & 0x3ffu) << 4;
+                    RA[q] = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(TT) + (Q4 & 0xff0u));
+                    RB[q] = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(TT) + ((Q4 >> 1) & 0xff0u));
+                    RC[q] = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(TT) + ((Q4 >> 2) & 0xff0u));
+                }
+            }
 #pragma unroll
             for (unsigned q = 0; q < 4; q++) {
                 const unsigned long long g = gen_index(wave, lane, 8 * q + i);
                 const unsigned long long off = g * L + (unsigned long long)r * 16;
-                if (!(g < G && off < nsamples)) continue;   // (the q loop)
+                if (!FULL && !(g < G && off < nsamples)) continue;   // (the q loop)
                 const unsigned long long slot = (unsigned long long)r * ((unsigned long long)nlanes * 32) + g;   // STAGED
                 if (!TX) {
                     int8_t *dst = (int8_t *)dst_;
                     const u32x4 v = {o[0][q], o[1][q], o[2][q], o[3][q]};
                     if (STAGED) {
                         reinterpret_cast<u32x4 *>(dst_)[slot] = v;
-                    } else if (off + 16 <= nsamples) {
+                    } else if (FULL || off + 16 <= nsamples) {
                         *reinterpret_cast<u32x4 *>(dst + off) = v;
                     } else {
                         const unsigned n = (unsigned)(nsamples - off);
@@ -328,12 +355,7 @@ awgn256_kernel(const uint32_t *__restrict planes, void *__restrict dst_, unsigne
                     }
                 } else {
                     int16_t *dst = (int16_t *)dst_;
-                    // 10-bit window: bit j = data bit M0 - 7 + j; rows of the three window shifts (16 bytes each)
-                    const uint32_t rel_q = (((uint32_t)g * L + r * 16u) >> 3) + tx.rel_base;
-                    const uint32_t Q4 = ((w4[q] >> (rel_q & 7u)) & 0x3ffu) << 4;
-                    const u32x4 A = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(TT) + (Q4 & 0xff0u));
-                    const u32x4 B = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(TT) + ((Q4 >> 1) & 0xff0u));
-                    const u32x4 C = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(TT) + ((Q4 >> 2) & 0xff0u));
+                    const u32x4 A = RA[q], B = RB[q], C = RC[q];
                     const u16x2 nv16 = {(uint16_t)(tx.noise_var * 16), (uint16_t)(tx.noise_var * 16)};
                     uint32_t x[8];
 #pragma unroll
@@ -343,8 +365,8 @@ awgn256_kernel(const uint32_t *__restrict planes, void *__restrict dst_, unsigne
                         const uint32_t u23 = __builtin_amdgcn_perm(0u, u, 0x0c030c02u);
                         // shaped pairs of samples 4w, 4w+1 and 4w+2, 4w+3 (pair d = (2w) & 3, (2w+1) & 3 of their group of eight)
                         const int d0 = (2 * w) & 3, d1 = (2 * w + 1) & 3;
-                        const uint32_t s01 = w < 2 ? bit_select(selmask[d0], A[d0], B[d0]) : bit_select(selmask[d0], B[d0], C[d0]);
-                        const uint32_t s23 = w < 2 ? bit_select(selmask[d1], A[d1], B[d1]) : bit_select(selmask[d1], B[d1], C[d1]);
+                        const uint32_t s01 = w < 2 ? bfi_uniform(selmask[d0], A[d0], B[d0]) : bfi_uniform(selmask[d0], B[d0], C[d0]);
+                        const uint32_t s23 = w < 2 ? bfi_uniform(selmask[d1], A[d1], B[d1]) : bfi_uniform(selmask[d1], B[d1], C[d1]);
                         const u16x2 m01 = __builtin_bit_cast(u16x2, u01) * nv16 + __builtin_bit_cast(u16x2, s01);
                         const u16x2 m23 = __builtin_bit_cast(u16x2, u23) * nv16 + __builtin_bit_cast(u16x2, s23);
                         x[2 * w] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(i16x2, m01) >> 4);
@@ -354,7 +376,7 @@ awgn256_kernel(const uint32_t *__restrict planes, void *__restrict dst_, unsigne
                         const u32x4 lo = {x[0], x[1], x[2], x[3]}, hi = {x[4], x[5], x[6], x[7]};
                         reinterpret_cast<u32x4 *>(dst_)[2 * slot] = lo;
                         reinterpret_cast<u32x4 *>(dst_)[2 * slot + 1] = hi;
-                    } else if (off + 16 <= nsamples) {
+                    } else if (FULL || off + 16 <= nsamples) {
                         const u32x4 lo = {x[0], x[1], x[2], x[3]}, hi = {x[4], x[5], x[6], x[7]};
                         reinterpret_cast<u32x4 *>(dst + off)[0] = lo;
                         reinterpret_cast<u32x4 *>(dst + off)[1] = hi;
@@ -365,22 +387,26 @@ awgn256_kernel(const uint32_t *__restrict planes, void *__restrict dst_, unsigne
                 }
             }
         };
-        if (TX) {
+        auto all_iterations = [&](auto full_c) {
+            if (TX) {
 #pragma unroll 1
-            for (unsigned ihalf = 0; ihalf < 2; ihalf++) {
-                uint32_t win[16];
-                load_windows(ihalf, win);
+                for (unsigned ihalf = 0; ihalf < 2; ihalf++) {
+                    uint32_t win[16];
+                    load_windows(ihalf, win);
 #pragma unroll
-                for (unsigned ii = 0; ii < 4; ii++) {
-                    const uint32_t w4[4] = {win[ii], win[4 + ii], win[8 + ii], win[12 + ii]};
-                    round_end(4 * ihalf + ii, w4);
+                    for (unsigned ii = 0; ii < 4; ii++) {
+                        const uint32_t w4[4] = {win[ii], win[4 + ii], win[8 + ii], win[12 + ii]};
+                        round_end(full_c, 4 * ihalf + ii, w4);
+                    }
                 }
-            }
-        } else {
-            const uint32_t none[4] = {0, 0, 0, 0};
+            } else {
+                const uint32_t none[4] = {0, 0, 0, 0};
 #pragma unroll 1
-            for (unsigned i = 0; i < 8; i++) round_end(i, none);
-        }
+                for (unsigned i = 0; i < 8; i++) round_end(full_c, i, none);
+            }
+        };
+        if (wave_full) all_iterations(std::true_type{});
+        else all_iterations(std::false_type{});
     }
 }
 
