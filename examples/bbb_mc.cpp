@@ -4,7 +4,7 @@
 //
 //   bbb_mc [--matrix FILE] [--init HEX] [--gpus N] [--json 1]
 //          BER sweep:   [--prbs 31] [--bits 1e9] [--nv 8] [--ebn0 A:B:STEP] [--seeds N] [--shard bits|seeds|trials]
-//          AWGN fill:   --nsamples 1e9 [--steps 5]
+//          AWGN fill:   --nsamples 1e9 [--steps 5] [--staged 0|1]   (1, default: bbb_lutopt_set_staged, the two-kernel form)
 //          loopback:    --loopback BITS
 //
 // --matrix   the reference's 0/1 text format (software/rnghunt/matrices/256); default: the shipped n256 matrix
@@ -80,13 +80,14 @@ struct Matrix {
 
 // AWGN fill on one device: `steps` fills of n samples, device d of ndev taking every ndev-th piece of the stream
 struct FillResult { int rc = 0; std::string err; double kernel_ms = 0, seed_ms = 0, wall_s = 0; std::vector<int8_t> head; };
-static void fill_worker(const Matrix &m, unsigned long long init0, int dev, int ndev, uint64_t n, int steps, FillResult *res) {
+static void fill_worker(const Matrix &m, unsigned long long init0, int dev, int ndev, uint64_t n, int steps, int staged, FillResult *res) {
     auto body = [&]() -> int {
         if (hipSetDevice(dev) != hipSuccess) { res->err = "hipSetDevice failed"; return 1; }
         const uint64_t init[8] = {init0, 0, 0, 0, 0, 0, 0, 0};
         bbb_lutopt *h = nullptr;
         int rc = bbb_lutopt_create(&h, m.n, m.taps.data(), m.off.data(), init, dev);
         if (rc) { res->err = bbb_last_error_detail(); return rc; }
+        (void)bbb_lutopt_set_staged(h, staged);               // two-kernel form: the piece mover of step s beside step s+1
         int8_t *buf = nullptr;
         if (hipMalloc((void **)&buf, (n + 15) / 16 * 16) != hipSuccess) { res->err = "hipMalloc failed"; return 1; }
         auto first = [&](int s) { return (uint64_t)16 + ((uint64_t)s * (uint64_t)ndev + (uint64_t)dev) * n; };
@@ -114,7 +115,7 @@ static void fill_worker(const Matrix &m, unsigned long long init0, int dev, int 
 
 int main(int argc, char **argv) {
     std::string matrix, shard = "bits";
-    int k = 31, nv = 8, seeds = 1, gpus = 1, json = 0, steps = 5, multi = 0;
+    int k = 31, nv = 8, seeds = 1, gpus = 1, json = 0, steps = 5, multi = 0, staged = 1;
     unsigned long long init0 = 1;
     double bits = 1e9, from = 0, to = 10, step = 1, loopback = 0, nsamples = 0;
     for (int i = 1; i + 1 < argc; i += 2) {
@@ -139,6 +140,7 @@ int main(int argc, char **argv) {
         else if (a == "--shard") shard = v;
         else if (a == "--json") json = std::atoi(v);
         else if (a == "--multi") multi = std::atoi(v);
+        else if (a == "--staged") staged = std::atoi(v);
         else if (a == "--gen") { if (std::string(v) != "lutopt") { std::fprintf(stderr, "--gen lutopt is the only generator the reference has\n"); return 2; } }
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
@@ -173,8 +175,8 @@ int main(int argc, char **argv) {
         const uint64_t n = (uint64_t)nsamples;
         std::vector<FillResult> res((size_t)gpus);
         std::vector<std::thread> th;
-        for (int d = 1; d < gpus; d++) th.emplace_back(fill_worker, std::cref(m), init0, d, gpus, n, steps, &res[(size_t)d]);
-        fill_worker(m, init0, 0, gpus, n, steps, &res[0]);
+        for (int d = 1; d < gpus; d++) th.emplace_back(fill_worker, std::cref(m), init0, d, gpus, n, steps, staged, &res[(size_t)d]);
+        fill_worker(m, init0, 0, gpus, n, steps, staged, &res[0]);
         for (auto &t : th) t.join();
         double wall = 0, kms = 0;
         for (int d = 0; d < gpus; d++) {
