@@ -646,7 +646,7 @@ clt_tree_kernel(int nwords, const unsigned long long *__restrict states, unsigne
 // ---------------------------------------------------------------------------------------------
 template <int W32>
 static int seed_and_slice(int k, const uint32_t *d_tabs, const uint32_t *s16, uint64_t G, uint32_t *d_states,
-                          uint64_t stride, unsigned nlanes, uint32_t *d_planes, hipStream_t st) {
+                          uint64_t stride, unsigned nlanes, uint32_t *d_planes, hipStream_t st, int slice_mode) {
     Seed16 s;
     for (int i = 0; i < 16; i++)
         for (int w = 0; w < 16; w++) s.w[i][w] = w < W32 ? s16[i * 16 + w] : 0u;
@@ -672,6 +672,7 @@ static int seed_and_slice(int k, const uint32_t *d_tabs, const uint32_t *s16, ui
         hipLaunchKernelGGL((seed_level_kernel<W32>), dim3((unsigned)((n + 255) / 256), 3), dim3(256), lds, st, d_tabs, k, e,
                            (unsigned long long)G, (unsigned long long)stride, d_states);
     }
+    if (slice_mode == 1) return bitslice512p_launch(d_states, G, stride, nlanes, d_planes, st);
     const uint64_t threads = (uint64_t)nlanes * (uint64_t)((k + 31) / 32);
     hipLaunchKernelGGL((bitslice_kernel<W32>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, d_states,
                        (unsigned long long)G, (unsigned long long)stride, nlanes, k, d_planes);
@@ -680,15 +681,15 @@ static int seed_and_slice(int k, const uint32_t *d_tabs, const uint32_t *s16, ui
 }
 
 int awgn_seed_launch(int k, const uint32_t *d_tabs, const uint32_t *s16, uint64_t G, uint32_t *d_states,
-                     uint64_t stride, unsigned nlanes, uint32_t *d_planes, hipStream_t st) {
+                     uint64_t stride, unsigned nlanes, uint32_t *d_planes, hipStream_t st, int slice_mode) {
     switch ((k + 31) / 32) {
-    case 1: return seed_and_slice<1>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st);
-    case 2: return seed_and_slice<2>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st);
-    case 3: case 4: return seed_and_slice<4>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st);
-    case 5: case 6: return seed_and_slice<6>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st);
-    case 7: case 8: return seed_and_slice<8>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st);
-    case 9: case 10: case 11: case 12: return seed_and_slice<12>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st);
-    case 13: case 14: case 15: case 16: return seed_and_slice<16>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st);
+    case 1: return seed_and_slice<1>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st, slice_mode);
+    case 2: return seed_and_slice<2>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st, slice_mode);
+    case 3: case 4: return seed_and_slice<4>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st, slice_mode);
+    case 5: case 6: return seed_and_slice<6>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st, slice_mode);
+    case 7: case 8: return seed_and_slice<8>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st, slice_mode);
+    case 9: case 10: case 11: case 12: return seed_and_slice<12>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st, slice_mode);
+    case 13: case 14: case 15: case 16: return seed_and_slice<16>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st, slice_mode);
     default: return fail(BBB_EINVAL, "k must be in [2, 512]");
     }
 }

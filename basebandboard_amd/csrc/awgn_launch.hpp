@@ -8,8 +8,14 @@ namespace bbb {
 // B^(j*4^e): [e][j-1][k/4 * 16 * W32]) stored word-major with `stride` words per state word, and
 // their bit planes
 // s16: the first 16 start states, [16][16] words (host computed)
+// slice_mode 0: planes [k][nlanes], 32 generators per lane; 1: the packed n512 layout of awgn512.hip, 16 per lane
 int awgn_seed_launch(int k, const uint32_t *d_tabs, const uint32_t *s16, uint64_t G, uint32_t *d_states,
-                     uint64_t stride, unsigned nlanes, uint32_t *d_planes, hipStream_t st);
+                     uint64_t stride, unsigned nlanes, uint32_t *d_planes, hipStream_t st, int slice_mode = 0);
+// awgn512.hip: generated kernel for the shipped n512 matrix (packed state, 16 generators per lane, int16 out)
+bool awgn512p_matches(int k, const uint16_t *taps, const uint32_t *row_off);
+int bitslice512p_launch(const uint32_t *d_states, uint64_t G, uint64_t stride, unsigned nlanes, uint32_t *d_planes, hipStream_t st);
+int awgn512p_fill_launch(const uint32_t *d_planes, int16_t *dst, uint64_t nsamples, unsigned L, uint64_t G, unsigned nlanes,
+                         hipStream_t st);
 // staged: dst is a staging buffer [L/16 rounds][nlanes * 32 generator slots][16 bytes], to be moved by unstage_launch
 int awgn256_fill_launch(const uint32_t *d_planes, int8_t *dst, uint64_t nsamples, unsigned L, uint64_t G,
                         unsigned nlanes, bool staged, hipStream_t st);

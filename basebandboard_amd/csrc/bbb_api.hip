@@ -65,6 +65,7 @@ struct bbb_lutopt {
     bbb_custom_fill_fn custom_fill = nullptr;   // a kernel built for this very matrix (bbb_lutopt_set_custom_fill)
     bbb_custom_ber_fn custom_ber = nullptr;     // the BER kernels built for it (bbb_lutopt_set_custom_ber)
     int small_fast = 0;          // 16 / 32 / 64 / 128 when (k, taps) is the shipped matrix a generated small kernel exists for
+    bool fast512 = false;        // the shipped n512 matrix: packed-state kernel of awgn512.hip (int16 out)
     hipStream_t stream = nullptr;
     std::vector<uint16_t> taps;
     std::vector<uint32_t> row_off;
@@ -367,6 +368,30 @@ int awgn_fill(bbb_lutopt *h, void *dst, int elem_size, uint64_t nsamples, uint64
     BBB_HIP(hipSetDevice(h->device));
     uint64_t L, G;
     unsigned nlanes;
+    if (h->fast512 && elem_size == 2) {
+        // packed state, 16 generators per lane: 1024 per wave, segments in multiples of 8 samples (16-byte stores)
+        const uint64_t gmax = (uint64_t)h->max_waves * 1024;
+        L = (nsamples + gmax - 1) / gmax;
+        if (L < 64) L = 64;
+        L = (L + 7) / 8 * 8;
+        if (L > 0xffffff00ull) return fail(BBB_EINVAL, "nsamples too large for one call (segment length must fit 32 bits): split it");
+        G = (nsamples + L - 1) / L;
+        nlanes = (unsigned)((G + 1023) / 1024 * 64);
+        int rc5 = begin_op(h, false);
+        if (rc5) return rc5;
+        JumpPlan *plan;
+        if ((rc5 = get_plan(h, L, &plan))) return rc5;
+        if ((rc5 = grow(&h->d_states, &h->states_cap, (size_t)G * h->W32))) return rc5;
+        if ((rc5 = grow(&h->d_planes, &h->planes_cap, (size_t)2 * h->k * nlanes))) return rc5;
+        uint64_t s0[8];
+        h->pw->apply(first_step, h->init, s0);
+        uint32_t s16[256];
+        first16(*plan, s0, s16);
+        h->planes_valid = false;                 // (another layout than the one prepare_planes caches)
+        if ((rc5 = awgn_seed_launch(h->k, plan->d_cols, s16, G, h->d_states, G, nlanes, h->d_planes, h->cs, 1))) return rc5;
+        if ((rc5 = awgn512p_fill_launch(h->d_planes, (int16_t *)dst, nsamples, (unsigned)L, G, nlanes, h->cs))) return rc5;
+        return mark_planes_read(h);
+    }
     partition(h, nsamples, 16, &L, &G, &nlanes);
     if (L > 0xffffff00ull) return fail(BBB_EINVAL, "nsamples too large for one call (segment length must fit 32 bits): split it");
     const bool fast256 = h->specialised && elem_size == 1;
@@ -621,6 +646,7 @@ int bbb_lutopt_create(bbb_lutopt **out, int k, const uint16_t *taps, const uint3
     h->pw.reset(new GF2Powers(A));
     h->specialised = awgn256_matches(k, taps, row_off);
     h->small_fast = awgn_small_matches(k, taps, row_off);
+    h->fast512 = awgn512p_matches(k, taps, row_off);
     if (device == -1) {
         *out = h.release();
         return BBB_OK;

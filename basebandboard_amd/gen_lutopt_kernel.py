@@ -294,6 +294,131 @@ class StepEmitter:
                 self.emit(f"  cnt[{lev}] = {x};")
 
 
+class Packed512Emitter:
+    """n = 512 on a 256-register state: register p holds plane p of 16 generators in its low half and plane
+    256 + (p ^ 1) of the same 16 generators in its high half (p ^ 1: both planes of a register then carry the same sign in
+    the adder tree, popcount(256 + (p ^ 1)) = popcount(p) mod 2, so the counter's input complement folds into its truth
+    tables exactly as for n = 256).  New register p = XOR over tap PAIRS: the i-th tap of row p and the i-th tap of row
+    256 + (p ^ 1) are brought into one word by ONE V_PERM_B32 (either half of either source register into either half
+    of the result; a missing tap is the zero byte selector), then V_BITOP3 / V_XOR as before.  The counter runs on the
+    NEW state: 9 planes per half (0..256), the kernel adds the halves."""
+
+    def __init__(self, taps):
+        assert len(taps) == 512
+        self.taps = taps
+        self.out, self.nops, self.tmp_id = [], 0, 0
+        self.levels = [[] for _ in range(10)]
+        self.nlev = 9
+
+    def emit(self, s):
+        self.out.append(s)
+
+    def tmp(self):
+        self.tmp_id += 1
+        return f"t{self.tmp_id}"
+
+    @staticmethod
+    def where(c):
+        """plane c -> (register, first byte of its half)"""
+        return (c, 0) if c < 256 else ((c - 256) ^ 1, 2)
+
+    def reg_taps(self):
+        """registers read by new register p (for the row order)"""
+        return [sorted({self.where(c)[0] for c in self.taps[p] + self.taps[256 + (p ^ 1)]}) for p in range(256)]
+
+    def push(self, level, item):
+        if level >= self.nlev:
+            return
+        lv = self.levels[level]
+        lv.append(item)
+        while len(lv) >= 3:
+            (a, ia), (b, ib), (c, ic) = lv[:3]
+            del lv[:3]
+            s = self.tmp()
+            self.emit(f"  const uint32_t {s} = __builtin_amdgcn_bitop3_b32({a}, {b}, {c}, 0x{tt3(lambda x, y, z: x ^ y ^ z, (ia, ib, ic)):02x});")
+            self.nops += 1
+            if level + 1 < self.nlev:
+                cy = self.tmp()
+                self.emit(f"  const uint32_t {cy} = __builtin_amdgcn_bitop3_b32({a}, {b}, {c}, 0x{tt3(lambda x, y, z: (x & y) | (x & z) | (y & z), (ia, ib, ic)):02x});")
+                self.nops += 1
+                self.push(level + 1, (cy, 0))
+            lv.append((s, 0))
+
+    def body(self, order):
+        for p in order:
+            lo, hi = self.taps[p], self.taps[256 + (p ^ 1)]
+            terms = []
+            for i in range(max(len(lo), len(hi))):
+                x = self.where(lo[i]) if i < len(lo) else None
+                y = self.where(hi[i]) if i < len(hi) else None
+                xb = [x[1], x[1] + 1] if x else [0x0c, 0x0c]
+                yb = [4 + y[1], 5 + y[1]] if y else [0x0c, 0x0c]
+                sel = xb[0] | xb[1] << 8 | yb[0] << 16 | yb[1] << 24
+                xr = f"a[{x[0]}]" if x else "0u"
+                yr = f"a[{y[0]}]" if y else "0u"
+                if x and y and x[0] == y[0] and sel == 0x07060100:
+                    terms.append(xr)                      # both halves already in place
+                    continue
+                v = self.tmp()
+                self.emit(f"  const uint32_t {v} = __builtin_amdgcn_perm({yr}, {xr}, 0x{sel:08x}u);")
+                self.nops += 1
+                terms.append(v)
+            while len(terms) > 3:
+                x3, terms = terms[:3], terms[3:]
+                v = self.tmp()
+                self.emit(f"  const uint32_t {v} = __builtin_amdgcn_bitop3_b32({x3[0]}, {x3[1]}, {x3[2]}, 0x96);")
+                self.nops += 1
+                terms.insert(0, v)
+            if len(terms) == 3:
+                self.emit(f"  b[{p}] = __builtin_amdgcn_bitop3_b32({terms[0]}, {terms[1]}, {terms[2]}, 0x96);")
+            elif len(terms) == 2:
+                self.emit(f"  b[{p}] = {terms[0]} ^ {terms[1]};")
+            else:
+                self.emit(f"  b[{p}] = {terms[0]};")
+            self.nops += 1
+            self.push(0, (f"b[{p}]", bin(p).count("1") & 1))
+        for lev in range(self.nlev):
+            lv = self.levels[lev]
+            while len(lv) > 1:
+                assert len(lv) == 2
+                (a, ia), (b, ib) = lv
+                del lv[:]
+                s = self.tmp()
+                self.emit(f"  const uint32_t {s} = __builtin_amdgcn_bitop3_b32({a}, {b}, {b}, 0x{tt3(lambda x, y, z: x ^ y, (ia, ib, ib)):02x});")
+                self.nops += 1
+                if lev + 1 < self.nlev:
+                    cy = self.tmp()
+                    self.emit(f"  const uint32_t {cy} = __builtin_amdgcn_bitop3_b32({a}, {b}, {b}, 0x{tt3(lambda x, y, z: x & y, (ia, ib, ib)):02x});")
+                    self.nops += 1
+                    self.push(lev + 1, (cy, 0))
+                lv.append((s, 0))
+            (x, ix), = lv
+            assert ix == 0
+            self.emit(f"  cnt[{lev}] = {x};")
+
+
+def generate_packed512(taps):
+    """The n = 512 form: see Packed512Emitter.  cnt[q], q = 0..8: bit q of the number of +1 terms among planes 0..255
+    (low half) and among planes 256..511 (high half) of the NEW state, per generator."""
+    out = []
+    emit = out.append
+    emit("// GENERATED by tools/gen_lutopt_kernel.py from lutopt_512.taps -- do not edit.")
+    flat = ",".join(",".join(map(str, t)) for t in taps)
+    emit(f"#define LUTOPT512_TAPS_CRC 0x{zlib.crc32(flat.encode()) & 0xffffffff:08x}u")
+    e = Packed512Emitter(taps)
+    order = row_order(256, e.reg_taps())
+    e.body(order)
+    emit("// packed state: register p = plane p (bits 0..15: generators 0..15) | plane 256 + (p ^ 1) (bits 16..31)")
+    emit("static __device__ __forceinline__ void lutopt512p_step_new(const uint32_t (&a)[256], uint32_t (&b)[256], uint32_t (&cnt)[9])")
+    emit("{")
+    out.extend(e.out)
+    emit("}")
+    emit(f"// {e.nops} VALU ops per step for 16 samples per lane")
+    emit(f"static const uint16_t LUTOPT512_NTAPS[512] = {{{','.join(str(len(t)) for t in taps)}}};")
+    emit(f"static const uint16_t LUTOPT512_TAPS[{sum(len(t) for t in taps)}] = {{{flat}}};")
+    return "\n".join(out) + "\n", e.nops
+
+
 # (suffix, planes resident in VGPRs at any point) of the parked variants (n = 256 only).  180 is the
 # measured optimum for the sample kernel: above it hipcc adds its own AGPR spills on top
 PARK_VARIANTS = (("", 180),)
@@ -364,7 +489,7 @@ def generate(n, taps):
 
 def main():
     n, taps = load(sys.argv[1])
-    text, nops = generate(n, taps)
+    text, nops = generate_packed512(taps) if n == 512 else generate(n, taps)
     open(sys.argv[2], "w").write(text)
     print(f"n={n}: {nops} ops/step -> {sys.argv[2]}")
 

@@ -130,3 +130,67 @@ def test_transpose32_and_gen_index(tmp_path):
     seen = {lib.gidx(w, l, j) for w in range(3) for l in range(64) for j in range(32)}
     assert seen == set(range(3 * 2048))
     assert lib.gidx(2, 5, 7) == (2 * 32 + 7) * 64 + 5
+
+
+HARNESS512 = r"""
+#include <cstdint>
+#include <cstring>
+#define __device__
+#define __forceinline__ inline
+static inline uint32_t __builtin_amdgcn_bitop3_b32(uint32_t a, uint32_t b, uint32_t c, unsigned tt) {
+  uint32_t r = 0;
+  for (int i = 0; i < 8; i++) if ((tt >> i) & 1) { uint32_t m = ~0u; m &= (i & 4) ? a : ~a; m &= (i & 2) ? b : ~b; m &= (i & 1) ? c : ~c; r |= m; }
+  return r;
+}
+// V_PERM_B32: the 8 source bytes are {hi, lo} (lo = bytes 0..3); selector byte 0x0c yields 0x00
+static inline uint32_t __builtin_amdgcn_perm(uint32_t hi, uint32_t lo, uint32_t sel) {
+  const uint64_t in = ((uint64_t)hi << 32) | lo;
+  uint32_t r = 0;
+  for (int i = 0; i < 4; i++) { const unsigned s = (sel >> (8 * i)) & 0xff; if (s < 8) r |= (uint32_t)((in >> (8 * s)) & 0xff) << (8 * i); }
+  return r;
+}
+#include "GEN_INC"
+extern "C" void step_new(const uint32_t* a, uint32_t* b, uint32_t* cnt) {
+  uint32_t A[256], B[256], Cn[9]; memcpy(A, a, sizeof A); lutopt512p_step_new(A, B, Cn); memcpy(b, B, sizeof B); memcpy(cnt, Cn, sizeof Cn);
+}
+"""
+
+
+def test_packed_n512_network_matches_oracle(oracle, tmp_path):
+    """n = 512 on 256 registers: register p = plane p of 16 generators (low half) | plane 256 + (p ^ 1) (high half).
+    The generated step (V_PERM pairs + XOR) and the two half counters against the oracle, 16 generators, 10 steps."""
+    inc = tmp_path / "lutopt512_gen.inc"
+    subprocess.check_call([sys.executable, str(ROOT / "tools" / "gen_lutopt_kernel.py"),
+                           str(ROOT / "basebandboard_amd" / "data" / "lutopt_512.taps"), str(inc)])
+    src = tmp_path / "h512.cpp"
+    src.write_text(HARNESS512.replace("GEN_INC", inc.name))
+    so = tmp_path / "h512.so"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", f"-I{tmp_path}", str(src), "-o", str(so)])
+    lib = C.CDLL(str(so))
+    m = oracle.Lutopt(path=oracle.data_path(512))
+    rng = np.random.default_rng(512)
+    states = [int.from_bytes(rng.bytes(64), "little") for _ in range(16)]
+    states[0], states[1] = 1, (1 << 512) - 1
+
+    def pack(sts):
+        a = np.zeros(256, dtype=np.uint32)
+        for g, s in enumerate(sts):
+            for p in range(256):
+                if (s >> p) & 1:
+                    a[p] |= np.uint32(1 << g)
+                if (s >> (256 + (p ^ 1))) & 1:
+                    a[p] |= np.uint32(1 << (16 + g))
+        return a
+
+    a = pack(states)
+    P = lambda x: x.ctypes.data_as(C.POINTER(C.c_uint32))  # noqa: E731
+    for _ in range(10):
+        b, cnt = np.zeros(256, dtype=np.uint32), np.zeros(9, dtype=np.uint32)
+        lib.step_new(P(a), P(b), P(cnt))
+        states = [m.step_int(s) for s in states]
+        assert np.array_equal(b, pack(states))
+        for g in range(16):
+            lo = sum(((int(cnt[q]) >> g) & 1) << q for q in range(9))
+            hi = sum(((int(cnt[q]) >> (16 + g)) & 1) << q for q in range(9))
+            assert lo + hi - 256 == m.clt_tree(states[g])          # T = number of +1 terms, tree = T - n/2
+        a = b
