@@ -310,14 +310,21 @@ awgn256_kernel(const uint32_t *__restrict planes, void *__restrict dst_, unsigne
         };
         // FULL: every generator of this wave exists and its whole segment lies inside the request (all waves but the
         // last): no per-generator bounds, no divergent branches
-        auto round_end = [&](auto full_c, const unsigned i, const uint32_t (&w4)[4]) {
+        asm volatile("" ::: "memory");      // (keeps hipcc from pulling the round end's first LDS reads into the step loop)
+        // the 16 staged words of iteration i (4 steps x 4 groups); read one iteration AHEAD of their use: beside the seeding
+        // kernel, which saturates the CU's LDS, a read takes microseconds
+        auto load_z = [&](const unsigned i, uint32_t (&zz)[16]) {
+#pragma unroll
+            for (int w = 0; w < 4; w++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) zz[4 * w + t] = Z[((4 * w + t) * 8 + i) * 64 + lane];
+        };
+        auto round_end = [&](auto full_c, const unsigned i, const uint32_t (&w4)[4], const uint32_t (&zz)[16]) {
             constexpr bool FULL = decltype(full_c)::value;
             uint32_t o[4][4];                 // o[w][q] after the transposes
 #pragma unroll
             for (int w = 0; w < 4; w++) {
-                uint32_t z[4];
-#pragma unroll
-                for (int t = 0; t < 4; t++) z[t] = Z[((4 * w + t) * 8 + i) * 64 + lane];
+                uint32_t z[4] = {zz[4 * w], zz[4 * w + 1], zz[4 * w + 2], zz[4 * w + 3]};
                 transpose4x4_bytes(z);        // z[q] = bytes (t = 4w..4w+3) of generator 8q+i
 #pragma unroll
                 for (int q = 0; q < 4; q++) o[w][q] = z[q];
@@ -393,16 +400,28 @@ awgn256_kernel(const uint32_t *__restrict planes, void *__restrict dst_, unsigne
                 for (unsigned ihalf = 0; ihalf < 2; ihalf++) {
                     uint32_t win[16];
                     load_windows(ihalf, win);
+                    uint32_t zc[16], zn[16];
+                    load_z(4 * ihalf, zn);
 #pragma unroll
                     for (unsigned ii = 0; ii < 4; ii++) {
+#pragma unroll
+                        for (int e = 0; e < 16; e++) zc[e] = zn[e];
+                        if (ii < 3) load_z(4 * ihalf + ii + 1, zn);
                         const uint32_t w4[4] = {win[ii], win[4 + ii], win[8 + ii], win[12 + ii]};
-                        round_end(full_c, 4 * ihalf + ii, w4);
+                        round_end(full_c, 4 * ihalf + ii, w4, zc);
                     }
                 }
             } else {
                 const uint32_t none[4] = {0, 0, 0, 0};
+                uint32_t zc[16], zn[16];
+                load_z(0, zn);
 #pragma unroll 1
-                for (unsigned i = 0; i < 8; i++) round_end(full_c, i, none);
+                for (unsigned i = 0; i < 8; i++) {
+#pragma unroll
+                    for (int e = 0; e < 16; e++) zc[e] = zn[e];
+                    load_z((i + 1) & 7, zn);          // (the last one re-reads iteration 0: harmless, keeps the loop uniform)
+                    round_end(full_c, i, none, zc);
+                }
             }
         };
         if (wave_full) all_iterations(std::true_type{});
@@ -653,7 +672,9 @@ static int seed_and_slice(int k, const uint32_t *d_tabs, const uint32_t *s16, ui
     int levels = 0;                                   // radix-4 levels needed: 4^levels >= G
     while ((1ull << (2 * levels)) < G) levels++;
     const int nnib_h = (k + 3) / 4, half_h = (nnib_h + 1) / 2 + ((nnib_h + 1) / 2 & 1);
-    const size_t lds = (size_t)half_h * 16 * W32 * sizeof(uint32_t);      // half a table at a time
+    size_t lds = (size_t)half_h * 16 * W32 * sizeof(uint32_t);      // half a table at a time
+    if (env_knob("BBB_SEED_LDS_KB", 0) > 0 && lds < (size_t)env_knob("BBB_SEED_LDS_KB", 0) * 1024)
+        lds = (size_t)env_knob("BBB_SEED_LDS_KB", 0) * 1024;        // (experiments: fewer seeding blocks per CU beside the sample kernel)
     if (lds > 48 * 1024) {     // per device (hipFuncSetAttribute applies to the current one), guarded
         static std::mutex mu;
         static bool attr_set[64] = {false};
