@@ -112,7 +112,8 @@ struct bbb_lutopt {
     hipEvent_t stage_free[2] = {nullptr, nullptr};     // recorded on ys after the mover that read the buffer
     bool stage_busy[2] = {false, false};
     int stage_slot = 0;
-    hipEvent_t ev_arith = nullptr, ev_user = nullptr;
+    hipEvent_t ev_user = nullptr;
+    int pf_waited_slot = -1;              // staging slot whose mover the pending prefetch's seeding waited for
     hipEvent_t cur_last_read = nullptr;   // same, for the buffers currently in d_states / d_planes
     bool cur_read_pending = false;
     // optional per-call device timing of the generator kernels (bbb_lutopt_profile)
@@ -302,8 +303,11 @@ int prepare_planes(bbb_lutopt *h, uint64_t first, uint64_t L, uint64_t G, unsign
 }
 
 // the start states of (first_step, L, G): those an announced prefetch seeded on the side stream, or seeded now
-int acquire_planes(bbb_lutopt *h, uint64_t first_step, uint64_t L, uint64_t G, unsigned nlanes, bool may_use_prefetch) {
+int acquire_planes(bbb_lutopt *h, uint64_t first_step, uint64_t L, uint64_t G, unsigned nlanes, bool may_use_prefetch,
+                   bool *from_prefetch = nullptr) {
+    if (from_prefetch) *from_prefetch = false;
     if (may_use_prefetch && h->pf.valid && h->pf.first == first_step && h->pf.L == L && h->pf.G == G) {
+        if (from_prefetch) *from_prefetch = true;
         // the announced fill: its start states were seeded on the side stream -- swap them in
         BBB_HIP(hipStreamWaitEvent(h->cs, h->pf.seeded, 0));
         std::swap(h->d_states, h->pf.d_states); std::swap(h->states_cap, h->pf.states_cap);
@@ -325,14 +329,17 @@ int acquire_planes(bbb_lutopt *h, uint64_t first_step, uint64_t L, uint64_t G, u
 //   caller's stream waits for the mover: whatever the caller queues next sees `dst` complete, as with one kernel.
 // Since the next call's arithmetic does not wait for this call's mover, the mover (HBM-bound, a few registers per
 // lane) runs beside it (integer-issue bound, one wave per SIMD).  Two staging buffers alternate.
+// planes_seeded_after_mover: the start states came from a prefetch whose seeding had itself waited for the mover that last
+// read this staging buffer (bbb_awgn_prefetch on a staged handle), so the arithmetic need not wait for it again -- every
+// event wait is a barrier packet of several microseconds between two sample kernels.
 template <typename LaunchArith>
 int staged_fill(bbb_lutopt *h, void *dst, uint64_t nbytes, int piece, uint64_t L, uint64_t G, unsigned nlanes,
-                bbb_lutopt::ProfEv *ev, LaunchArith launch_arith) {
+                bbb_lutopt::ProfEv *ev, bool planes_seeded_after_mover, LaunchArith launch_arith) {
     const uint64_t Gpad = (uint64_t)nlanes * 32;
     const unsigned rounds = (unsigned)(L / 16);
     const size_t need_words = (size_t)(Gpad * rounds * (uint64_t)piece / 4);
     const int slot = h->stage_slot ^= 1;
-    for (hipEvent_t *e : {&h->stage_free[slot], &h->ev_arith, &h->ev_user})
+    for (hipEvent_t *e : {&h->stage_free[slot], &h->ev_user})
         if (!*e) BBB_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     if (h->stage_cap[slot] < need_words) {
         if (h->stage_busy[slot]) BBB_HIP(hipEventSynchronize(h->stage_free[slot]));     // growing frees the old buffer
@@ -340,16 +347,16 @@ int staged_fill(bbb_lutopt *h, void *dst, uint64_t nbytes, int piece, uint64_t L
         int rc = grow(&h->d_stage[slot], &h->stage_cap[slot], need_words);
         if (rc) return rc;
     }
-    if (h->stage_busy[slot]) BBB_HIP(hipStreamWaitEvent(h->cs, h->stage_free[slot], 0));   // its last mover has read it
+    if (h->stage_busy[slot] && !(planes_seeded_after_mover && h->pf_waited_slot == slot))
+        BBB_HIP(hipStreamWaitEvent(h->cs, h->stage_free[slot], 0));   // its last mover has read it
     if (ev) BBB_HIP(hipEventRecord(ev->e1, h->cs));
     int rc = launch_arith((void *)h->d_stage[slot]);
     if (rc) return rc;
     if ((rc = mark_planes_read(h))) return rc;
     if (ev) BBB_HIP(hipEventRecord(ev->e2, h->cs));
-    BBB_HIP(hipEventRecord(h->ev_arith, h->cs));
     BBB_HIP(hipEventRecord(h->ev_user, h->stream));
     BBB_HIP(hipStreamWaitEvent(h->ys, h->ev_user, 0));
-    BBB_HIP(hipStreamWaitEvent(h->ys, h->ev_arith, 0));
+    BBB_HIP(hipStreamWaitEvent(h->ys, h->cur_last_read, 0));         // recorded right behind the arithmetic (mark_planes_read)
     if ((rc = unstage_launch(h->d_stage[slot], dst, nbytes, (unsigned)(L * (uint64_t)piece / 16), G, Gpad, rounds, piece, h->ys))) return rc;
     BBB_HIP(hipEventRecord(h->stage_free[slot], h->ys));
     h->stage_busy[slot] = true;
@@ -403,10 +410,11 @@ int awgn_fill(bbb_lutopt *h, void *dst, int elem_size, uint64_t nsamples, uint64
         BBB_HIP(hipEventCreate(&ev.e0)); BBB_HIP(hipEventCreate(&ev.e1)); BBB_HIP(hipEventCreate(&ev.e2));
         BBB_HIP(hipEventRecord(ev.e0, h->cs));
     }
-    rc = acquire_planes(h, first_step, L, G, nlanes, fast256);
+    bool from_pf = false;
+    rc = acquire_planes(h, first_step, L, G, nlanes, fast256, &from_pf);
     if (rc) return rc;
     if (staged) {
-        rc = staged_fill(h, dst, nsamples, 16, L, G, nlanes, h->profiling ? &ev : nullptr, [&](void *stage) {
+        rc = staged_fill(h, dst, nsamples, 16, L, G, nlanes, h->profiling ? &ev : nullptr, from_pf, [&](void *stage) {
             return awgn256_fill_launch(h->d_planes, (int8_t *)stage, nsamples, (unsigned)L, G, nlanes, true, h->cs);
         });
         if (h->profiling) h->prof_pending.push_back(ev);
@@ -674,7 +682,7 @@ int bbb_lutopt_destroy(bbb_lutopt *h) {
                     (void *)h->d_txbits, (void *)h->pf.d_states, (void *)h->pf.d_planes})
         (void)hipFree(p);
     for (hipEvent_t e : {h->pf.seeded, h->pf.last_read, h->cur_last_read, h->handover, h->stage_free[0], h->stage_free[1],
-                         h->ev_arith, h->ev_user})
+                         h->ev_user})
         if (e) (void)hipEventDestroy(e);
     for (hipStream_t st : {h->side, h->xs, h->ys})
         if (st) (void)hipStreamDestroy(st);
@@ -777,7 +785,11 @@ int bbb_awgn_prefetch(bbb_lutopt *h, uint64_t nsamples, uint64_t first_step) {
     // waves, 416 registers each, wait for a SIMD.  The guests of fill s are the piece mover of fill s-1 and this seeding
     // (for fill s+1): the seeding waits for that mover.  (The mover of fill s itself starts when fill s has finished.)
     const hipStream_t side = h->side;
-    if (h->staged_mode && h->stage_busy[h->stage_slot ^ 1]) BBB_HIP(hipStreamWaitEvent(side, h->stage_free[h->stage_slot ^ 1], 0));
+    h->pf_waited_slot = -1;
+    if (h->staged_mode && h->stage_busy[h->stage_slot ^ 1]) {
+        BBB_HIP(hipStreamWaitEvent(side, h->stage_free[h->stage_slot ^ 1], 0));
+        h->pf_waited_slot = h->stage_slot ^ 1;
+    }
     if (!pf.seeded) BBB_HIP(hipEventCreateWithFlags(&pf.seeded, hipEventDisableTiming));
     // the buffers may still be read by the sample kernel that used them last (main stream)
     if (pf.read_pending) BBB_HIP(hipStreamWaitEvent(side, pf.last_read, 0));
@@ -992,14 +1004,15 @@ int bbb_tx_fill_i16(bbb_lutopt *h, const bbb_tx_cfg *cfg, int16_t *out_dev, uint
             else rc = pulse_bits_launch(bits64, m0, (nbits + 63) / 64, h->cs);
             if (rc) return rc;
         }
-        if ((rc = acquire_planes(h, cfg->warmup + first_sample, L, G, nlanes, true))) return rc;      // tx.py:70-71
+        bool from_pf = false;
+        if ((rc = acquire_planes(h, cfg->warmup + first_sample, L, G, nlanes, true, &from_pf))) return rc;      // tx.py:70-71
         const uint32_t rel_base = (uint32_t)(FM - 7 - (m0 - 128));
         auto arith = [&](void *dst, bool to_stage) {
             return awgn256_tx_launch(h->d_planes, (int16_t *)dst, nsamples, (unsigned)L, G, nlanes, cfg->coeffs, h->d_txbits,
                                      (uint32_t)(words64 * 2), rel_base, (uint32_t)(F & 7), cfg->noise_var, cfg->bit_en, use_bits ? 1 : 0,
                                      to_stage, h->cs);
         };
-        if (staged) return staged_fill(h, out_dev, nsamples * 2, 32, L, G, nlanes, nullptr, [&](void *stage) { return arith(stage, true); });
+        if (staged) return staged_fill(h, out_dev, nsamples * 2, 32, L, G, nlanes, nullptr, from_pf, [&](void *stage) { return arith(stage, true); });
         rc = arith(out_dev, false);
         return rc ? rc : mark_planes_read(h);
     }

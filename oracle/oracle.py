@@ -180,8 +180,10 @@ class Lutopt:
     def clt_wrap(self, v):
         return self._l.bbo_clt_wrap(v, self.k)
 
-    def awgn(self, init, first_step, nsamples, fast=False):
-        out = np.empty(nsamples, dtype=np.int8)
+    def awgn(self, init, first_step, nsamples, fast=False, out=None):
+        if out is None:
+            out = np.empty(nsamples, dtype=np.int8)
+        assert out.dtype == np.int8 and out.size >= nsamples and out.flags.c_contiguous
         f = self._l.bbo_awgn_stream_i8_fast256 if fast else self._l.bbo_awgn_stream_i8
         f(C.byref(self._m), _u64(int_to_words(init, self.k)), first_step, nsamples,
           out.ctypes.data_as(C.POINTER(C.c_int8)))
