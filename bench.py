@@ -67,6 +67,17 @@ def cpu_baseline():
     # its own buffer, allocated and touched BEFORE the clock starts: with fresh buffers inside the timed region the
     # threads spent their time in page faults behind the process's one address-space lock (0.28 Gsample/s on 256 threads)
     ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None                                    # a container's CPU share (cgroup quota), where one is set
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: None if t.split()[0] == "max" else int(t.split()[0]) / int(t.split()[1])),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: None if int(t) <= 0 else int(t) / 100000.0)):
+        try:
+            quota = parse(open(path).read().strip())
+            if quota:
+                break
+        except Exception:
+            pass
+    if quota:
+        ncores = max(1, min(ncores, int(quota + 0.999)))
     nthr = max(1, min(ncores, 512))
     per = 4 if nthr <= 64 else 2                    # pieces per thread
     nt = 10_000_000
@@ -85,7 +96,8 @@ def cpu_baseline():
     n_all = nthr * per * nt
     return {"value": round(n_all / dtn / 1e9, 5), "unit": "Gsample/s", "cores": nthr, "kind": "port",
             "sample": f"{nthr * per} x {nt} samples of the same stream, {per} pieces per thread on {nthr} threads (all the cores this "
-                      f"process may use; the host reports {os.cpu_count()} logical cores); oracle k=256 byte-table path, "
+                      f"process may use: affinity {len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else '?'}, "
+                      f"cgroup quota {quota}; the host reports {os.cpu_count()} logical cores); oracle k=256 byte-table path, "
                       f"gcc -O3 -march=native",
             "single_core_value": round(reps * n / dt / 1e9, 5), "single_core_sample": f"{reps} x {n} samples on one core"}
 
