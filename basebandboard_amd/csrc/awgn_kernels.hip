@@ -790,6 +790,73 @@ int awgn_generic_fill_launch(int k, const uint16_t *d_taps, const uint32_t *d_ro
     return BBB_OK;
 }
 
+// The word stream of the shipped n256 matrix on the generated network: the step of the sample kernel (its counter is
+// dead code here), then the 256 new planes go back to one word per generator by eight 32 x 32 bit transposes, two at a
+// time in the registers the old state has just vacated -> four 8-byte stores per generator and step (one 32-byte piece
+// once L2 has merged them).  MSB: bit 32j of the state is the MSB of word j (verify.py:46-52) -- the planes simply enter
+// the transposes in reverse order.
+template <bool MSB>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+words256_kernel(const uint32_t *__restrict planes, uint32_t *__restrict dst, unsigned long long nstates, unsigned L,
+                unsigned long long G, unsigned nlanes) {
+    const unsigned lane = threadIdx.x;
+    const unsigned long long wave = blockIdx.x;
+    const unsigned long long LG = wave * 64 + lane;
+    __builtin_amdgcn_s_setprio(3);
+    uint32_t a[256], b[256], pa[256], pb[256], cnt[8];
+#pragma unroll
+    for (int p = 0; p < 256; p++) a[p] = planes[(size_t)p * nlanes + LG];
+#define BBB_PARK(p) BBB_ACC_WRITE(pa[p], a[p]);
+    LUTOPT256_FOR_PARKED(BBB_PARK)
+#undef BBB_PARK
+    // emit state `x` (VGPR part) / `px` (AGPR part) as state number t of every generator of this lane
+    auto emit = [&](const uint32_t (&x)[256], const uint32_t (&px)[256], const unsigned t) {
+#pragma unroll
+        for (int h = 0; h < 4; h++) {
+            uint32_t q[2][32];
+#pragma unroll
+            for (int w = 0; w < 2; w++) {
+#pragma unroll
+                for (int e = 0; e < 32; e++) {
+                    const int p = 32 * (2 * h + w) + (MSB ? 31 - e : e);
+                    if (lutopt256_is_parked(p)) BBB_ACC_READ(q[w][e], px[p]);
+                    else q[w][e] = x[p];
+                }
+                transpose32(q[w]);                // q[w][j] = word 2h + w of generator j
+            }
+#pragma unroll
+            for (unsigned j = 0; j < 32; j++) {
+                const unsigned long long g = gen_index(wave, lane, j);
+                const unsigned long long st = g * L + t;
+                if (g < G && st < nstates) {
+                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                    const u32x2 v = {q[0][j], q[1][j]};
+                    *reinterpret_cast<u32x2 *>(dst + st * 8 + 2 * h) = v;
+                }
+            }
+        }
+    };
+#pragma unroll 1
+    for (unsigned t = 0; t < L; t += 2) {
+        lutopt256_step_parked(a, pa, b, pb, cnt);
+        emit(b, pb, t);
+        lutopt256_step_parked(b, pb, a, pa, cnt);
+        if (t + 1 < L) emit(a, pa, t + 1);
+    }
+}
+
+int lutopt_words256_launch(const uint32_t *d_planes, uint32_t *dst, uint64_t nstates, unsigned L, uint64_t G, unsigned nlanes,
+                           bool msb_first, hipStream_t st) {
+    if (msb_first)
+        hipLaunchKernelGGL(words256_kernel<true>, dim3(nlanes / 64), dim3(64), 0, st, d_planes, dst, (unsigned long long)nstates, L,
+                           (unsigned long long)G, nlanes);
+    else
+        hipLaunchKernelGGL(words256_kernel<false>, dim3(nlanes / 64), dim3(64), 0, st, d_planes, dst, (unsigned long long)nstates, L,
+                           (unsigned long long)G, nlanes);
+    BBB_HIP(hipGetLastError());
+    return BBB_OK;
+}
+
 int lutopt_words_launch(int k, const uint16_t *d_taps, const uint32_t *d_row_off, uint32_t *d_planes2, uint32_t *dst,
                         uint64_t nstates, unsigned L, uint64_t G, unsigned nlanes, bool msb_first, hipStream_t st) {
     hipLaunchKernelGGL(lutopt_words_kernel, dim3(nlanes / 64), dim3(64), 0, st, k, d_taps, d_row_off, d_planes2, dst,

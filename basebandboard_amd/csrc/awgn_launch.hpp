@@ -35,6 +35,9 @@ int awgn_generic_fill_launch(int k, const uint16_t *d_taps, const uint32_t *d_ro
 // LUTOPT.x as 32-bit words, k/32 per state (k a multiple of 32), table driven
 int lutopt_words_launch(int k, const uint16_t *d_taps, const uint32_t *d_row_off, uint32_t *d_planes2, uint32_t *dst,
                         uint64_t nstates, unsigned L, uint64_t G, unsigned nlanes, bool msb_first, hipStream_t st);
+// the same for the shipped n256 matrix on the generated network (dst 16-byte aligned)
+int lutopt_words256_launch(const uint32_t *d_planes, uint32_t *dst, uint64_t nstates, unsigned L, uint64_t G, unsigned nlanes,
+                           bool msb_first, hipStream_t st);
 int clt_tree_launch(int k, const uint64_t *states, uint64_t nstates, int16_t *out, hipStream_t st);
 bool awgn256_matches(int k, const uint16_t *taps, const uint32_t *row_off);
 // awgn_small.hip: generated kernels for the shipped n16 / n32 / n64 / n128 matrices

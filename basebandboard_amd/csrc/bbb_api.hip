@@ -837,11 +837,16 @@ int bbb_lutopt_fill_words(bbb_lutopt *h, uint32_t *dst_dev, uint64_t nstates, ui
     BBB_HIP(hipSetDevice(h->device));
     uint64_t L, G;
     unsigned nlanes;
-    partition(h, nstates, 1, &L, &G, &nlanes);
+    const bool fast = h->specialised && !((uintptr_t)dst_dev & 7);
+    partition(h, nstates, fast ? 2 : 1, &L, &G, &nlanes);
     int rc = begin_op(h, false);
     if (rc) return rc;
     rc = prepare_planes(h, first_step, L, G, nlanes);
     if (rc) return rc;
+    if (fast) {        // the shipped n256 matrix: generated network, planes stay valid (not advanced in place)
+        rc = lutopt_words256_launch(h->d_planes, dst_dev, nstates, (unsigned)L, G, nlanes, msb_first != 0, h->cs);
+        return rc ? rc : mark_planes_read(h);
+    }
     h->planes_valid = false;    // the table-driven kernel advances the planes in place
     rc = lutopt_words_launch(h->k, h->d_taps, h->d_row_off, h->d_planes, dst_dev, nstates, (unsigned)L, G, nlanes,
                              msb_first != 0, h->cs);
