@@ -210,7 +210,6 @@ struct TxFuse {
     int32_t bit_en;           // 0: shaped = 0 (tx.py:65-66)
     int32_t use_bits;         // 0: every data bit reads as 0
     uint32_t last_word;       // index of the last 32-bit word of the buffer that may be read
-    int32_t low_prio;         // (experiments) run at the default wave priority instead of the highest
 };
 
 // (mask & a) | (~mask & b) with a wave-uniform mask: ONE V_BFI_B32 (left to itself hipcc turns the uniform mask into
@@ -240,8 +239,7 @@ awgn256_kernel(const uint32_t *__restrict planes, void *__restrict dst_, unsigne
     const unsigned long long LG = wave * 64 + lane;
     // highest wave priority: when the seeding of the next fill (bbb_awgn_prefetch) shares the SIMD it gets the
     // issue slots this wave leaves free instead of every other one
-    if (tx.low_prio) __builtin_amdgcn_s_setprio(0);
-    else __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(3);
 
     uint32_t selmask[4] = {0, 0, 0, 0};
     if (TX) {
@@ -718,8 +716,7 @@ int awgn_seed_launch(int k, const uint32_t *d_tabs, const uint32_t *s16, uint64_
 int awgn256_fill_launch(const uint32_t *d_planes, int8_t *dst, uint64_t nsamples, unsigned L, uint64_t G,
                         unsigned nlanes, bool staged, hipStream_t st) {
     const unsigned nwaves = nlanes / 64;
-    TxFuse none{};
-    none.low_prio = env_knob("BBB_AWGN_LOW_PRIO", 0);
+    const TxFuse none{};
     if (staged)
         hipLaunchKernelGGL((awgn256_kernel<false, true>), dim3(nwaves), dim3(64), 0, st, d_planes, (void *)dst, (unsigned long long)nsamples, L,
                            (unsigned long long)G, nlanes, none);
@@ -761,7 +758,6 @@ int awgn256_tx_launch(const uint32_t *d_planes, int16_t *dst, uint64_t nsamples,
     tx.c0 = c0;
     tx.noise_var = noise_var;
     tx.bit_en = bit_en;
-    tx.low_prio = env_knob("BBB_AWGN_LOW_PRIO", 0);
     tx.use_bits = use_bits && nwords32 >= 2;
     tx.last_word = nwords32 ? nwords32 - 1 : 1;
     if (staged)
