@@ -4,6 +4,7 @@
 #include "awgn_launch.hpp"
 #include "gf2.hpp"
 #include "rccl_loader.hpp"
+#include "sweep_shard.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -1116,30 +1117,9 @@ int bbb_ber_trials(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, bbb_ber *
 /* ---- the path's one collective: a sweep sharded over the GPUs of this process ------------------------- */
 
 int bbb_sweep_shard(const bbb_trial_cfg *cfgs, int ncfg, int ndev, int rank, int mode, bbb_trial_cfg *mine) {
-    if (ncfg < 0 || (ncfg && (!cfgs || !mine)) || ndev < 1 || rank < 0 || rank >= ndev)
-        return fail(BBB_EINVAL, "bad shard arguments");
-    for (int i = 0; i < ncfg; i++) {
-        bbb_trial_cfg c = cfgs[i];
-        switch (mode) {
-        case BBB_SHARD_TRIALS:                        // trial i belongs to rank i % ndev
-            if (i % ndev != rank) c.nbits = 0;
-            break;
-        case BBB_SHARD_SEEDS:                         // every rank runs every trial (on its own reset state)
-            break;
-        case BBB_SHARD_BITS: {                        // rank r takes bits [r*nbits/ndev, (r+1)*nbits/ndev) of every trial
-            const unsigned __int128 nb = cfgs[i].nbits;
-            const uint64_t lo = (uint64_t)(nb * (unsigned)rank / (unsigned)ndev);
-            const uint64_t hi = (uint64_t)(nb * (unsigned)(rank + 1) / (unsigned)ndev);
-            if (c.first_bit + lo < c.first_bit) return fail(BBB_EINVAL, "first_bit + nbits overflows");
-            c.first_bit += lo;
-            c.nbits = hi - lo;
-            break;
-        }
-        default:
-            return fail(BBB_EINVAL, "mode must be BBB_SHARD_TRIALS, BBB_SHARD_SEEDS or BBB_SHARD_BITS");
-        }
-        mine[i] = c;
-    }
+    const int e = sweep_shard(cfgs, ncfg, ndev, rank, mode, mine);
+    if (e == -2) return fail(BBB_EINVAL, "first_bit + nbits overflows");
+    if (e) return fail(BBB_EINVAL, "bad shard arguments (ndev >= 1, 0 <= rank < ndev, mode BBB_SHARD_TRIALS / _SEEDS / _BITS)");
     return BBB_OK;
 }
 

@@ -6,12 +6,47 @@
 #include "../basebandboard_amd/csrc/gf2.hpp"
 #include "../basebandboard_amd/csrc/gf2poly.hpp"
 #include "../basebandboard_amd/csrc/search_rng.hpp"
+#include "../basebandboard_amd/csrc/sweep_shard.hpp"
 
 #include <cstdio>
 
 using namespace bbb;
 
+static int check_shards() {
+    // bbb_sweep_shard's arithmetic on ragged and extreme sizes: slices contiguous, in rank order, covering exactly
+    bbb_trial_cfg t[4] = {};
+    const unsigned long long nb[4] = {1000000007ull, 3, 0, ~0ull - 5};
+    const unsigned long long fb[4] = {0, 5, 9, 2};
+    for (int i = 0; i < 4; i++) { t[i].prbs_k = 31; t[i].nbits = nb[i]; t[i].first_bit = fb[i]; t[i].prbs_state = 1; }
+    for (int ndev : {1, 2, 3, 8, 64}) {
+        unsigned long long pos[4], tot[4] = {0, 0, 0, 0};
+        for (int i = 0; i < 4; i++) pos[i] = fb[i];
+        for (int r = 0; r < ndev; r++) {
+            bbb_trial_cfg mine[4];
+            if (sweep_shard(t, 4, ndev, r, BBB_SHARD_BITS, mine)) return 20;
+            for (int i = 0; i < 4; i++) {
+                if (mine[i].first_bit != pos[i]) return 21;
+                pos[i] += mine[i].nbits;
+            }
+            if (sweep_shard(t, 4, ndev, r, BBB_SHARD_TRIALS, mine)) return 22;
+            for (int i = 0; i < 4; i++) tot[i] += mine[i].nbits != 0;
+        }
+        for (int i = 0; i < 4; i++) {
+            if (pos[i] != fb[i] + nb[i]) return 23;
+            if (tot[i] != (nb[i] != 0)) return 24;
+        }
+    }
+    bbb_trial_cfg o{};
+    o.nbits = 100; o.first_bit = ~0ull - 10;
+    bbb_trial_cfg m1;
+    if (sweep_shard(&o, 1, 2, 1, BBB_SHARD_BITS, &m1) != -2) return 25;       // first_bit + lo overflows
+    if (sweep_shard(&o, 1, 2, 2, BBB_SHARD_BITS, &m1) != -1) return 26;
+    if (sweep_shard(&o, 1, 2, 0, 7, &m1) != -1) return 27;
+    return 0;
+}
+
 int main() {
+    if (int e = check_shards()) return e;
     // x^4 + x^3 + 1 primitive, x^4 + x^2 + x + 1 not (binary_polynomial.rs:352-360)
     GF2Poly p;
     p.set(4); p.set(3); p.set(0);
