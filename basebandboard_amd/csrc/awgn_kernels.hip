@@ -13,7 +13,7 @@
 // instructions (tools/gen_lutopt_kernel.py emits the straight-line network for the matrix).
 //
 // Kernels
-//   seed_first/level_kernel  start states, radix 4: S[j*4^e + i] = (A^L)^(j*4^e) * S[i]
+//   seed_first/level_kernel  start states, radix 16: S[j*16^e + i] = (A^L)^(j*16^e) * S[i]
 //   bitslice_kernel      [G][k bits] -> planes [k][lanes] (32x32 bit transposes)
 //   awgn256_kernel       the hot kernel (n256 matrix of gateware/bbb/rng_recurrences.py:172-259)
 //   awgn_generic_kernel  any k <= 512 / any taps, table driven, planes in global scratch
@@ -33,8 +33,9 @@
 namespace bbb {
 
 // ---------------------------------------------------------------------------------------------
-// Start states: S[g] = B^g * s0 with B = A^L, built radix 4.  Level e maps the first 4^e states
-// through B^(j*4^e), j = 1..3:   S[j*4^e + i] = B^(j*4^e) * S[i].
+// Start states: S[g] = B^g * s0 with B = A^L, built radix 16 (radix 4 until round 2: twice the launches, and the
+// chain of small levels -- 17 us each -- was half of an un-overlapped seeding).  Level e maps the first 16^e states
+// through B^(j*16^e), j = 1..15:   S[j*16^e + i] = B^(j*16^e) * S[i].
 // y = M x is evaluated four state bits at a time: a table holds, per nibble position n, the 16
 // XOR-combinations of columns 4n..4n+3 of M ([k/4][chunks][16][C] words, built on the host, one
 // table per (level, j)).  The big levels stage their table in LDS (32 KiB for k = 256) and every
@@ -100,7 +101,7 @@ __global__ void __launch_bounds__(256, 5)   // <= 96 registers: a block must fit
 seed_level_kernel(const uint32_t *__restrict tabs, int k, int e, unsigned long long G, unsigned long long stride,
                   uint32_t *__restrict S) {
     extern __shared__ __attribute__((aligned(16))) uint32_t tab[];
-    const unsigned long long lo = 1ull << (2 * e);
+    const unsigned long long lo = 1ull << (4 * e);
     const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned j = blockIdx.y + 1;
     const unsigned long long dst = (unsigned long long)j * lo + i;
@@ -122,7 +123,7 @@ seed_level_kernel(const uint32_t *__restrict tabs, int k, int e, unsigned long l
         if (part) __syncthreads();
         {
             typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-            const u4 *src = reinterpret_cast<const u4 *>(tabs + ((size_t)e * 3 + (j - 1)) * nt + (size_t)nlo * 16 * W32);
+            const u4 *src = reinterpret_cast<const u4 *>(tabs + ((size_t)e * 15 + (j - 1)) * nt + (size_t)nlo * 16 * W32);
             u4 *dstp = reinterpret_cast<u4 *>(tab);
             const int n4 = (nhi - nlo) * 16 * W32 / 4;
             for (int base = 0; base < n4; base += 4 * 256) {     // 16 KiB = 4 x 16 B per thread
@@ -667,8 +668,8 @@ static int seed_and_slice(int k, const uint32_t *d_tabs, const uint32_t *s16, ui
     Seed16 s;
     for (int i = 0; i < 16; i++)
         for (int w = 0; w < 16; w++) s.w[i][w] = w < W32 ? s16[i * 16 + w] : 0u;
-    int levels = 0;                                   // radix-4 levels needed: 4^levels >= G
-    while ((1ull << (2 * levels)) < G) levels++;
+    int levels = 0;                                   // radix-16 levels needed: 16^levels >= G
+    while ((1ull << (4 * levels)) < G) levels++;
     const int nnib_h = (k + 3) / 4, half_h = (nnib_h + 1) / 2 + ((nnib_h + 1) / 2 & 1);
     size_t lds = (size_t)half_h * 16 * W32 * sizeof(uint32_t);      // half a table at a time
     if (env_knob("BBB_SEED_LDS_KB", 0) > 0 && lds < (size_t)env_knob("BBB_SEED_LDS_KB", 0) * 1024)
@@ -686,9 +687,9 @@ static int seed_and_slice(int k, const uint32_t *d_tabs, const uint32_t *s16, ui
     }
     hipLaunchKernelGGL((seed_store16_kernel<W32>), dim3(1), dim3(64), 0, st, s, (unsigned long long)G,
                        (unsigned long long)stride, d_states);
-    for (int e = 2; e < levels; e++) {               // levels 0 and 1 (states 1..15) were done on the host
-        const uint64_t n = 1ull << (2 * e);
-        hipLaunchKernelGGL((seed_level_kernel<W32>), dim3((unsigned)((n + 255) / 256), 3), dim3(256), lds, st, d_tabs, k, e,
+    for (int e = 1; e < levels; e++) {               // level 0 (states 1..15) was done on the host
+        const uint64_t n = 1ull << (4 * e);
+        hipLaunchKernelGGL((seed_level_kernel<W32>), dim3((unsigned)((n + 255) / 256), 15), dim3(256), lds, st, d_tabs, k, e,
                            (unsigned long long)G, (unsigned long long)stride, d_states);
     }
     if (slice_mode == 1) return bitslice512p_launch(d_states, G, stride, nlanes, d_planes, st);

@@ -4,8 +4,8 @@
 
 namespace bbb {
 
-// start states S[g] = B^g s0 (per radix-4 level e and digit j = 1..3 a nibble-combination table of
-// B^(j*4^e): [e][j-1][k/4 * 16 * W32]) stored word-major with `stride` words per state word, and
+// start states S[g] = B^g s0 (per radix-16 level e and digit j = 1..15 a nibble-combination table of
+// B^(j*16^e): [e][j-1][k/4 * 16 * W32]) stored word-major with `stride` words per state word, and
 // their bit planes
 // s16: the first 16 start states, [16][16] words (host computed)
 // slice_mode 0: planes [k][nlanes], 32 generators per lane; 1: the packed n512 layout of awgn512.hip, 16 per lane

@@ -52,7 +52,7 @@ int use_device(int device) {
 // device copy of the doubling matrices for one segment length L
 struct JumpPlan {
     GF2Mat B;                     // the per-generator jump itself (host copy, for the first 16 states)
-    uint32_t *d_cols = nullptr;   // [levels][3][k/4 * 16 * W32] nibble tables of M^(j*4^e)
+    uint32_t *d_cols = nullptr;   // [levels][15][k/4 * 16 * W32] nibble tables of M^(j*16^e)
     int levels = 0;
 };
 
@@ -176,19 +176,20 @@ void nibble_table(const GF2Mat &M, uint32_t *out) {
     }
 }
 
-// Radix-4 jump plan of M: for e < levels and j = 1..3 the table of M^(j*4^e), packed
-// [e][j-1][table], uploaded to the device.
+// Radix-16 jump plan of M: for 1 <= e < levels and j = 1..15 the table of M^(j*16^e), packed
+// [e][j-1][table], uploaded to the device (level 0, the first 16 states, is done on the host: first16).
 int build_plan(const GF2Mat &M, int levels, JumpPlan *plan) {
     const int k = M.n, W32 = pad_w32(k), nnib = (k + 3) / 4;
     const size_t nt = (size_t)nnib * 16 * W32;
-    std::vector<uint32_t> host((size_t)levels * 3 * nt, 0);
-    GF2Mat m1 = M;                                   // M^(4^e)
-    for (int e = 0; e < levels; e++) {
-        if (e) { m1 = m1.mul(m1); m1 = m1.mul(m1); }
-        const GF2Mat m2 = m1.mul(m1), m3 = m2.mul(m1);
-        nibble_table(m1, &host[((size_t)e * 3 + 0) * nt]);
-        nibble_table(m2, &host[((size_t)e * 3 + 1) * nt]);
-        nibble_table(m3, &host[((size_t)e * 3 + 2) * nt]);
+    std::vector<uint32_t> host((size_t)levels * 15 * nt, 0);
+    GF2Mat m1 = M;                                   // M^(16^e)
+    for (int e = 1; e < levels; e++) {
+        for (int q = 0; q < 4; q++) m1 = m1.mul(m1);
+        GF2Mat mj = m1;
+        for (int j = 1; j <= 15; j++) {
+            if (j > 1) mj = mj.mul(m1);
+            nibble_table(mj, &host[((size_t)e * 15 + (j - 1)) * nt]);
+        }
     }
     BBB_HIP(hipMalloc((void **)&plan->d_cols, host.size() * sizeof(uint32_t)));
     BBB_HIP(hipMemcpy(plan->d_cols, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -209,7 +210,7 @@ void first16(const JumpPlan &plan, const uint64_t *s0, uint32_t *out) {
     }
 }
 
-constexpr int kPlanLevels = 13;   // radix 4: up to 4^13 = 2^26 generators
+constexpr int kPlanLevels = 7;    // radix 16: up to 16^7 = 2^28 generators
 
 int get_plan(bbb_lutopt *h, uint64_t L, JumpPlan **out) {
     auto it = h->plans.find(L);
