@@ -256,12 +256,9 @@ void partition(const bbb_lutopt *h, uint64_t n, unsigned granule, uint64_t *L, u
 // everything the library queued on the old one.
 int begin_op(bbb_lutopt *h, bool internal) {
     if (internal && !h->xs) {
-        // the arithmetic gets the highest stream priority, the piece mover the lowest: when both have blocks waiting,
-        // the sample kernel's waves (which need a whole SIMD's registers) are placed first and the mover takes what is left
-        int lo = 0, hi = 0;
-        BBB_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        BBB_HIP(hipStreamCreateWithPriority(&h->xs, hipStreamNonBlocking, hi));
-        BBB_HIP(hipStreamCreateWithPriority(&h->ys, hipStreamNonBlocking, lo));
+        // (stream priorities -- arithmetic high, mover low -- made no measurable difference: profiles/README.md)
+        BBB_HIP(hipStreamCreateWithFlags(&h->xs, hipStreamNonBlocking));
+        BBB_HIP(hipStreamCreateWithFlags(&h->ys, hipStreamNonBlocking));
     }
     hipStream_t want = internal ? h->xs : h->stream;
     if (h->cs_valid && h->cs != want) {

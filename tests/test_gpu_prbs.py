@@ -141,3 +141,34 @@ def test_baseline_config3_full_size_with_error_mask(gpu):
     st = det.run_stream(buf2, nbits)
     first_in_reload = 1 if st["reload_clocks"] > 0 else 0                  # bit 0 arrives during the reload out of reset
     assert st["errors_raw"] + 0 >= 10_000 - first_in_reload and st["errors"] in (10_000, 10_000 - first_in_reload)
+
+
+def test_concurrent_checks_do_not_share_a_counter(gpu, oracle):
+    """bbb_prbs_check from several threads and streams on one device at once: every call owns its counter
+    (stream-ordered allocation), so the counts do not bleed into each other."""
+    import threading
+    nbits = 40_000_003
+    p = gpu.PRBS(31)
+    bufs, want = [], []
+    for t in range(4):
+        b = p.generate(nbits)
+        for i in range(t * 3):                       # t * 3 flipped bits in buffer t
+            b[1000 + 17 * i] ^= 1 << (i % 60)
+        bufs.append(b)
+        want.append(t * 3)
+    torch.cuda.synchronize()
+    got = [[None] * 6 for _ in range(4)]
+
+    def work(t):
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            det = gpu.PRBSErrorDetector(31)
+            for r in range(6):
+                got[t][r] = det.count_errors(bufs[t], nbits)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert got == [[w] * 6 for w in want]
