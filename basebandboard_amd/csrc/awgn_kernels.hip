@@ -440,8 +440,13 @@ awgn256_kernel(const uint32_t *__restrict planes, void *__restrict dst_, unsigne
 // its share of the generator groups with 16 loads of 16 bytes in flight per lane.
 template <int PIECE>
 __global__ void __launch_bounds__(256, 5)
-unstage_kernel(const char *__restrict stg, char *__restrict dst, unsigned long long nbytes, unsigned Lb,
-               unsigned long long G, unsigned long long Gpad, unsigned rounds) {
+unstage_kernel(const char *__restrict stg, char *__restrict dst_, unsigned long long win_lo, unsigned long long nbytes_,
+               unsigned Lb, unsigned long long G, unsigned long long Gpad, unsigned rounds) {
+    // the staged stream may be longer than what this call delivers (look-ahead: two fills' worth per sample kernel):
+    // bytes [win_lo, win_lo + nbytes_) of it go to dst_[0 .. nbytes_).  Only generator groups that touch the window.
+    char *const dst = dst_ - win_lo;                       // indexed by stream offset below, within [win_lo, nbytes)
+    const unsigned long long nbytes = win_lo + nbytes_;
+    const unsigned long long trip0 = win_lo / ((unsigned long long)Lb * 32);
     constexpr unsigned CP = PIECE / 16;          // 16-byte chunks per piece
     constexpr unsigned RT = 8 / CP;              // rounds per tile
     constexpr unsigned NG = 4;                   // groups of 8 generators per trip: with 4 round tiles, 16 loads in flight per lane
@@ -452,8 +457,12 @@ unstage_kernel(const char *__restrict stg, char *__restrict dst, unsigned long l
     const unsigned long long sstride = (unsigned long long)RT * Gpad * PIECE;
     constexpr unsigned dstride = RT * PIECE;
     const unsigned long long gstride_src = 8ull * PIECE, gstride_dst = 8ull * Lb;
-    const unsigned long long ntrips = (G + 8 * NG - 1) / (8 * NG);
-    for (unsigned long long trip = wave0; trip < ntrips; trip += nwaves) {
+    unsigned long long ntrips = (G + 8 * NG - 1) / (8 * NG);
+    {
+        const unsigned long long last = (nbytes + (unsigned long long)Lb * 32 - 1) / ((unsigned long long)Lb * 32);
+        if (last < ntrips) ntrips = last;
+    }
+    for (unsigned long long trip = trip0 + wave0; trip < ntrips; trip += nwaves) {
         const unsigned long long g0 = trip * (8 * NG) + gl;
         if (g0 >= G) continue;
         // all 64-bit address arithmetic once per trip; the loops below only add (wave-uniform) strides
@@ -461,7 +470,7 @@ unstage_kernel(const char *__restrict stg, char *__restrict dst, unsigned long l
         const unsigned long long seg0 = g0 * (unsigned long long)Lb;
         char *out0 = dst + seg0 + rl * PIECE + c * 16;
         // fast path: all NG groups exist and end inside the request -- no bounds inside the loops
-        if (g0 + 8 * (NG - 1) < G && seg0 + (NG - 1) * gstride_dst + Lb <= nbytes) {
+        if (g0 + 8 * (NG - 1) < G && seg0 >= win_lo && seg0 + (NG - 1) * gstride_dst + Lb <= nbytes) {
             unsigned r = rl;
             for (; r + 3 * RT < rounds; r += 4 * RT) {
                 u32x4 v[NG][4];
@@ -495,6 +504,7 @@ unstage_kernel(const char *__restrict stg, char *__restrict dst, unsigned long l
             for (unsigned r = rl; r < rounds; r += RT, src += sstride) {
                 const unsigned long long off = seg + (unsigned long long)r * PIECE + c * 16;
                 if (off >= nbytes) break;
+                if (off < win_lo) continue;                // (win_lo is a multiple of 16: whole chunks)
                 const u32x4 v = *reinterpret_cast<const u32x4 *>(src);
                 if (off + 16 <= nbytes) {
                     *reinterpret_cast<u32x4 *>(dst + off) = v;
@@ -507,8 +517,9 @@ unstage_kernel(const char *__restrict stg, char *__restrict dst, unsigned long l
     }
 }
 
-int unstage_launch(const void *stg, void *dst, uint64_t nbytes, unsigned Lb, uint64_t G, uint64_t Gpad, unsigned rounds,
-                   int piece, hipStream_t st) {
+int unstage_launch(const void *stg, void *dst, uint64_t win_lo, uint64_t nbytes, unsigned Lb, uint64_t G, uint64_t Gpad,
+                   unsigned rounds, int piece, hipStream_t st) {
+    if (win_lo & 15) return fail(BBB_EINVAL, "window must start on a 16-byte boundary of the staged stream");
     int dev = 0, ncu = 256;
     BBB_HIP(hipGetDevice(&dev));
     BBB_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
@@ -519,10 +530,10 @@ int unstage_launch(const void *stg, void *dst, uint64_t nbytes, unsigned Lb, uin
     const size_t lds = static_cast<size_t>(env_knob("BBB_UNSTAGE_LDS_KB", 0)) * 1024;
     if (piece == 16)
         hipLaunchKernelGGL(unstage_kernel<16>, dim3((unsigned)blocks), dim3(256), lds, st, (const char *)stg, (char *)dst,
-                           (unsigned long long)nbytes, Lb, (unsigned long long)G, (unsigned long long)Gpad, rounds);
+                           (unsigned long long)win_lo, (unsigned long long)nbytes, Lb, (unsigned long long)G, (unsigned long long)Gpad, rounds);
     else
         hipLaunchKernelGGL(unstage_kernel<32>, dim3((unsigned)blocks), dim3(256), lds, st, (const char *)stg, (char *)dst,
-                           (unsigned long long)nbytes, Lb, (unsigned long long)G, (unsigned long long)Gpad, rounds);
+                           (unsigned long long)win_lo, (unsigned long long)nbytes, Lb, (unsigned long long)G, (unsigned long long)Gpad, rounds);
     BBB_HIP(hipGetLastError());
     return BBB_OK;
 }

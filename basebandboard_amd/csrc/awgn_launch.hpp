@@ -19,9 +19,10 @@ int awgn512p_fill_launch(const uint32_t *d_planes, int16_t *dst, uint64_t nsampl
 // staged: dst is a staging buffer [L/16 rounds][nlanes * 32 generator slots][16 bytes], to be moved by unstage_launch
 int awgn256_fill_launch(const uint32_t *d_planes, int8_t *dst, uint64_t nsamples, unsigned L, uint64_t G,
                         unsigned nlanes, bool staged, hipStream_t st);
-// staging buffer [rounds][Gpad][piece bytes] -> sequential stream of nbytes, generator g owning [g Lb, (g+1) Lb)
-int unstage_launch(const void *stg, void *dst, uint64_t nbytes, unsigned Lb, uint64_t G, uint64_t Gpad, unsigned rounds,
-                   int piece, hipStream_t st);
+// staging buffer [rounds][Gpad][piece bytes] holds a sequential stream, generator g owning [g Lb, (g+1) Lb): its bytes
+// [win_lo, win_lo + nbytes) go to dst[0 .. nbytes)
+int unstage_launch(const void *stg, void *dst, uint64_t win_lo, uint64_t nbytes, unsigned Lb, uint64_t G, uint64_t Gpad,
+                   unsigned rounds, int piece, hipStream_t st);
 // the transmitter's output fused into the sample kernel: x = wrap12(bit_en * shaped + g * noise_var) as int16.
 // d_bits: packed data bits (32-bit words); rel_base = window bit offset of output position 0; c0 = (first_sample - 17) & 7
 int awgn256_tx_launch(const uint32_t *d_planes, int16_t *dst, uint64_t nsamples, unsigned L, uint64_t G, unsigned nlanes,

@@ -115,6 +115,12 @@ struct bbb_lutopt {
     int stage_slot = 0;
     hipEvent_t ev_user = nullptr;
     int pf_waited_slot = -1;              // staging slot whose mover the pending prefetch's seeding waited for
+    hipEvent_t stage_arith[2] = {nullptr, nullptr};   // recorded behind the sample kernel that filled the slot
+    // look-ahead (bbb_lutopt_set_staged(h, m), m >= 2): the sample kernel of a fill also produced the next m - 1 fills'
+    // samples, which wait in its staging slot: `left` more fills of n samples, the next one at stream position `first`,
+    // at byte `win_lo` of the kernel's output; (L, G, nlanes) = that kernel's partition
+    struct Ahead { bool valid = false; uint64_t first = 0, n = 0, win_lo = 0, L = 0, G = 0; unsigned nlanes = 0, left = 0; int slot = 0; } ahead;
+    int staged_level = 0;                 // 0 off, 1 staged, m >= 2 staged with m fills per sample kernel
     hipEvent_t cur_last_read = nullptr;   // same, for the buffers currently in d_states / d_planes
     bool cur_read_pending = false;
     // optional per-call device timing of the generator kernels (bbb_lutopt_profile)
@@ -328,17 +334,41 @@ int acquire_planes(bbb_lutopt *h, uint64_t first_step, uint64_t L, uint64_t G, u
 //   caller's stream waits for the mover: whatever the caller queues next sees `dst` complete, as with one kernel.
 // Since the next call's arithmetic does not wait for this call's mover, the mover (HBM-bound, a few registers per
 // lane) runs beside it (integer-issue bound, one wave per SIMD).  Two staging buffers alternate.
+
+// the piece mover of staging slot `slot`: stream bytes [win_lo, win_lo + nbytes) -> dst; behind the slot's sample kernel
+// and behind everything the caller has queued so far; the caller's stream then waits for it
+int queue_mover(bbb_lutopt *h, int slot, void *dst, uint64_t win_lo, uint64_t nbytes, int piece, uint64_t L, uint64_t G,
+                unsigned nlanes) {
+    const uint64_t Gpad = (uint64_t)nlanes * 32;
+    const unsigned rounds = (unsigned)(L / 16);
+    for (hipEvent_t *e : {&h->stage_free[slot], &h->ev_user})
+        if (!*e) BBB_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    BBB_HIP(hipEventRecord(h->ev_user, h->stream));
+    BBB_HIP(hipStreamWaitEvent(h->ys, h->ev_user, 0));
+    BBB_HIP(hipStreamWaitEvent(h->ys, h->stage_arith[slot], 0));
+    int rc = unstage_launch(h->d_stage[slot], dst, win_lo, nbytes, (unsigned)(L * (uint64_t)piece / 16), G, Gpad, rounds, piece, h->ys);
+    if (rc) return rc;
+    BBB_HIP(hipEventRecord(h->stage_free[slot], h->ys));
+    h->stage_busy[slot] = true;
+    BBB_HIP(hipStreamWaitEvent(h->stream, h->stage_free[slot], 0));
+    return BBB_OK;
+}
+
 // planes_seeded_after_mover: the start states came from a prefetch whose seeding had itself waited for the mover that last
 // read this staging buffer (bbb_awgn_prefetch on a staged handle), so the arithmetic need not wait for it again -- every
 // event wait is a barrier packet of several microseconds between two sample kernels.
+// The sample kernel produces `total_bytes` of stream (L, G, nlanes are ITS partition); `nbytes` of them, from offset 0, are
+// delivered to dst now (look-ahead: total_bytes = 2 nbytes, the rest waits in the slot).  *slot_out = the slot used.
 template <typename LaunchArith>
 int staged_fill(bbb_lutopt *h, void *dst, uint64_t nbytes, int piece, uint64_t L, uint64_t G, unsigned nlanes,
-                bbb_lutopt::ProfEv *ev, bool planes_seeded_after_mover, LaunchArith launch_arith) {
+                bbb_lutopt::ProfEv *ev, bool planes_seeded_after_mover, LaunchArith launch_arith, int *slot_out = nullptr) {
     const uint64_t Gpad = (uint64_t)nlanes * 32;
     const unsigned rounds = (unsigned)(L / 16);
     const size_t need_words = (size_t)(Gpad * rounds * (uint64_t)piece / 4);
     const int slot = h->stage_slot ^= 1;
-    for (hipEvent_t *e : {&h->stage_free[slot], &h->ev_user})
+    if (slot_out) *slot_out = slot;
+    if (h->ahead.valid && h->ahead.slot == slot) h->ahead.valid = false;            // its look-ahead half is overwritten now
+    for (hipEvent_t *e : {&h->stage_free[slot], &h->stage_arith[slot]})
         if (!*e) BBB_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     if (h->stage_cap[slot] < need_words) {
         if (h->stage_busy[slot]) BBB_HIP(hipEventSynchronize(h->stage_free[slot]));     // growing frees the old buffer
@@ -353,14 +383,8 @@ int staged_fill(bbb_lutopt *h, void *dst, uint64_t nbytes, int piece, uint64_t L
     if (rc) return rc;
     if ((rc = mark_planes_read(h))) return rc;
     if (ev) BBB_HIP(hipEventRecord(ev->e2, h->cs));
-    BBB_HIP(hipEventRecord(h->ev_user, h->stream));
-    BBB_HIP(hipStreamWaitEvent(h->ys, h->ev_user, 0));
-    BBB_HIP(hipStreamWaitEvent(h->ys, h->cur_last_read, 0));         // recorded right behind the arithmetic (mark_planes_read)
-    if ((rc = unstage_launch(h->d_stage[slot], dst, nbytes, (unsigned)(L * (uint64_t)piece / 16), G, Gpad, rounds, piece, h->ys))) return rc;
-    BBB_HIP(hipEventRecord(h->stage_free[slot], h->ys));
-    h->stage_busy[slot] = true;
-    BBB_HIP(hipStreamWaitEvent(h->stream, h->stage_free[slot], 0));
-    return BBB_OK;
+    BBB_HIP(hipEventRecord(h->stage_arith[slot], h->cs));
+    return queue_mover(h, slot, dst, 0, nbytes, piece, L, G, nlanes);
 }
 
 int awgn_fill(bbb_lutopt *h, void *dst, int elem_size, uint64_t nsamples, uint64_t first_step) {
@@ -402,6 +426,24 @@ int awgn_fill(bbb_lutopt *h, void *dst, int elem_size, uint64_t nsamples, uint64
     if (L > 0xffffff00ull) return fail(BBB_EINVAL, "nsamples too large for one call (segment length must fit 32 bits): split it");
     const bool fast256 = h->specialised && elem_size == 1;
     const bool staged = fast256 && h->staged_mode && nsamples >= (1ull << 24);
+    // look-ahead: this very range was produced by the previous fill's sample kernel and waits in its staging slot
+    if (staged && h->ahead.valid && h->ahead.first == first_step && h->ahead.n == nsamples) {
+        int rc0 = begin_op(h, true);
+        if (rc0) return rc0;
+        const bbb_lutopt::Ahead a = h->ahead;
+        h->ahead.first += nsamples;
+        h->ahead.win_lo += nsamples;
+        h->ahead.valid = --h->ahead.left > 0;
+        return queue_mover(h, a.slot, dst, a.win_lo, nsamples, 16, a.L, a.G, a.nlanes);
+    }
+    const uint64_t m = (uint64_t)h->staged_level;
+    const bool ahead = staged && m >= 2 && (nsamples % 16) == 0 && m * nsamples < (1ull << 40) &&
+                       first_step + m * nsamples > first_step;
+    const uint64_t ntotal = ahead ? m * nsamples : nsamples;      // what the sample kernel produces
+    if (ahead) {
+        partition(h, ntotal, 16, &L, &G, &nlanes);
+        if (L > 0xffffff00ull) return fail(BBB_EINVAL, "nsamples too large for one call (segment length must fit 32 bits): split it");
+    }
     int rc = begin_op(h, staged);
     if (rc) return rc;
     bbb_lutopt::ProfEv ev{};
@@ -413,10 +455,17 @@ int awgn_fill(bbb_lutopt *h, void *dst, int elem_size, uint64_t nsamples, uint64
     rc = acquire_planes(h, first_step, L, G, nlanes, fast256, &from_pf);
     if (rc) return rc;
     if (staged) {
+        int slot = 0;
         rc = staged_fill(h, dst, nsamples, 16, L, G, nlanes, h->profiling ? &ev : nullptr, from_pf, [&](void *stage) {
-            return awgn256_fill_launch(h->d_planes, (int8_t *)stage, nsamples, (unsigned)L, G, nlanes, true, h->cs);
-        });
+            return awgn256_fill_launch(h->d_planes, (int8_t *)stage, ntotal, (unsigned)L, G, nlanes, true, h->cs);
+        }, &slot);
         if (h->profiling) h->prof_pending.push_back(ev);
+        if (!rc && ahead) {
+            h->ahead.valid = true;
+            h->ahead.first = first_step + nsamples; h->ahead.n = nsamples; h->ahead.win_lo = nsamples;
+            h->ahead.left = (unsigned)m - 1;
+            h->ahead.L = L; h->ahead.G = G; h->ahead.nlanes = nlanes; h->ahead.slot = slot;
+        }
         return rc;
     }
     if (fast256) {
@@ -681,7 +730,7 @@ int bbb_lutopt_destroy(bbb_lutopt *h) {
                     (void *)h->d_txbits, (void *)h->pf.d_states, (void *)h->pf.d_planes})
         (void)hipFree(p);
     for (hipEvent_t e : {h->pf.seeded, h->pf.last_read, h->cur_last_read, h->handover, h->stage_free[0], h->stage_free[1],
-                         h->ev_user})
+                         h->stage_arith[0], h->stage_arith[1], h->ev_user})
         if (e) (void)hipEventDestroy(e);
     for (hipStream_t st : {h->side, h->xs, h->ys})
         if (st) (void)hipStreamDestroy(st);
@@ -729,7 +778,10 @@ int bbb_lutopt_attach_custom_library(bbb_lutopt *h, const char *path) {
 
 int bbb_lutopt_set_staged(bbb_lutopt *h, int enable) {
     if (!h) return fail(BBB_EINVAL, "null handle");
+    if (enable < 0 || enable > 8) return fail(BBB_EINVAL, "0 = off, 1 = staged, 2..8 = staged with that many fills per sample kernel");
     h->staged_mode = enable != 0;
+    h->staged_level = enable;
+    h->ahead.valid = false;               // (also the way to drop a waiting look-ahead half)
     return BBB_OK;
 }
 
@@ -772,8 +824,20 @@ int bbb_awgn_prefetch(bbb_lutopt *h, uint64_t nsamples, uint64_t first_step) {
     BBB_HIP(hipSetDevice(h->device));
     uint64_t L, G;
     unsigned nlanes;
+    if (h->staged_level >= 2 && nsamples >= (1ull << 24) && (nsamples % 16) == 0) {
+        // look-ahead: a sample kernel covers m fills.  If the announced fill is one that already waits in a staging slot,
+        // what needs start states is the fill after the LAST waiting one; and they are those of an m-fold request.
+        const uint64_t m = (uint64_t)h->staged_level;
+        if (h->ahead.valid && h->ahead.first == first_step && h->ahead.n == nsamples) {
+            const uint64_t skip = (uint64_t)h->ahead.left * nsamples;
+            if (first_step + skip < first_step) return BBB_OK;
+            first_step += skip;
+        }
+        if (m * nsamples < (1ull << 40) && first_step + m * nsamples > first_step) nsamples *= m;
+    }
     partition(h, nsamples, 16, &L, &G, &nlanes);
     if (L > 0xffffff00ull) return BBB_OK;                         // the matching fill will refuse; nothing to prepare
+    if (h->pf.valid && h->pf.first == first_step && h->pf.L == L && h->pf.G == G) return BBB_OK;      // already under way
     JumpPlan *plan;
     int rc = get_plan(h, L, &plan);
     if (rc) return rc;

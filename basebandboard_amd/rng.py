@@ -125,10 +125,13 @@ class LUTOPT:
         self._custom = so
         return so
 
-    def set_staged(self, enable=True):
+    def set_staged(self, enable=True, look_ahead=False):
         """Two-kernel form of the large k = 256 fills of this handle (bbb_lutopt_set_staged): same samples; the output
-        is written as full lines by a second kernel that overlaps the next fill's arithmetic."""
-        _lib.check(_lib.lib().bbb_lutopt_set_staged(self._h, int(bool(enable))), "bbb_lutopt_set_staged")
+        is written as full lines by a second kernel that overlaps the next fill's arithmetic.  look_ahead = m (True: 2):
+        a fill's sample kernel also produces the next m - 1 fills' samples (for consumers that read the stream
+        sequentially in equal fills); 2 <= m <= 8."""
+        level = 0 if not enable else (1 if not look_ahead else (2 if look_ahead is True else int(look_ahead)))
+        _lib.check(_lib.lib().bbb_lutopt_set_staged(self._h, level), "bbb_lutopt_set_staged")
 
     def state_at(self, nsteps):
         """Integer value of `x` after nsteps clocks from reset."""

@@ -209,8 +209,14 @@ def main():
     # the two-kernel form of the stream (bbb_lutopt_set_staged): the sample kernel writes full lines into a staging
     # buffer, a piece mover puts them in place beside the NEXT step's arithmetic; same bytes (tests/test_gpu_staged.py).
     # BENCH_ONE_KERNEL=1 times the one-kernel form instead (it is also reported in `extra`).
+    # Look-ahead (level 2 of the same switch): a step's sample kernel produces its own 1e9 samples AND the next step's
+    # (one seeding, one launch per two steps); the next step is then only its piece mover.  Needs the rank's steps to
+    # be consecutive in the stream, hence the per-rank sub-streams below.  BENCH_NO_LOOK_AHEAD=1 turns it off.
     staged = not os.environ.get("BENCH_ONE_KERNEL")
-    u.set_staged(staged)
+    look_ahead = int(os.environ.get("BENCH_LOOK_AHEAD", "2")) if staged and not os.environ.get("BENCH_NO_LOOK_AHEAD") else 0
+    if look_ahead < 2:
+        look_ahead = 0
+    u.set_staged(staged, look_ahead=look_ahead)
     g = bbb.CLTGRNG(u)
     buf = torch.empty(NSAMP, dtype=torch.int8, device=f"cuda:{local_rank}")
 
@@ -221,7 +227,9 @@ def main():
         torch.cuda.synchronize()
 
     def first_step(step):
-        return WARM_STATE + (step * world + rank) * NSAMP
+        # every rank reads its own contiguous stretch of the one stream, 2^48 steps apart (jump-ahead makes any start
+        # position as cheap as any other); within a rank the steps follow each other
+        return WARM_STATE + (rank << 48) + step * NSAMP
 
     # parity spot check before timing (rank 0): a prefix of step 0 against the oracle
     verified = None
@@ -239,6 +247,12 @@ def main():
         g.generate(NSAMP, first_step=first_step(s), out=buf)
         if prefetch:
             g.prefetch(NSAMP, first_step=first_step(s + 1))
+    if look_ahead:
+        # the timed region must not inherit arithmetic from the warm-up: drop a waiting second half, so that the first
+        # timed step launches a sample kernel (with an odd --steps the last kernel's second half is produced and unused)
+        u.set_staged(staged, look_ahead=look_ahead)
+        if prefetch:
+            g.prefetch(NSAMP, first_step=first_step(args.warmup + 1))
     u.profile(True)
     u.profile_read(reset=True)
     barrier()
@@ -257,8 +271,9 @@ def main():
         dt = float(t.item())
 
     value = world * args.steps * NSAMP / dt / 1e9
-    kern_avg_ms = kern_ms / max(calls, 1)
-    achieved = NSAMP / (kern_avg_ms * 1e-3) / 1e9 if kern_avg_ms > 0 else 0.0
+    kern_avg_ms = kern_ms / max(calls, 1)                 # per LAUNCH of the sample kernel
+    per_launch = look_ahead * NSAMP if look_ahead else NSAMP       # samples (= algorithmic bytes) one launch produces
+    achieved = per_launch / (kern_avg_ms * 1e-3) / 1e9 if kern_avg_ms > 0 else 0.0
 
     # attainable write ceiling on this box: a plain streaming fill of the same 1e9 bytes
     fill_gbs = None
@@ -279,11 +294,14 @@ def main():
     # --pmc FETCH_SIZE, profiles/README.md), so the line carries the committed summary of this round's pass and
     # says which file it came from (stale if the kernel changed since)
     traffic = traffic_src = None
-    for name in ("r02_awgn256_pmc.json", "r01_awgn256_pmc.json"):
+    for name in ("r02_awgn256_la_pmc.json", "r02_awgn256_pmc.json", "r01_awgn256_pmc.json"):
         pmc = ROOT / "profiles" / name
         if pmc.exists():
             try:
-                traffic = json.load(open(pmc)).get("awgn256_kernel_hbm_bytes_per_launch")
+                rec = json.load(open(pmc))
+                if int(rec.get("samples_per_launch", NSAMP)) != per_launch:
+                    continue                      # measured on launches of another size (with / without look-ahead)
+                traffic = rec.get("awgn256_kernel_hbm_bytes_per_launch")
                 traffic_src = f"profiles/{name} (separate --pmc WRITE_SIZE / FETCH_SIZE passes over this command; stale if the kernel changed since)"
                 break
             except Exception:
@@ -469,14 +487,17 @@ def main():
                                    "generator, no xorshift/CLT-12 exists in the reference)",
                        "samples_per_step_per_gpu": NSAMP, "seeding_in_timed_region": True,
                        "form": "two kernels: sample kernel -> staging buffer (full lines), piece mover -> output, the mover of step s "
-                               "beside the arithmetic of step s+1; all of it inside the timed region" if staged else "one kernel",
+                               "beside the arithmetic of step s+1; all of it inside the timed region"
+                               + (f"; look-ahead: one sample-kernel launch (and one seeding) per {look_ahead} consecutive steps, the timed region "
+                                   "starts on a launch" if look_ahead else "") if staged else "one kernel",
                        "seeding_overlapped_by_prefetch_hint": bool(prefetch),
                        "verified_vs_oracle": verified},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "awgn256_kernel<false, staged>" if staged else "awgn256_kernel<false, false>", "kernel_ms_avg": round(kern_avg_ms, 4),
                          "seed_ms_avg": round(seed_ms / max(calls, 1), 4), "launches_timed": int(calls),
-                         "algorithmic_bytes_per_launch": NSAMP,
+                         "algorithmic_bytes_per_launch": per_launch,
+                         "steps_per_launch": per_launch // NSAMP,
                          "streaming_fill_gb_s": round(fill_gbs, 1) if fill_gbs else None,
                          "frac_of_streaming_fill": round(achieved / fill_gbs, 4) if fill_gbs else None,
                          "true_bound": "integer VALU (bit-sliced XOR/majority network), not HBM",

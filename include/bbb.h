@@ -118,7 +118,13 @@ int bbb_awgn_prefetch(bbb_lutopt *h, uint64_t nsamples, uint64_t first_step);
  * second kernel runs on an internal stream: the caller's stream waits for it (anything queued after the call sees the
  * output complete, as before), but the NEXT fill's arithmetic does not -- the mover (memory bound) and the next
  * arithmetic (integer-issue bound) share the machine.  Worth it for back-to-back fills; a single isolated fill
- * finishes later than in the one-kernel form.  Costs two staging buffers of the fill's size. */
+ * finishes later than in the one-kernel form.  Costs two staging buffers of the fill's size.
+ * enable = m in 2..8 adds LOOK-AHEAD for bbb_awgn_fill_i8: a fill of n samples at `first` lets its sample kernel produce
+ * the m n samples from `first` (one seeding, one launch for m fills; the rest waits in the staging buffer); while the
+ * following fills ask for exactly (n, first + n), (n, first + 2 n) ... -- a consumer reading the one sequential stream
+ * the reference's generator emits -- each only costs its piece mover.  A fill elsewhere discards what still waits (that
+ * work was wasted).  Staging buffers are m times as large.  Results are identical in every mode; calling this function
+ * (with any value) drops whatever waits. */
 int bbb_lutopt_set_staged(bbb_lutopt *h, int enable);
 /* Same stream as int16 (needed for k = 512, whose CLTGRNG output is 9 bits: rng.py:78). */
 int bbb_awgn_fill_i16(bbb_lutopt *h, int16_t *dst_dev, uint64_t nsamples, uint64_t first_step);

@@ -92,3 +92,129 @@ def test_staged_tx_equals_one_kernel_form(gpu, oracle, golden_shaper):
     m = oracle.Lutopt(path=oracle.data_path(256))
     exp = oracle.tx(m, 1, golden_shaper["rcf_coeffs"][16], 31, 200_000, first_sample=n, noise_var=8, warmup=16)
     assert np.array_equal(outs[1][:200_000].cpu().numpy(), exp)
+
+
+def _look_ahead_gen(gpu, init=1, fills=True):
+    u = gpu.LUTOPT.shipped(256, init=init)
+    u.set_staged(True, look_ahead=fills)
+    return u, gpu.CLTGRNG(u)
+
+
+@pytest.mark.parametrize("prefetch", [False, True])
+@pytest.mark.parametrize("fills", [2, 3, 4])
+def test_look_ahead_stream_equals_oracle(gpu, oracle, prefetch, fills):
+    """Look-ahead: one sample kernel per `fills` sequential fills; the others are only piece movers.  Seven fills (the
+    last sample kernel's output is not asked for in full), whole buffers against the oracle."""
+    m = oracle.Lutopt(path=oracle.data_path(256))
+    u, g = _look_ahead_gen(gpu, init=0xABCDE, fills=fills)
+    n = BIG + 4096 + 16          # 16-sample aligned, segment boundaries do not fall on n
+    bufs = []
+    for s in range(7):
+        bufs.append(g.generate(n, first_step=16 + s * n))
+        if prefetch:
+            g.prefetch(n, first_step=16 + (s + 1) * n)
+    torch.cuda.synchronize()
+    ref = m.awgn(0xABCDE, 16, 7 * n, fast=True)
+    for s, b in enumerate(bufs):
+        assert np.array_equal(b.cpu().numpy(), ref[s * n:(s + 1) * n]), s
+    # one buffer reused, with a reader on the caller's stream between fills
+    buf = torch.empty(n, dtype=torch.int8, device="cuda")
+    sums = []
+    for s in range(5):
+        g.generate(n, first_step=16 + s * n, out=buf)
+        if prefetch:
+            g.prefetch(n, first_step=16 + (s + 1) * n)
+        sums.append(buf.to(torch.int64).sum())
+    assert [int(x) for x in sums] == [int(ref[s * n:(s + 1) * n].astype(np.int64).sum()) for s in range(5)]
+
+
+@pytest.mark.parametrize("fills", [2, 4])
+def test_look_ahead_broken_chains(gpu, oracle, fills):
+    """The next fill is NOT the announced continuation: another position, another size, a size that is not a multiple
+    of 16 (no look-ahead for it), a repeat of the same range, and wrong prefetch hints.  Every buffer exact."""
+    m = oracle.Lutopt(path=oracle.data_path(256))
+    u, g = _look_ahead_gen(gpu, fills=fills)
+    d = gpu.CLTGRNG(gpu.LUTOPT.shipped(256))
+    n = BIG + 160
+    plan = [(n, 16), (n, 16 + n),                 # miss, hit
+            (n, 16 + n),                          # the same range again: miss (that part was consumed)
+            (n, 16 + 3 * n),                      # a skip: miss, discards the waiting half
+            (n + 16, 16 + 4 * n),                 # continuation position but another size: miss
+            (n + 5, 1000),                        # not a multiple of 16: plain staged fill
+            (n + 5, 1000 + n + 5),
+            (n, 7), (n, 7 + n), (n, 7 + 2 * n), (n, 7 + 3 * n)]        # a clean chain from an odd position
+    outs = []
+    for i, (cnt, first) in enumerate(plan):
+        outs.append(g.generate(cnt, first_step=first))
+        if i % 3 == 0:
+            g.prefetch(cnt, first_step=first + cnt)           # right hint
+        elif i % 3 == 1:
+            g.prefetch(cnt, first_step=first + 12345)         # wrong hint
+    torch.cuda.synchronize()
+    for (cnt, first), got in zip(plan, outs):
+        assert torch.equal(got, d.generate(cnt, first_step=first)), (cnt, first)
+        assert np.array_equal(got[:100_000].cpu().numpy(), m.awgn(u.state_at(first), 0, 100_000, fast=True))
+
+
+def test_look_ahead_interleaved_with_other_calls(gpu, oracle, golden_shaper):
+    """Between a fill and its continuation: a BER trial, raw words, a small fill, a TX fill on the same handle (it shares
+    the staging slots), a level change.  The continuation is exact whether or not its half survived."""
+    m = oracle.Lutopt(path=oracle.data_path(256))
+    x = gpu.TX(31, 1, 0, 16, 1, 8)
+    u = x.urng
+    u.set_staged(True, look_ahead=True)
+    g = gpu.CLTGRNG(u)
+    n = BIG + 320
+    ref = m.awgn(1, 16, 8 * n, fast=True)
+    a0 = g.generate(n, first_step=16)
+    t = gpu.Trial(nbits=300_001, amp=100, noise_var=8)
+    assert gpu.run_trials(u, [t])[0] == m.ber_trial(1, 31, 1, 100, 8, 16, 0, 300_001)
+    w = u.generate_words(500, first_step=3)
+    small = g.generate(4096, first_step=5)
+    a1 = g.generate(n, first_step=16 + n)                      # hit
+    a2 = g.generate(n, first_step=16 + 2 * n)                  # miss, leaves a half
+    tx1 = x.generate(BIG + 64, first_sample=0)                 # staged TX takes the other slot
+    tx2 = x.generate(BIG + 64, first_sample=BIG + 64)          # ... and then the slot of the waiting half
+    a3 = g.generate(n, first_step=16 + 3 * n)                  # must notice its half is gone
+    a4 = g.generate(n, first_step=16 + 4 * n)
+    u.set_staged(True)                                         # level 1: drops whatever waits
+    a5 = g.generate(n, first_step=16 + 5 * n)
+    u.set_staged(True, look_ahead=True)
+    a6 = g.generate(n, first_step=16 + 6 * n)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):                              # the continuation on another caller stream
+        a7 = g.generate(n, first_step=16 + 7 * n)
+        s7 = a7.to(torch.int64).sum()
+    torch.cuda.synchronize()
+    for s, b in enumerate((a0, a1, a2, a3, a4, a5, a6, a7)):
+        assert np.array_equal(b.cpu().numpy(), ref[s * n:(s + 1) * n]), s
+    assert int(s7) == int(ref[7 * n:].astype(np.int64).sum())
+    assert np.array_equal(small.cpu().numpy(), m.awgn(1, 5, 4096, fast=True))
+    assert np.array_equal(w.cpu().numpy().view(np.uint32), m.words_u32(1, 3, 500))
+    y = gpu.TX(31, 1, 0, 16, 1, 8)
+    assert torch.equal(tx1, y.generate(BIG + 64, first_sample=0))
+    assert torch.equal(tx2, y.generate(BIG + 64, first_sample=BIG + 64))
+
+
+def test_look_ahead_level_is_checked(gpu):
+    u = gpu.LUTOPT.shipped(256)
+    for bad in (9, 100):
+        with pytest.raises(ValueError):
+            u.set_staged(True, look_ahead=bad)
+
+
+@pytest.mark.parametrize("fills,launches", [(2, 3), (3, 2), (4, 2)])
+def test_look_ahead_costs_one_sample_kernel_per_m_fills(gpu, fills, launches):
+    u, g = _look_ahead_gen(gpu, fills=fills)
+    n = 1 << 26
+    buf = torch.empty(n, dtype=torch.int8, device="cuda")
+    g.generate(n, first_step=0, out=buf)
+    u.set_staged(True, look_ahead=fills)           # drop what waits: the counted fills start on a miss
+    u.profile(True)
+    u.profile_read(reset=True)
+    for s in range(6):
+        g.generate(n, first_step=(1 + s) * n, out=buf)
+    torch.cuda.synchronize()
+    _, _, calls = u.profile_read(reset=True)
+    u.profile(False)
+    assert calls == launches
