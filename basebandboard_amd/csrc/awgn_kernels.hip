@@ -95,11 +95,17 @@ seed_store16_kernel(Seed16 s, unsigned long long G, unsigned long long stride, u
     for (int w = 0; w < W32; w++) S[w * stride + i] = s.w[i][w];
 }
 
+// nibbles per staged piece of the table: ceil(nnib / parts), made even (lookups are folded in pairs)
+__host__ __device__ inline int seed_part_nibbles(int nnib, int parts) {
+    const int h = (nnib + parts - 1) / parts;
+    return h + (h & 1);
+}
+
 // level e: blockIdx.y = j - 1
 template <int W32>
 __global__ void __launch_bounds__(256, 5)   // <= 96 registers: a block must fit beside the sample kernel's waves
 seed_level_kernel(const uint32_t *__restrict tabs, int k, int e, unsigned long long G, unsigned long long stride,
-                  uint32_t *__restrict S) {
+                  uint32_t *__restrict S, int parts) {
     extern __shared__ __attribute__((aligned(16))) uint32_t tab[];
     const unsigned long long lo = 1ull << (4 * e);
     const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -113,12 +119,13 @@ seed_level_kernel(const uint32_t *__restrict tabs, int k, int e, unsigned long l
     uint32_t x[W32], y[W32];
 #pragma unroll
     for (int w = 0; w < W32; w++) { x[w] = active ? S[w * stride + i] : 0u; y[w] = 0u; }   // in flight while the table is staged
-    // The table is staged in two halves (16 KiB each for k = 256): with half the LDS footprint a
-    // block of this kernel fits beside the four resident blocks of the sample kernel on a CU, so
-    // that prefetched seeding (bbb_awgn_prefetch) can overlap the previous fill.
-    const int half = (nnib + 1) / 2 + ((nnib + 1) / 2 & 1);          // even number of nibbles
-    for (int part = 0; part < 2; part++) {
-        const int nlo = part * half, nhi = part ? nnib : (half < nnib ? half : nnib);
+    // The table is staged in `parts` pieces (2: 16 KiB each for k = 256; 4: 8 KiB): a block of this kernel then fits
+    // beside the four resident blocks of the sample kernel on a CU (4 x 32 KiB of the 160; the transmitter variant
+    // holds 4 x 36 KiB, beside which only the 8 KiB form fits), so that prefetched seeding (bbb_awgn_prefetch) can
+    // overlap the previous fill.
+    const int half = seed_part_nibbles(nnib, parts);                  // even number of nibbles
+    for (int part = 0; part < parts; part++) {
+        const int nlo = part * half, nhi = (part + 1) * half < nnib ? (part + 1) * half : nnib;
         if (nlo >= nhi) break;
         if (part) __syncthreads();
         {
@@ -675,14 +682,16 @@ clt_tree_kernel(int nwords, const unsigned long long *__restrict states, unsigne
 // ---------------------------------------------------------------------------------------------
 template <int W32>
 static int seed_and_slice(int k, const uint32_t *d_tabs, const uint32_t *s16, uint64_t G, uint32_t *d_states,
-                          uint64_t stride, unsigned nlanes, uint32_t *d_planes, hipStream_t st, int slice_mode) {
+                          uint64_t stride, unsigned nlanes, uint32_t *d_planes, hipStream_t st, int slice_mode, int parts) {
+    parts = (int)env_knob("BBB_SEED_PARTS", parts);
     Seed16 s;
     for (int i = 0; i < 16; i++)
         for (int w = 0; w < 16; w++) s.w[i][w] = w < W32 ? s16[i * 16 + w] : 0u;
     int levels = 0;                                   // radix-16 levels needed: 16^levels >= G
     while ((1ull << (4 * levels)) < G) levels++;
-    const int nnib_h = (k + 3) / 4, half_h = (nnib_h + 1) / 2 + ((nnib_h + 1) / 2 & 1);
-    size_t lds = (size_t)half_h * 16 * W32 * sizeof(uint32_t);      // half a table at a time
+    if (parts != 2 && parts != 4) return fail(BBB_EINVAL, "seeding stages its tables in 2 or 4 pieces");
+    const int nnib_h = (k + 3) / 4, half_h = seed_part_nibbles(nnib_h, parts);
+    size_t lds = (size_t)half_h * 16 * W32 * sizeof(uint32_t);      // one piece of a table at a time
     if (env_knob("BBB_SEED_LDS_KB", 0) > 0 && lds < (size_t)env_knob("BBB_SEED_LDS_KB", 0) * 1024)
         lds = (size_t)env_knob("BBB_SEED_LDS_KB", 0) * 1024;        // (experiments: fewer seeding blocks per CU beside the sample kernel)
     if (lds > 48 * 1024) {     // per device (hipFuncSetAttribute applies to the current one), guarded
@@ -701,7 +710,7 @@ static int seed_and_slice(int k, const uint32_t *d_tabs, const uint32_t *s16, ui
     for (int e = 1; e < levels; e++) {               // level 0 (states 1..15) was done on the host
         const uint64_t n = 1ull << (4 * e);
         hipLaunchKernelGGL((seed_level_kernel<W32>), dim3((unsigned)((n + 255) / 256), 15), dim3(256), lds, st, d_tabs, k, e,
-                           (unsigned long long)G, (unsigned long long)stride, d_states);
+                           (unsigned long long)G, (unsigned long long)stride, d_states, parts);
     }
     if (slice_mode == 1) return bitslice512p_launch(d_states, G, stride, nlanes, d_planes, st);
     const uint64_t threads = (uint64_t)nlanes * (uint64_t)((k + 31) / 32);
@@ -712,15 +721,15 @@ static int seed_and_slice(int k, const uint32_t *d_tabs, const uint32_t *s16, ui
 }
 
 int awgn_seed_launch(int k, const uint32_t *d_tabs, const uint32_t *s16, uint64_t G, uint32_t *d_states,
-                     uint64_t stride, unsigned nlanes, uint32_t *d_planes, hipStream_t st, int slice_mode) {
+                     uint64_t stride, unsigned nlanes, uint32_t *d_planes, hipStream_t st, int slice_mode, int parts) {
     switch ((k + 31) / 32) {
-    case 1: return seed_and_slice<1>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st, slice_mode);
-    case 2: return seed_and_slice<2>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st, slice_mode);
-    case 3: case 4: return seed_and_slice<4>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st, slice_mode);
-    case 5: case 6: return seed_and_slice<6>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st, slice_mode);
-    case 7: case 8: return seed_and_slice<8>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st, slice_mode);
-    case 9: case 10: case 11: case 12: return seed_and_slice<12>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st, slice_mode);
-    case 13: case 14: case 15: case 16: return seed_and_slice<16>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st, slice_mode);
+    case 1: return seed_and_slice<1>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st, slice_mode, parts);
+    case 2: return seed_and_slice<2>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st, slice_mode, parts);
+    case 3: case 4: return seed_and_slice<4>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st, slice_mode, parts);
+    case 5: case 6: return seed_and_slice<6>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st, slice_mode, parts);
+    case 7: case 8: return seed_and_slice<8>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st, slice_mode, parts);
+    case 9: case 10: case 11: case 12: return seed_and_slice<12>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st, slice_mode, parts);
+    case 13: case 14: case 15: case 16: return seed_and_slice<16>(k, d_tabs, s16, G, d_states, stride, nlanes, d_planes, st, slice_mode, parts);
     default: return fail(BBB_EINVAL, "k must be in [2, 512]");
     }
 }

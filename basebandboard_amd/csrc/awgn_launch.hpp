@@ -9,8 +9,10 @@ namespace bbb {
 // their bit planes
 // s16: the first 16 start states, [16][16] words (host computed)
 // slice_mode 0: planes [k][nlanes], 32 generators per lane; 1: the packed n512 layout of awgn512.hip, 16 per lane
+// parts: the level kernels stage their jump tables in LDS in 2 or 4 pieces (16 / 8 KiB for k = 256): 4 when the
+// seeding is to run beside the transmitter variant of the sample kernel, which leaves less LDS free
 int awgn_seed_launch(int k, const uint32_t *d_tabs, const uint32_t *s16, uint64_t G, uint32_t *d_states,
-                     uint64_t stride, unsigned nlanes, uint32_t *d_planes, hipStream_t st, int slice_mode = 0);
+                     uint64_t stride, unsigned nlanes, uint32_t *d_planes, hipStream_t st, int slice_mode = 0, int parts = 2);
 // awgn512.hip: generated kernel for the shipped n512 matrix (packed state, 16 generators per lane, int16 out)
 bool awgn512p_matches(int k, const uint16_t *taps, const uint32_t *row_off);
 int bitslice512p_launch(const uint32_t *d_states, uint64_t G, uint64_t stride, unsigned nlanes, uint32_t *d_planes, hipStream_t st);

@@ -84,6 +84,12 @@ struct bbb_lutopt {
     unsigned long long *d_counters = nullptr; size_t counters_cap = 0;
     uint32_t *d_txnoise = nullptr; size_t txnoise_cap = 0;    // TX: int8 noise samples (as words)
     uint32_t *d_txbits = nullptr; size_t txbits_cap = 0;      // TX: packed data bits (as words)
+    // fused TX (bbb_tx_fill_i16 with noise): the data bits of call s+1 are generated on the side stream while the sample
+    // kernel of call s still reads its own -- two buffers, each with the event of its last reader
+    uint32_t *d_fbits[2] = {nullptr, nullptr}; size_t fbits_cap[2] = {0, 0};
+    hipEvent_t fbits_read[2] = {nullptr, nullptr}, fbits_ready = nullptr;
+    bool fbits_pending[2] = {false, false};
+    int fbits_slot = 0;
     // which stream position the planes in d_planes currently describe
     bool planes_valid = false;
     uint64_t planes_first = 0, planes_L = 0, planes_G = 0;
@@ -120,6 +126,7 @@ struct bbb_lutopt {
     // samples, which wait in its staging slot: `left` more fills of n samples, the next one at stream position `first`,
     // at byte `win_lo` of the kernel's output; (L, G, nlanes) = that kernel's partition
     struct Ahead { bool valid = false; uint64_t first = 0, n = 0, win_lo = 0, L = 0, G = 0; unsigned nlanes = 0, left = 0; int slot = 0; } ahead;
+    bool last_fill_tx = false;            // the last sample-kernel launch was the transmitter variant (more LDS: see bbb_awgn_prefetch)
     int staged_level = 0;                 // 0 off, 1 staged, m >= 2 staged with m fills per sample kernel
     hipEvent_t cur_last_read = nullptr;   // same, for the buffers currently in d_states / d_planes
     bool cur_read_pending = false;
@@ -425,6 +432,7 @@ int awgn_fill(bbb_lutopt *h, void *dst, int elem_size, uint64_t nsamples, uint64
     partition(h, nsamples, 16, &L, &G, &nlanes);
     if (L > 0xffffff00ull) return fail(BBB_EINVAL, "nsamples too large for one call (segment length must fit 32 bits): split it");
     const bool fast256 = h->specialised && elem_size == 1;
+    h->last_fill_tx = false;
     const bool staged = fast256 && h->staged_mode && nsamples >= (1ull << 24);
     // look-ahead: this very range was produced by the previous fill's sample kernel and waits in its staging slot
     if (staged && h->ahead.valid && h->ahead.first == first_step && h->ahead.n == nsamples) {
@@ -727,10 +735,10 @@ int bbb_lutopt_destroy(bbb_lutopt *h) {
     for (auto &p : h->prbs_plans) (void)hipFree(p.second.d_cols);
     for (void *p : {(void *)h->d_states, (void *)h->d_planes, (void *)h->d_pstates, (void *)h->d_pplanes,
                     (void *)h->d_taps, (void *)h->d_row_off, (void *)h->d_counters, (void *)h->d_txnoise,
-                    (void *)h->d_txbits, (void *)h->pf.d_states, (void *)h->pf.d_planes})
+                    (void *)h->d_txbits, (void *)h->d_fbits[0], (void *)h->d_fbits[1], (void *)h->pf.d_states, (void *)h->pf.d_planes})
         (void)hipFree(p);
     for (hipEvent_t e : {h->pf.seeded, h->pf.last_read, h->cur_last_read, h->handover, h->stage_free[0], h->stage_free[1],
-                         h->stage_arith[0], h->stage_arith[1], h->ev_user})
+                         h->stage_arith[0], h->stage_arith[1], h->ev_user, h->fbits_read[0], h->fbits_read[1], h->fbits_ready})
         if (e) (void)hipEventDestroy(e);
     for (hipStream_t st : {h->side, h->xs, h->ys})
         if (st) (void)hipStreamDestroy(st);
@@ -866,7 +874,8 @@ int bbb_awgn_prefetch(bbb_lutopt *h, uint64_t nsamples, uint64_t first_step) {
     h->pw->apply(first_step, h->init, s0);
     uint32_t s16[256];
     first16(*plan, s0, s16);
-    if ((rc = awgn_seed_launch(h->k, plan->d_cols, s16, G, pf.d_states, G, nlanes, pf.d_planes, side))) return rc;
+    // (this seeding runs beside the kernel of the fill before: the transmitter variant leaves LDS for 8 KiB pieces only)
+    if ((rc = awgn_seed_launch(h->k, plan->d_cols, s16, G, pf.d_states, G, nlanes, pf.d_planes, side, 0, h->last_fill_tx ? 4 : 2))) return rc;
     BBB_HIP(hipEventRecord(pf.seeded, side));
     pf.valid = true;
     pf.first = first_step; pf.L = L; pf.G = G; pf.nlanes = nlanes;
@@ -1056,33 +1065,51 @@ int bbb_tx_fill_i16(bbb_lutopt *h, const bbb_tx_cfg *cfg, int16_t *out_dev, uint
         partition(h, nsamples, 16, &L, &G, &nlanes);
         const bool staged = h->staged_mode && nsamples >= (1ull << 24);
         if ((rc = begin_op(h, staged))) return rc;
+        h->last_fill_tx = true;
         const int64_t F = (int64_t)first_sample - 17, FM = F >> 3;            // arithmetic shift = floor
         const bool use_bits = cfg->bit_en && nbits;
         // buffer: two zero 64-bit words (data bits before the first read as 0, the shaper's reset shift register), the
         // bits m0 .. m0+nbits-1, slack for the windows of rounds past the end of the request
         const uint64_t words64 = 2 + (nbits + 63) / 64 + (L / 8 + 63) / 64 + 2;
-        if (h->txbits_cap < (size_t)words64 * 2) {
-            BBB_HIP(hipStreamSynchronize(h->cs));                                // an earlier call's kernel may still read it
-            if ((rc = grow(&h->d_txbits, &h->txbits_cap, (size_t)words64 * 2))) return rc;
+        const int bs = h->fbits_slot ^= 1;
+        if (!h->side) BBB_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        for (hipEvent_t *e : {&h->fbits_read[bs], &h->fbits_ready})
+            if (!*e) BBB_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        if (h->fbits_cap[bs] < (size_t)words64 * 2) {
+            if (h->fbits_pending[bs]) BBB_HIP(hipEventSynchronize(h->fbits_read[bs]));      // growing frees the old buffer
+            h->fbits_pending[bs] = false;
+            if ((rc = grow(&h->d_fbits[bs], &h->fbits_cap[bs], (size_t)words64 * 2))) return rc;
         }
+        uint32_t *const d_bits = h->d_fbits[bs];
         if (use_bits) {
-            BBB_HIP(hipMemsetAsync(h->d_txbits, 0, 16, h->cs));
-            uint64_t *bits64 = (uint64_t *)h->d_txbits + 2;
-            if (cfg->source == 0) rc = prbs_fill_launch(cfg->prbs_k, cfg->prbs_state, (uint64_t)m0, nbits, bits64, h->cs);
-            else rc = pulse_bits_launch(bits64, m0, (nbits + 63) / 64, h->cs);
+            // on the side stream: not behind the previous call's sample kernel, which is what h->cs would mean
+            if (h->fbits_pending[bs]) BBB_HIP(hipStreamWaitEvent(h->side, h->fbits_read[bs], 0));
+            BBB_HIP(hipMemsetAsync(d_bits, 0, 16, h->side));
+            uint64_t *bits64 = (uint64_t *)d_bits + 2;
+            if (cfg->source == 0) rc = prbs_fill_launch(cfg->prbs_k, cfg->prbs_state, (uint64_t)m0, nbits, bits64, h->side);
+            else rc = pulse_bits_launch(bits64, m0, (nbits + 63) / 64, h->side);
             if (rc) return rc;
+            BBB_HIP(hipEventRecord(h->fbits_ready, h->side));
+            BBB_HIP(hipStreamWaitEvent(h->cs, h->fbits_ready, 0));
         }
         bool from_pf = false;
         if ((rc = acquire_planes(h, cfg->warmup + first_sample, L, G, nlanes, true, &from_pf))) return rc;      // tx.py:70-71
         const uint32_t rel_base = (uint32_t)(FM - 7 - (m0 - 128));
         auto arith = [&](void *dst, bool to_stage) {
-            return awgn256_tx_launch(h->d_planes, (int16_t *)dst, nsamples, (unsigned)L, G, nlanes, cfg->coeffs, h->d_txbits,
+            return awgn256_tx_launch(h->d_planes, (int16_t *)dst, nsamples, (unsigned)L, G, nlanes, cfg->coeffs, d_bits,
                                      (uint32_t)(words64 * 2), rel_base, (uint32_t)(F & 7), cfg->noise_var, cfg->bit_en, use_bits ? 1 : 0,
                                      to_stage, h->cs);
         };
-        if (staged) return staged_fill(h, out_dev, nsamples * 2, 32, L, G, nlanes, nullptr, from_pf, [&](void *stage) { return arith(stage, true); });
-        rc = arith(out_dev, false);
-        return rc ? rc : mark_planes_read(h);
+        if (staged) {
+            rc = staged_fill(h, out_dev, nsamples * 2, 32, L, G, nlanes, nullptr, from_pf, [&](void *stage) { return arith(stage, true); });
+        } else {
+            rc = arith(out_dev, false);
+            if (!rc) rc = mark_planes_read(h);
+        }
+        if (rc) return rc;
+        BBB_HIP(hipEventRecord(h->fbits_read[bs], h->cs));        // (staged: the piece mover does not read the bits)
+        h->fbits_pending[bs] = true;
+        return BBB_OK;
     }
     if ((rc = begin_op(h, false))) return rc;
     const bool have_bits = cfg->source == 0 && nbits && cfg->bit_en;

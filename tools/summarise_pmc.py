@@ -46,6 +46,10 @@ def main():
         res["awgn256_kernel_hbm_write_bytes_per_launch"] = w
         res["awgn256_kernel_hbm_fetch_bytes_per_launch_corrected"] = f
         res["awgn256_kernel_hbm_bytes_per_launch"] = w + f
+    # what one launch of the timed workload produces: 1e9 samples, or m x 1e9 with bench.py's look-ahead (BENCH_LOOK_AHEAD,
+    # default 2); bench.py only quotes a summary whose launches are the size of its own
+    import os
+    res["samples_per_launch"] = int(os.environ.get("BBB_SAMPLES_PER_LAUNCH", "1000000000"))
     if "GRBM_GUI_ACTIVE" in a and "SQ_INSTS_VALU" in a:
         res["awgn256_kernel_shader_cycles_per_xcd"] = a["GRBM_GUI_ACTIVE"]["avg"] / 8
     json.dump(res, open(out, "w"), indent=1)
