@@ -171,6 +171,16 @@ def main():
         # the GPU (no torch.cuda / HIP call has happened yet); the ranks are its children.
         sys.exit(launch_ranks(args.gpus))
 
+    # stdout carries ONE line, the JSON: libraries that print there on their own (RCCL's version banner under
+    # NCCL_DEBUG=VERSION, which some images export) go to stderr for the whole run -- at the descriptor level, so that
+    # C code is covered -- and the result is written to the saved descriptor at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
+
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -186,7 +196,7 @@ def main():
         t = torch.tensor([rank + 1], dtype=torch.int64)
         dist.all_reduce(t)
         if rank == 0:
-            print(json.dumps({"launch_check": world, "sum": int(t.item())}))
+            emit({"launch_check": world, "sum": int(t.item())})
         dist.barrier()
         dist.destroy_process_group()
         return
@@ -530,7 +540,7 @@ def main():
             out["roofline_other"] = other
         if extra:
             out["extra"] = extra
-        print(json.dumps(out))
+        emit(out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
