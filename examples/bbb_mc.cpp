@@ -4,7 +4,8 @@
 //
 //   bbb_mc [--matrix FILE] [--init HEX] [--gpus N] [--json 1]
 //          BER sweep:   [--prbs 31] [--bits 1e9] [--nv 8] [--ebn0 A:B:STEP] [--seeds N] [--shard bits|seeds|trials]
-//          AWGN fill:   --nsamples 1e9 [--steps 5] [--staged 0|1]   (1, default: bbb_lutopt_set_staged, the two-kernel form)
+//          AWGN fill:   --nsamples 1e9 [--steps 5] [--staged 0|1|m]   (bbb_lutopt_set_staged: 1 = the two-kernel form,
+//                       m = 2..8 (default 2) = one sample kernel per m consecutive steps)
 //          loopback:    --loopback BITS
 //
 // --matrix   the reference's 0/1 text format (software/rnghunt/matrices/256); default: the shipped n256 matrix
@@ -78,7 +79,7 @@ struct Matrix {
     std::vector<uint32_t> off;
 };
 
-// AWGN fill on one device: `steps` fills of n samples, device d of ndev taking every ndev-th piece of the stream
+// AWGN fill on one device: `steps` consecutive fills of n samples; device d reads its own stretch of the stream, 2^48 d steps in
 struct FillResult { int rc = 0; std::string err; double kernel_ms = 0, seed_ms = 0, wall_s = 0; std::vector<int8_t> head; };
 static void fill_worker(const Matrix &m, unsigned long long init0, int dev, int ndev, uint64_t n, int steps, int staged, FillResult *res) {
     auto body = [&]() -> int {
@@ -90,10 +91,12 @@ static void fill_worker(const Matrix &m, unsigned long long init0, int dev, int 
         (void)bbb_lutopt_set_staged(h, staged);               // two-kernel form: the piece mover of step s beside step s+1
         int8_t *buf = nullptr;
         if (hipMalloc((void **)&buf, (n + 15) / 16 * 16) != hipSuccess) { res->err = "hipMalloc failed"; return 1; }
-        auto first = [&](int s) { return (uint64_t)16 + ((uint64_t)s * (uint64_t)ndev + (uint64_t)dev) * n; };
+        (void)ndev;
+        auto first = [&](int s) { return (uint64_t)16 + ((uint64_t)dev << 48) + (uint64_t)s * n; };
         if ((rc = bbb_awgn_fill_i8(h, buf, n, first(0)))) { res->err = bbb_last_error_detail(); return rc; }   // builds the jump plan
         res->head.resize(n < 64 ? n : 64);
         (void)hipMemcpy(res->head.data(), buf, res->head.size(), hipMemcpyDeviceToHost);
+        (void)bbb_lutopt_set_staged(h, staged);               // (drops a look-ahead half: the timed steps start on a launch)
         (void)bbb_lutopt_profile(h, 1);
         (void)hipDeviceSynchronize();
         const double t0 = now_s();
@@ -115,7 +118,7 @@ static void fill_worker(const Matrix &m, unsigned long long init0, int dev, int 
 
 int main(int argc, char **argv) {
     std::string matrix, shard = "bits";
-    int k = 31, nv = 8, seeds = 1, gpus = 1, json = 0, steps = 5, multi = 0, staged = 1;
+    int k = 31, nv = 8, seeds = 1, gpus = 1, json = 0, steps = 5, multi = 0, staged = 2;
     unsigned long long init0 = 1;
     double bits = 1e9, from = 0, to = 10, step = 1, loopback = 0, nsamples = 0;
     for (int i = 1; i + 1 < argc; i += 2) {
@@ -185,12 +188,15 @@ int main(int argc, char **argv) {
             kms = std::fmax(kms, res[(size_t)d].kernel_ms);
         }
         const double gs = (double)gpus * steps * (double)n / wall / 1e9;
-        const double kernel_gbs = kms > 0 ? (double)n / (kms * 1e-3) / 1e9 : 0;        // 1 B per sample
+        // what one launch of the sample kernel produces (bbb.h, bbb_lutopt_set_staged: look-ahead applies to fills of at
+        // least 2^24 samples, a multiple of 16)
+        const uint64_t per_launch = (staged >= 2 && n >= (1ull << 24) && n % 16 == 0) ? (uint64_t)staged * n : n;
+        const double kernel_gbs = kms > 0 ? (double)per_launch / (kms * 1e-3) / 1e9 : 0;        // 1 B per sample
         if (json) {
             std::printf("{\"mode\": \"awgn_fill\", \"n_gpus\": %d, \"samples_per_step_per_gpu\": %llu, \"steps\": %d, \"gsample_s\": %.3f, "
-                        "\"kernel_ms_avg\": %.4f, \"seed_ms_avg\": %.4f, \"hbm_write_gb_s_per_gpu\": %.1f, \"hbm_roofline_frac\": %.4f, "
+                        "\"kernel_ms_avg\": %.4f, \"samples_per_launch\": %llu, \"seed_ms_avg\": %.4f, \"hbm_write_gb_s_per_gpu\": %.1f, \"hbm_roofline_frac\": %.4f, "
                         "\"collective\": \"none (independent shards of one sequential stream)\", \"head\": [",
-                        gpus, (unsigned long long)n, steps, gs, kms, res[0].seed_ms, kernel_gbs, kernel_gbs / kHbmPeakGBs);
+                        gpus, (unsigned long long)n, steps, gs, kms, (unsigned long long)per_launch, res[0].seed_ms, kernel_gbs, kernel_gbs / kHbmPeakGBs);
             for (size_t i = 0; i < res[0].head.size(); i++) std::printf("%s%d", i ? ", " : "", (int)res[0].head[i]);
             std::printf("]}\n");
         } else {

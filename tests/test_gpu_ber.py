@@ -233,6 +233,14 @@ def test_cli_json_multi_and_awgn_modes(gpu, oracle):
     assert r.returncode == 0, r.stderr
     a = json.loads(r.stdout.strip().splitlines()[-1])
     assert a["mode"] == "awgn_fill" and a["gsample_s"] > 0 and 0 < a["hbm_roofline_frac"] < 1
-    assert a["head"] == m.awgn(1, 16, 64, fast=True).tolist()
+    assert a["head"] == m.awgn(1, 16, 64, fast=True).tolist() and a["samples_per_launch"] == 3_000_000
+    # a size at which the staged form and its look-ahead apply (default --staged 2; 1 and 0 for the plainer forms)
+    nbig = (1 << 24) + 16
+    for staged, per in ((2, 2 * nbig), (1, nbig), (0, nbig)):
+        r = subprocess.run([str(exe), "--nsamples", str(nbig), "--steps", "4", "--staged", str(staged), "--json", "1"], cwd=str(ROOT),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        a = json.loads(r.stdout.strip().splitlines()[-1])
+        assert a["samples_per_launch"] == per and a["gsample_s"] > 0 and a["head"] == m.awgn(1, 16, 64, fast=True).tolist()
     r = subprocess.run([str(exe), "--gpus", "64"], cwd=str(ROOT), capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "visible" in r.stderr
