@@ -123,9 +123,13 @@ struct bbb_lutopt {
     int pf_waited_slot = -1;              // staging slot whose mover the pending prefetch's seeding waited for
     hipEvent_t stage_arith[2] = {nullptr, nullptr};   // recorded behind the sample kernel that filled the slot
     // look-ahead (bbb_lutopt_set_staged(h, m), m >= 2): the sample kernel of a fill also produced the next m - 1 fills'
-    // samples, which wait in its staging slot: `left` more fills of n samples, the next one at stream position `first`,
-    // at byte `win_lo` of the kernel's output; (L, G, nlanes) = that kernel's partition
-    struct Ahead { bool valid = false; uint64_t first = 0, n = 0, win_lo = 0, L = 0, G = 0; unsigned nlanes = 0, left = 0; int slot = 0; } ahead;
+    // samples, which wait in its staging slot: `left` more fills of n samples, the next one at stream position `first`
+    // (kind 0: bbb_awgn_fill_i8, a generator step; kind 1: bbb_tx_fill_i16 with configuration `cfg`, a TX sample index)
+    // = generator step `step`, at byte `win_lo` of the kernel's output; (L, G, nlanes) = that kernel's partition
+    struct Ahead {
+        bool valid = false; int kind = 0; uint64_t first = 0, step = 0, n = 0, win_lo = 0, L = 0, G = 0;
+        unsigned nlanes = 0, left = 0; int slot = 0; bbb_tx_cfg cfg{};
+    } ahead;
     bool last_fill_tx = false;            // the last sample-kernel launch was the transmitter variant (more LDS: see bbb_awgn_prefetch)
     int staged_level = 0;                 // 0 off, 1 staged, m >= 2 staged with m fills per sample kernel
     hipEvent_t cur_last_read = nullptr;   // same, for the buffers currently in d_states / d_planes
@@ -435,11 +439,11 @@ int awgn_fill(bbb_lutopt *h, void *dst, int elem_size, uint64_t nsamples, uint64
     h->last_fill_tx = false;
     const bool staged = fast256 && h->staged_mode && nsamples >= (1ull << 24);
     // look-ahead: this very range was produced by the previous fill's sample kernel and waits in its staging slot
-    if (staged && h->ahead.valid && h->ahead.first == first_step && h->ahead.n == nsamples) {
+    if (staged && h->ahead.valid && h->ahead.kind == 0 && h->ahead.first == first_step && h->ahead.n == nsamples) {
         int rc0 = begin_op(h, true);
         if (rc0) return rc0;
         const bbb_lutopt::Ahead a = h->ahead;
-        h->ahead.first += nsamples;
+        h->ahead.first += nsamples; h->ahead.step += nsamples;
         h->ahead.win_lo += nsamples;
         h->ahead.valid = --h->ahead.left > 0;
         return queue_mover(h, a.slot, dst, a.win_lo, nsamples, 16, a.L, a.G, a.nlanes);
@@ -469,8 +473,8 @@ int awgn_fill(bbb_lutopt *h, void *dst, int elem_size, uint64_t nsamples, uint64
         }, &slot);
         if (h->profiling) h->prof_pending.push_back(ev);
         if (!rc && ahead) {
-            h->ahead.valid = true;
-            h->ahead.first = first_step + nsamples; h->ahead.n = nsamples; h->ahead.win_lo = nsamples;
+            h->ahead.valid = true; h->ahead.kind = 0;
+            h->ahead.first = h->ahead.step = first_step + nsamples; h->ahead.n = nsamples; h->ahead.win_lo = nsamples;
             h->ahead.left = (unsigned)m - 1;
             h->ahead.L = L; h->ahead.G = G; h->ahead.nlanes = nlanes; h->ahead.slot = slot;
         }
@@ -834,14 +838,17 @@ int bbb_awgn_prefetch(bbb_lutopt *h, uint64_t nsamples, uint64_t first_step) {
     unsigned nlanes;
     if (h->staged_level >= 2 && nsamples >= (1ull << 24) && (nsamples % 16) == 0) {
         // look-ahead: a sample kernel covers m fills.  If the announced fill is one that already waits in a staging slot,
-        // what needs start states is the fill after the LAST waiting one; and they are those of an m-fold request.
+        // what needs start states is the fill after the LAST waiting one; and they are those of an m-fold request
+        // (which kind of fill comes next is not known here: the kind of the last one is assumed; a wrong guess only
+        // means that the fill seeds for itself)
         const uint64_t m = (uint64_t)h->staged_level;
-        if (h->ahead.valid && h->ahead.first == first_step && h->ahead.n == nsamples) {
+        if (h->ahead.valid && h->ahead.step == first_step && h->ahead.n == nsamples) {
             const uint64_t skip = (uint64_t)h->ahead.left * nsamples;
             if (first_step + skip < first_step) return BBB_OK;
             first_step += skip;
         }
-        if (m * nsamples < (1ull << 40) && first_step + m * nsamples > first_step) nsamples *= m;
+        const uint64_t cap = h->last_fill_tx ? (1ull << 31) : (1ull << 40);
+        if (m * nsamples < cap && first_step + m * nsamples > first_step) nsamples *= m;
     }
     partition(h, nsamples, 16, &L, &G, &nlanes);
     if (L > 0xffffff00ull) return BBB_OK;                         // the matching fill will refuse; nothing to prepare
@@ -1011,6 +1018,12 @@ static void tx_bit_range(uint64_t first, uint64_t n, int64_t *m0, uint64_t *nbit
     *nbits = hi >= *m0 ? (uint64_t)(hi - *m0 + 1) : 0;
 }
 
+static bool tx_cfg_equal(const bbb_tx_cfg &a, const bbb_tx_cfg &b) {
+    return std::memcmp(a.coeffs, b.coeffs, sizeof a.coeffs) == 0 && a.source == b.source && a.prbs_k == b.prbs_k &&
+           a.prbs_state == b.prbs_state && a.bit_en == b.bit_en && a.noise_en == b.noise_en && a.noise_var == b.noise_var &&
+           a.warmup == b.warmup;
+}
+
 static int tx_check(const bbb_tx_cfg *cfg) {
     if (!cfg) return fail(BBB_EINVAL, "null cfg");
     if (cfg->source != 0 && cfg->source != 1) return fail(BBB_EINVAL, "source must be 0 (PRBS) or 1 (pulse)");
@@ -1056,14 +1069,30 @@ int bbb_tx_fill_i16(bbb_lutopt *h, const bbb_tx_cfg *cfg, int16_t *out_dev, uint
     BBB_HIP(hipSetDevice(h->device));
     int64_t m0;
     uint64_t nbits;
-    tx_bit_range(first_sample, nsamples, &m0, &nbits);
     if (cfg->noise_en && h->specialised && first_sample + nsamples < (1ull << 62) && nsamples < (1ull << 31)) {
         // the shaper fused into the sample kernel: the int8 noise stream never goes through HBM
         if (cfg->warmup + first_sample + nsamples < nsamples) return fail(BBB_EINVAL, "warmup + first_sample + nsamples overflows");
         uint64_t L, G;
         unsigned nlanes;
-        partition(h, nsamples, 16, &L, &G, &nlanes);
         const bool staged = h->staged_mode && nsamples >= (1ull << 24);
+        // look-ahead (bbb_lutopt_set_staged(h, m >= 2)): these very samples, of this very configuration, were produced by
+        // an earlier call's sample kernel and wait in its staging slot
+        if (staged && h->ahead.valid && h->ahead.kind == 1 && h->ahead.first == first_sample && h->ahead.n == nsamples &&
+            tx_cfg_equal(h->ahead.cfg, *cfg)) {
+            if ((rc = begin_op(h, true))) return rc;
+            h->last_fill_tx = true;
+            const bbb_lutopt::Ahead a = h->ahead;
+            h->ahead.first += nsamples; h->ahead.step += nsamples;
+            h->ahead.win_lo += 2 * nsamples;
+            h->ahead.valid = --h->ahead.left > 0;
+            return queue_mover(h, a.slot, out_dev, a.win_lo, 2 * nsamples, 32, a.L, a.G, a.nlanes);
+        }
+        const uint64_t mla = (uint64_t)h->staged_level;
+        const bool ahead = staged && mla >= 2 && (nsamples % 16) == 0 && mla * nsamples < (1ull << 31) &&
+                           first_sample + mla * nsamples < (1ull << 62) && cfg->warmup + first_sample + mla * nsamples >= mla * nsamples;
+        const uint64_t ntotal = ahead ? mla * nsamples : nsamples;        // what the sample kernel produces
+        tx_bit_range(first_sample, ntotal, &m0, &nbits);
+        partition(h, ntotal, 16, &L, &G, &nlanes);
         if ((rc = begin_op(h, staged))) return rc;
         h->last_fill_tx = true;
         const int64_t F = (int64_t)first_sample - 17, FM = F >> 3;            // arithmetic shift = floor
@@ -1096,12 +1125,20 @@ int bbb_tx_fill_i16(bbb_lutopt *h, const bbb_tx_cfg *cfg, int16_t *out_dev, uint
         if ((rc = acquire_planes(h, cfg->warmup + first_sample, L, G, nlanes, true, &from_pf))) return rc;      // tx.py:70-71
         const uint32_t rel_base = (uint32_t)(FM - 7 - (m0 - 128));
         auto arith = [&](void *dst, bool to_stage) {
-            return awgn256_tx_launch(h->d_planes, (int16_t *)dst, nsamples, (unsigned)L, G, nlanes, cfg->coeffs, d_bits,
+            return awgn256_tx_launch(h->d_planes, (int16_t *)dst, ntotal, (unsigned)L, G, nlanes, cfg->coeffs, d_bits,
                                      (uint32_t)(words64 * 2), rel_base, (uint32_t)(F & 7), cfg->noise_var, cfg->bit_en, use_bits ? 1 : 0,
                                      to_stage, h->cs);
         };
         if (staged) {
-            rc = staged_fill(h, out_dev, nsamples * 2, 32, L, G, nlanes, nullptr, from_pf, [&](void *stage) { return arith(stage, true); });
+            int slot = 0;
+            rc = staged_fill(h, out_dev, nsamples * 2, 32, L, G, nlanes, nullptr, from_pf, [&](void *stage) { return arith(stage, true); }, &slot);
+            if (!rc && ahead) {
+                bbb_lutopt::Ahead &a = h->ahead;
+                a.valid = true; a.kind = 1; a.cfg = *cfg;
+                a.first = first_sample + nsamples; a.step = cfg->warmup + first_sample + nsamples;
+                a.n = nsamples; a.win_lo = 2 * nsamples; a.left = (unsigned)mla - 1;
+                a.L = L; a.G = G; a.nlanes = nlanes; a.slot = slot;
+            }
         } else {
             rc = arith(out_dev, false);
             if (!rc) rc = mark_planes_read(h);
@@ -1112,6 +1149,7 @@ int bbb_tx_fill_i16(bbb_lutopt *h, const bbb_tx_cfg *cfg, int16_t *out_dev, uint
         return BBB_OK;
     }
     if ((rc = begin_op(h, false))) return rc;
+    tx_bit_range(first_sample, nsamples, &m0, &nbits);
     const bool have_bits = cfg->source == 0 && nbits && cfg->bit_en;
     if (have_bits) {
         if ((rc = grow(&h->d_txbits, &h->txbits_cap, (size_t)((nbits + 63) / 64 + 2) * 2))) return rc;

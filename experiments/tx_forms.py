@@ -1,5 +1,6 @@
-"""TX waveform rate (2^29 samples per call) in the one-kernel and the staged form; with the experiments build the knob
-BBB_SEED_PARTS overrides how many pieces the seeding stages its tables in."""
+"""TX waveform rate per call size in the one-kernel form, the staged form and the staged form with look-ahead (one sample
+kernel per two calls); with the experiments build the knob BBB_SEED_PARTS overrides how many pieces the seeding
+stages its tables in."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,19 +8,20 @@ from basebandboard_amd import _lib
 if os.environ.get("BBB_EXP"):
     _lib.select_build("experiments")
 import basebandboard_amd as bbb
-for ntx, staged in ((1 << 29, False), (1 << 29, True), (1 << 30, False), (1 << 30, True)):
-    tx = bbb.TX(31, 1, 0, 16, 1, 8)
-    tx.urng.set_staged(staged)
-    buf = torch.empty(ntx, dtype=torch.int16, device="cuda")
-    for i in range(3):
-        tx.generate(ntx, first_sample=i * ntx, out=buf)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for i in range(3, 13):
-        tx.generate(ntx, first_sample=i * ntx, out=buf)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 10
-    print(f"n={ntx} staged={staged} parts={os.environ.get('BBB_SEED_PARTS','default')}: {ms:.4f} ms per call = {ntx/ms/1e6:.1f} Gsample/s", flush=True)
-    del tx
+for ntx in (1 << 29, 1_000_000_000):
+    for form in ("one kernel", "staged", "staged + look-ahead 2"):
+        tx = bbb.TX(31, 1, 0, 16, 1, 8)
+        tx.urng.set_staged(form != "one kernel", look_ahead=2 if "look" in form else False)
+        buf = torch.empty(ntx, dtype=torch.int16, device="cuda")
+        for i in range(4):
+            tx.generate(ntx, first_sample=i * ntx, out=buf)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(4, 14):
+            tx.generate(ntx, first_sample=i * ntx, out=buf)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        print(f"n={ntx} {form}: {ms:.4f} ms per call = {ntx/ms/1e6:.1f} Gsample/s", flush=True)
+        del tx

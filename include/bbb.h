@@ -119,7 +119,8 @@ int bbb_awgn_prefetch(bbb_lutopt *h, uint64_t nsamples, uint64_t first_step);
  * output complete, as before), but the NEXT fill's arithmetic does not -- the mover (memory bound) and the next
  * arithmetic (integer-issue bound) share the machine.  Worth it for back-to-back fills; a single isolated fill
  * finishes later than in the one-kernel form.  Costs two staging buffers of the fill's size.
- * enable = m in 2..8 adds LOOK-AHEAD for bbb_awgn_fill_i8: a fill of n samples at `first` lets its sample kernel produce
+ * enable = m in 2..8 adds LOOK-AHEAD for bbb_awgn_fill_i8 (and for bbb_tx_fill_i16 with noise on this handle, while the
+ * configuration stays the same and m n < 2^31): a fill of n samples at `first` lets its sample kernel produce
  * the m n samples from `first` (one seeding, one launch for m fills; the rest waits in the staging buffer); while the
  * following fills ask for exactly (n, first + n), (n, first + 2 n) ... -- a consumer reading the one sequential stream
  * the reference's generator emits -- each only costs its piece mover.  A fill elsewhere discards what still waits (that

@@ -218,3 +218,37 @@ def test_look_ahead_costs_one_sample_kernel_per_m_fills(gpu, fills, launches):
     _, _, calls = u.profile_read(reset=True)
     u.profile(False)
     assert calls == launches
+
+
+@pytest.mark.parametrize("fills", [2, 3])
+def test_tx_look_ahead_equals_one_kernel_form(gpu, oracle, golden_shaper, fills):
+    """bbb_tx_fill_i16 on a look-ahead handle: one TX sample kernel per `fills` consecutive calls of one configuration;
+    a changed configuration, position or size falls back to its own kernel.  Against the one-kernel form, and a stretch
+    of a later call against the oracle."""
+    n = BIG + 4096
+    x = gpu.TX(31, 1, 0, 16, 1, 8)
+    x.urng.set_staged(True, look_ahead=fills)
+    y = gpu.TX(31, 1, 0, 16, 1, 8)
+    pos = [i * n for i in range(5)]
+    outs = [x.generate(n, first_sample=p) for p in pos]
+    x.noise_var = 3                                            # the waiting samples were made with 8: must not be used
+    outs.append(x.generate(n, first_sample=5 * n))
+    outs.append(x.generate(n, first_sample=6 * n))
+    outs.append(x.generate(n + 16, first_sample=7 * n))        # another size
+    outs.append(x.generate(n, first_sample=100))               # another position
+    outs.append(x.generate(n, first_sample=100 + n, stream_on=False))
+    u = x.urng
+    a = gpu.CLTGRNG(u).generate(n, first_step=16)              # the noise stream on the same handle in between
+    outs.append(x.generate(n, first_sample=100 + 2 * n))
+    torch.cuda.synchronize()
+    refs = [y.generate(n, first_sample=p) for p in pos]
+    y.noise_var = 3
+    refs += [y.generate(n, first_sample=5 * n), y.generate(n, first_sample=6 * n), y.generate(n + 16, first_sample=7 * n),
+             y.generate(n, first_sample=100), y.generate(n, first_sample=100 + n), y.generate(n, first_sample=100 + 2 * n)]
+    torch.cuda.synchronize()
+    for i, (g_, r_) in enumerate(zip(outs, refs)):
+        assert torch.equal(g_, r_), i
+    m = oracle.Lutopt(path=oracle.data_path(256))
+    exp = oracle.tx(m, 1, golden_shaper["rcf_coeffs"][16], 31, 100_000, first_sample=3 * n, noise_var=8, warmup=16)
+    assert np.array_equal(outs[3][:100_000].cpu().numpy(), exp)
+    assert np.array_equal(a[:100_000].cpu().numpy(), m.awgn(1, 16, 100_000, fast=True))
