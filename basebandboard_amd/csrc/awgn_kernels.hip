@@ -123,6 +123,11 @@ seed_level_kernel(const uint32_t *__restrict tabs, int k, int e, unsigned long l
     // beside the four resident blocks of the sample kernel on a CU (4 x 32 KiB of the 160; the transmitter variant
     // holds 4 x 36 KiB, beside which only the 8 KiB form fits), so that prefetched seeding (bbb_awgn_prefetch) can
     // overlap the previous fill.
+    if (parts == 0) {
+        // no LDS at all: the lookups go to the table in global memory (32 KiB per level and digit: the vector cache and
+        // L2 hold it) -- for seeding beside a kernel whose waves wait on the CU's LDS pipeline
+        if (active) nibble_matvec_part<W32>(tabs + ((size_t)e * 15 + (j - 1)) * nt, 0, nnib, x, y);
+    } else {
     const int half = seed_part_nibbles(nnib, parts);                  // even number of nibbles
     for (int part = 0; part < parts; part++) {
         const int nlo = part * half, nhi = (part + 1) * half < nnib ? (part + 1) * half : nnib;
@@ -149,6 +154,7 @@ seed_level_kernel(const uint32_t *__restrict tabs, int k, int e, unsigned long l
         }
         __syncthreads();
         if (active) nibble_matvec_part<W32>(tab, nlo, nhi, x, y);
+    }
     }
     if (active) {
 #pragma unroll
@@ -689,8 +695,8 @@ static int seed_and_slice(int k, const uint32_t *d_tabs, const uint32_t *s16, ui
         for (int w = 0; w < 16; w++) s.w[i][w] = w < W32 ? s16[i * 16 + w] : 0u;
     int levels = 0;                                   // radix-16 levels needed: 16^levels >= G
     while ((1ull << (4 * levels)) < G) levels++;
-    if (parts != 2 && parts != 4) return fail(BBB_EINVAL, "seeding stages its tables in 2 or 4 pieces");
-    const int nnib_h = (k + 3) / 4, half_h = seed_part_nibbles(nnib_h, parts);
+    if (parts != 0 && parts != 2 && parts != 4) return fail(BBB_EINVAL, "seeding stages its tables in 2 or 4 pieces, or reads them in place (0)");
+    const int nnib_h = (k + 3) / 4, half_h = parts ? seed_part_nibbles(nnib_h, parts) : 0;
     size_t lds = (size_t)half_h * 16 * W32 * sizeof(uint32_t);      // one piece of a table at a time
     if (env_knob("BBB_SEED_LDS_KB", 0) > 0 && lds < (size_t)env_knob("BBB_SEED_LDS_KB", 0) * 1024)
         lds = (size_t)env_knob("BBB_SEED_LDS_KB", 0) * 1024;        // (experiments: fewer seeding blocks per CU beside the sample kernel)
