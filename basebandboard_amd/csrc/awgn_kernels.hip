@@ -365,7 +365,11 @@ awgn256_kernel(const uint32_t *__restrict planes, void *__restrict dst_, unsigne
                     int8_t *dst = (int8_t *)dst_;
                     const u32x4 v = {o[0][q], o[1][q], o[2][q], o[3][q]};
                     if (STAGED) {
+#if defined(BBB_EXPERIMENTS) && defined(BBB_STAGE_NT_STORE)
+                        __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(dst_) + slot);
+#else
                         reinterpret_cast<u32x4 *>(dst_)[slot] = v;
+#endif
                     } else if (FULL || off + 16 <= nsamples) {
                         *reinterpret_cast<u32x4 *>(dst + off) = v;
                     } else {
@@ -451,6 +455,22 @@ awgn256_kernel(const uint32_t *__restrict planes, void *__restrict dst_, unsigne
 // after the other).  So the mover is persistent and narrow: one block of four waves per CU (<= 96 registers per lane, and
 // an unused 32 KiB of dynamic LDS so that no second block fits beside four sample-kernel waves), each wave looping over
 // its share of the generator groups with 16 loads of 16 bytes in flight per lane.
+// the mover's accesses (experiments build: -DBBB_UNSTAGE_NT_LOAD / -DBBB_UNSTAGE_NT_STORE make them non-temporal)
+__device__ __forceinline__ u32x4 mover_load(const char *p) {
+#if defined(BBB_EXPERIMENTS) && defined(BBB_UNSTAGE_NT_LOAD)
+    return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+#else
+    return *reinterpret_cast<const u32x4 *>(p);
+#endif
+}
+__device__ __forceinline__ void mover_store(char *p, const u32x4 &v) {
+#if defined(BBB_EXPERIMENTS) && defined(BBB_UNSTAGE_NT_STORE)
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p));
+#else
+    *reinterpret_cast<u32x4 *>(p) = v;
+#endif
+}
+
 template <int PIECE>
 __global__ void __launch_bounds__(256, 5)
 unstage_kernel(const char *__restrict stg, char *__restrict dst_, unsigned long long win_lo, unsigned long long nbytes_,
@@ -490,20 +510,20 @@ unstage_kernel(const char *__restrict stg, char *__restrict dst_, unsigned long 
 #pragma unroll
                 for (unsigned k = 0; k < NG; k++)
 #pragma unroll
-                    for (unsigned t = 0; t < 4; t++) v[k][t] = *reinterpret_cast<const u32x4 *>(src0 + k * gstride_src + t * sstride);
+                    for (unsigned t = 0; t < 4; t++) v[k][t] = mover_load(src0 + k * gstride_src + t * sstride);
 #pragma unroll
                 for (unsigned k = 0; k < NG; k++)
 #pragma unroll
-                    for (unsigned t = 0; t < 4; t++) *reinterpret_cast<u32x4 *>(out0 + k * gstride_dst + t * dstride) = v[k][t];
+                    for (unsigned t = 0; t < 4; t++) mover_store(out0 + k * gstride_dst + t * dstride, v[k][t]);
                 src0 += 4 * sstride;
                 out0 += 4 * dstride;
             }
             for (; r < rounds; r += RT) {
                 u32x4 v[NG];
 #pragma unroll
-                for (unsigned k = 0; k < NG; k++) v[k] = *reinterpret_cast<const u32x4 *>(src0 + k * gstride_src);
+                for (unsigned k = 0; k < NG; k++) v[k] = mover_load(src0 + k * gstride_src);
 #pragma unroll
-                for (unsigned k = 0; k < NG; k++) *reinterpret_cast<u32x4 *>(out0 + k * gstride_dst) = v[k];
+                for (unsigned k = 0; k < NG; k++) mover_store(out0 + k * gstride_dst, v[k]);
                 src0 += sstride;
                 out0 += dstride;
             }

@@ -118,6 +118,28 @@ __device__ __forceinline__ void xor_inplace(u32x4 &a, const u32x4 &b) {
     asm("v_xor_b32 %0, %0, %1" : "+v"(a.w) : "v"(b.w));
 }
 
+// The checker's row loads are NON-TEMPORAL: every byte is read once, and with the hint the read stream runs at 6.3-6.4 TB/s
+// instead of 5.5-5.6 on a clean buffer, and right after a fill it trades fewer of the fill's dirty lines in the
+// memory-side cache for lines it will never read again (0.244 against 0.277 ms for 1.25 GB; profiles/README.md, round 2).
+// -DBBB_PRBS_CHECK_PLAIN (experiments build) restores plain loads for the A/B; -DBBB_PRBS_FILL_NT makes the generator's
+// stores non-temporal (no gain in round 1).
+template <typename T>
+__device__ __forceinline__ T check_load(const T *p) {
+#if defined(BBB_EXPERIMENTS) && defined(BBB_PRBS_CHECK_PLAIN)
+    return *p;
+#else
+    return __builtin_nontemporal_load(p);
+#endif
+}
+template <typename T>
+__device__ __forceinline__ void fill_store(T *p, const T &v) {
+#if defined(BBB_EXPERIMENTS) && defined(BBB_PRBS_FILL_NT)
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 // LW = true keeps the K-row window in (lane-private) LDS instead of registers: the checker then
 // only holds its in-flight loads in registers and can use 16-byte accesses without spilling.
 template <int K, bool CHECK, int WPL, bool LW>
@@ -218,7 +240,7 @@ prbs_stream_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwords,
                 // loads run one batch ahead of the compares (two register batches, static indices)
                 lw_t D[2][DB];
 #pragma unroll
-                for (int i = 0; i < DB && i < K; i++) D[0][i] = reinterpret_cast<const lw_t *>(rowp + (u64)i * RW)[lane];
+                for (int i = 0; i < DB && i < K; i++) D[0][i] = check_load(reinterpret_cast<const lw_t *>(rowp + (u64)i * RW) + lane);
                 // LW: the window makes one LDS round trip per pass (K reads issued back to back, the
                 // in-place recurrence in registers, K writes) so that no register state is carried
                 // around the loop
@@ -244,7 +266,7 @@ prbs_stream_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwords,
 #pragma unroll
                         for (int i = 0; i < DB; i++)
                             if ((bidx + 1) * DB + i < K)
-                                D[(bidx + 1) & 1][i] = reinterpret_cast<const lw_t *>(rowp + (u64)((bidx + 1) * DB + i) * RW)[lane];
+                                D[(bidx + 1) & 1][i] = check_load(reinterpret_cast<const lw_t *>(rowp + (u64)((bidx + 1) * DB + i) * RW) + lane);
                     }
 #pragma unroll
                     for (int i = 0; i < DB; i++) {
@@ -273,12 +295,12 @@ prbs_stream_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwords,
 #pragma unroll
                 for (int i = 0; i < K; i++) Xv[i * 64 + lane] = W[i];
 #pragma unroll
-                for (int i = 0; i < K; i++) reinterpret_cast<lw_t *>(rowp + (u64)i * RW)[lane] = W[i];
+                for (int i = 0; i < K; i++) fill_store(reinterpret_cast<lw_t *>(rowp + (u64)i * RW) + lane, W[i]);
             } else {
 #pragma unroll
                 for (int i = 0; i < K; i++) xor_inplace(V[i], V[(i - TAP + K) % K]);
 #pragma unroll
-                for (int i = 0; i < K; i++) reinterpret_cast<lw_t *>(rowp + (u64)i * RW)[lane] = V[i];
+                for (int i = 0; i < K; i++) fill_store(reinterpret_cast<lw_t *>(rowp + (u64)i * RW) + lane, V[i]);
             }
             continue;
         }
@@ -415,7 +437,7 @@ prbs_check_rev_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwor
             const u64 *rowp = buf + (word0 + (u64)q0 * RW);
             u32x2 D[2][DB];
 #pragma unroll
-            for (int i = 0; i < DB && i < K; i++) D[0][i] = reinterpret_cast<const u32x2 *>(rowp + (u64)i * RW)[lane];
+            for (int i = 0; i < DB && i < K; i++) D[0][i] = check_load(reinterpret_cast<const u32x2 *>(rowp + (u64)i * RW) + lane);
             uint32_t e32 = 0;
 #pragma unroll
             for (int bidx = 0; bidx < NB; bidx++) {
@@ -423,7 +445,7 @@ prbs_check_rev_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwor
 #pragma unroll
                     for (int i = 0; i < DB; i++)
                         if ((bidx + 1) * DB + i < K)
-                            D[(bidx + 1) & 1][i] = reinterpret_cast<const u32x2 *>(rowp + (u64)((bidx + 1) * DB + i) * RW)[lane];
+                            D[(bidx + 1) & 1][i] = check_load(reinterpret_cast<const u32x2 *>(rowp + (u64)((bidx + 1) * DB + i) * RW) + lane);
                 }
 #pragma unroll
                 for (int i = 0; i < DB; i++) {

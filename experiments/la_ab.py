@@ -6,7 +6,7 @@ import basebandboard_amd as bbb
 if os.environ.get("EXP"): bbb._lib.select_build("experiments")
 N = 1_000_000_000
 buf = torch.empty(N, dtype=torch.int8, device="cuda")
-for m in (1, 2, 1, 2, 4, 1, 2):
+for m in [int(x) for x in os.environ.get("MS", "1,2,1,2,4,1,2").split(",")]:
     u = bbb.LUTOPT.shipped(256); u.set_staged(True, look_ahead=m if m > 1 else False)
     g = bbb.CLTGRNG(u)
     first = lambda s: 16 + s * N
