@@ -128,6 +128,10 @@ int tx_waveform_launch(const int16_t *coeffs, const uint64_t *d_bits, int64_t m0
 // bit j = decide(sample[phase + j*stride]); lane l of a wave takes bit 64w + l and one wave-wide
 // ballot packs the word (LSB first) -- the layout bbb_prbs_check reads.
 // ---------------------------------------------------------------------------------------------
+// Two forms.  Strides 1, 2, 4: a lane reads 8 consecutive samples with ONE 16-byte load (non-temporal: every sample is read
+// once; a wave's load covers 1 KiB), decides its 8 / stride of them, and the `stride` lanes of an output byte OR their
+// pieces together (one or two cross-lane moves); little-endian u64 words are those bytes in order.  Any other stride: lane l of a wave takes bit 64w + l (one
+// 2-byte load each; with stride 8 a wave touches 8 lines per load) and a wave-wide ballot packs the word.
 __global__ void __launch_bounds__(256)
 rx_slice_kernel(const int16_t *__restrict samples, unsigned long long nbits, unsigned long long stride,
                 unsigned long long phase, int strict, unsigned long long *__restrict out) {
@@ -135,7 +139,19 @@ rx_slice_kernel(const int16_t *__restrict samples, unsigned long long nbits, uns
     const unsigned long long nwords = (nbits + 63) / 64;
     const unsigned long long wave0 = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const unsigned long long nwaves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
-    for (unsigned long long w = wave0; w < nwords; w += nwaves) {
+    unsigned long long w = wave0;
+    // four words per trip while they are all whole: four independent loads in flight per lane
+    for (; w + 3 * nwaves < nwords && (w + 3 * nwaves) * 64 + 64 <= nbits; w += 4 * nwaves) {
+        int v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = __builtin_nontemporal_load(samples + phase + ((w + u * nwaves) * 64 + lane) * stride);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const unsigned long long word = __ballot(strict ? v[u] > 0 : v[u] >= 0);
+            if (lane == 0) out[w + u * nwaves] = word;
+        }
+    }
+    for (; w < nwords; w += nwaves) {
         const unsigned long long j = w * 64 + lane;
         int decision = 0;
         if (j < nbits) {
@@ -147,10 +163,62 @@ rx_slice_kernel(const int16_t *__restrict samples, unsigned long long nbits, uns
     }
 }
 
+typedef uint32_t rxu32x4 __attribute__((ext_vector_type(4)));
+template <int S>
+__global__ void __launch_bounds__(256)
+rx_slice_bytes_kernel(const int16_t *__restrict samples, unsigned long long nbits, unsigned long long phase, int strict,
+                      uint8_t *__restrict out, unsigned long long nbytes) {
+    constexpr int PB = 8 / S;                                       // decisions per lane: 8, 4 or 2
+    const unsigned long long t0 = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long nthreads = (unsigned long long)gridDim.x * blockDim.x;
+    const unsigned long long nchunks = nbytes * S;                  // a multiple of S: the S lanes of a byte stay together
+    for (unsigned long long ch = t0; ch < nchunks; ch += nthreads) {
+        const unsigned long long bit0 = ch * PB;
+        unsigned piece = 0;
+        if (bit0 + PB < nbits) {
+            // the lane's 8 samples all exist: the sample of bit bit0 + PB lies behind them
+            typedef rxu32x4 __attribute__((aligned(2))) chunk_t;
+            const rxu32x4 c = __builtin_nontemporal_load(reinterpret_cast<const chunk_t *>(samples + phase + ch * 8));
+#pragma unroll
+            for (int e = 0; e < PB; e++) {
+                const int idx = e * S;
+                const uint32_t dw = c[idx / 2];
+                const int v = (int)(int16_t)((idx & 1) ? (dw >> 16) : (dw & 0xffffu));
+                piece |= (unsigned)(strict ? v > 0 : v >= 0) << e;
+            }
+        } else {
+            for (int e = 0; e < PB; e++) {
+                if (bit0 + e >= nbits) break;
+                const int v = samples[phase + (bit0 + e) * S];
+                piece |= (unsigned)(strict ? v > 0 : v >= 0) << e;
+            }
+        }
+        unsigned byte = piece << ((unsigned)(ch % S) * PB);
+        if (S >= 2) byte |= (unsigned)__shfl_xor((int)byte, 1, 64);
+        if (S >= 4) byte |= (unsigned)__shfl_xor((int)byte, 2, 64);
+        if (ch % S == 0) out[ch / S] = (uint8_t)byte;
+    }
+}
+
 int rx_slice_launch(const int16_t *d_samples, uint64_t nbits, uint64_t stride, uint64_t phase, int strict,
                     uint64_t *d_out, hipStream_t st) {
     if (nbits == 0) return BBB_OK;
     const uint64_t nwords = (nbits + 63) / 64;
+    if (stride == 1 || stride == 2 || stride == 4) {
+        const uint64_t nbytes = nwords * 8;                 // whole words: the bytes behind the last bit are written as 0
+        uint64_t blocks = (nbytes * stride + 255) / 256;    // a thread per 8 samples
+        if (blocks > 256 * 64) blocks = 256 * 64;
+        uint8_t *ob = reinterpret_cast<uint8_t *>(d_out);
+        const dim3 grid((unsigned)blocks), block(256);
+        if (stride == 1)
+            hipLaunchKernelGGL(rx_slice_bytes_kernel<1>, grid, block, 0, st, d_samples, (unsigned long long)nbits, (unsigned long long)phase, strict, ob, (unsigned long long)nbytes);
+        else if (stride == 2)
+            hipLaunchKernelGGL(rx_slice_bytes_kernel<2>, grid, block, 0, st, d_samples, (unsigned long long)nbits, (unsigned long long)phase, strict, ob, (unsigned long long)nbytes);
+        else
+            hipLaunchKernelGGL(rx_slice_bytes_kernel<4>, grid, block, 0, st, d_samples, (unsigned long long)nbits, (unsigned long long)phase, strict, ob, (unsigned long long)nbytes);
+        BBB_HIP(hipGetLastError());
+        return BBB_OK;
+    }
     uint64_t blocks = (nwords + 3) / 4;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(rx_slice_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_samples, (unsigned long long)nbits,

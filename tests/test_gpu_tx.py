@@ -118,6 +118,27 @@ def test_rx_slice_matches_oracle(gpu, oracle):
         gpu.RX(31, 12, 0)
 
 
+@pytest.mark.parametrize("stride", [1, 2, 3, 4, 8, 16])
+def test_rx_slice_sizes_and_phases(gpu, oracle, stride):
+    """Every slicer form (byte per lane for strides 1, 2, 4; ballot per word otherwise; their unrolled and tail paths) at
+    ragged sizes: bit counts around byte and word boundaries, odd phases (unaligned 16-byte loads), both thresholds, and
+    zeroed padding behind the last bit."""
+    rng = np.random.default_rng(stride)
+    big = rng.integers(-3, 4, size=1_200_000).astype(np.int16)          # many zeros: >= and > differ often
+    for n in (1, 2, 7, 8, 9, 63, 64, 65, 127, 129, 511, 513, 4096, 70_001, 1_200_000):
+        for first, delay in ((0, 0), (1, 0), (5, 1), (16, stride if stride <= 16 else 0), (1001, stride - 1)):
+            x = big[:n]
+            xt = torch.from_numpy(x.copy()).cuda()
+            for strict in (False, True):
+                rx = gpu.RX(31, 16, delay)
+                bits, nbits = rx.slice(xt, first_sample=first, stride=stride, strict=strict)
+                exp = oracle.rx_slice(x[first:], stride, delay, strict) if first < n else np.zeros(0, np.uint8)
+                assert nbits == len(exp), (n, first, delay)
+                raw = np.unpackbits(bits.cpu().numpy().view(np.uint8), bitorder="little")
+                assert np.array_equal(raw[:nbits], exp), (n, first, delay, strict)
+                assert not raw[nbits:].any()
+
+
 def test_tx_rx_loopback(gpu, oracle, golden_shaper):
     """TX -> slicer at the pulse centre -> PRBS checker.  Noise-free: the decided bits ARE the PRBS
     (0 errors); with noise the count equals the oracle's count over its own TX samples."""
