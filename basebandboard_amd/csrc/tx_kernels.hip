@@ -23,6 +23,93 @@ struct Coeffs64 { int16_t c[64]; };
 
 __device__ __forceinline__ int wrap12_dev(int v) { return (int)((unsigned)v << 20) >> 20; }
 
+// Q bit j = data bit M0-7+j, j = 0..9 (bits before the first one are 0: the reset shift register).
+// `bits` holds data bits m0 .. m0+navail-1 and nothing else may be read: a window reaching past them
+// (only bits that no sample of the request needs) takes the bit-by-bit path, which reads 0 there
+__device__ __forceinline__ unsigned data_window10(const unsigned long long *__restrict bits, long long m0, unsigned long long navail,
+                                                  int source, long long M0) {
+    unsigned Q = 0;
+    if (source == 0 && M0 - 7 >= m0 && (unsigned long long)(M0 - 7 - m0) + 10 <= navail) {
+        const unsigned long long rel = (unsigned long long)(M0 - 7 - m0);
+        const unsigned sh = (unsigned)(rel & 63);
+        unsigned long long w = bits[rel >> 6] >> sh;
+        if (sh > 54) w |= bits[(rel >> 6) + 1] << (64 - sh);
+        Q = (unsigned)w & 0x3ffu;
+    } else {
+#pragma unroll 1
+        for (int j = 0; j < 10; j++) {
+            const long long m = M0 - 7 + j;
+            unsigned b = 0;
+            if (m >= 0) {
+                if (source == 0) {
+                    const unsigned long long rel = (unsigned long long)(m - m0);
+                    if (m >= m0 && rel < navail) b = (unsigned)((bits[rel >> 6] >> (rel & 63)) & 1ull);
+                } else {
+                    b = (m & 255) == 0;                                  // Pulser: counter == 0 (tx.py:28-30)
+                }
+            }
+            Q |= b << j;
+        }
+    }
+    return Q;
+}
+
+// The shaper alone (noise off, bits on: PRBSShaper.x, bitshaper.py:25-86): nothing but table rows.  A thread's 8 samples
+// start at n = first_sample + 8 g, so c0 = (n - 17) & 7 is the same for every thread: sample e has phase (c0 + e) & 7 and
+// window shift (c0 + e) >> 3 in {0, 1}.  TT[q][j] = T[(c0 + j) & 7][q] gives the 8 phases of one window by ONE 16-byte
+// read; the rows of the two shifts and a per-dword select with uniform masks give the 8 samples as 4 packed pairs (the
+// scheme of the fused kernel, awgn_kernels.hip).  The 4 KiB table is built once per call by shaper_table_kernel and read
+// copied into LDS by every block (one 16-byte load per thread; gathering the rows straight from global memory was slower:
+// 3.0 against 3.7 TB/s), so the grid can be what streams best -- many short blocks, four 16-byte stores per thread, a
+// wave's store covering 1 KiB (profiles/r02_ubench4_stream_patterns.log: every further store of a thread costs rate).
+typedef uint32_t shu32x4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256)
+shaper_table_kernel(Coeffs64 cf, unsigned c0, uint16_t *__restrict TT) {
+    for (int e = threadIdx.x; e < 256 * 8; e += blockDim.x) {
+        const int q = e >> 3, j = e & 7, ph = (int)((c0 + (unsigned)j) & 7u);
+        int sum = 0;
+#pragma unroll
+        for (int idx = 0; idx < 8; idx++) {
+            const int c = cf.c[8 * idx + ph];
+            sum += ((q >> (7 - idx)) & 1) ? c : -c;
+        }
+        TT[e] = (uint16_t)(wrap12_dev(sum) & 0xffff);
+    }
+}
+
+constexpr int kShaperIters = 4;       // 16-byte stores per thread: few (every further store of a thread costs rate), but
+                                      // enough to pay for the block's copy of the table
+__global__ void __launch_bounds__(256)
+shaper_only_kernel(const uint16_t *__restrict TTg, const unsigned long long *__restrict bits, long long m0, unsigned long long navail,
+                   int source, unsigned c0, unsigned long long first_sample, unsigned long long nsamples, int16_t *__restrict out) {
+    __shared__ __attribute__((aligned(16))) uint16_t TT[256 * 8];
+    reinterpret_cast<shu32x4 *>(TT)[threadIdx.x] = reinterpret_cast<const shu32x4 *>(TTg)[threadIdx.x];      // 256 x 16 B = the table
+    uint32_t sel[4];
+#pragma unroll
+    for (unsigned d = 0; d < 4; d++)
+        sel[d] = (c0 + 2u * d < 8u ? 0x0000ffffu : 0u) | (c0 + 2u * d + 1u < 8u ? 0xffff0000u : 0u);
+    __syncthreads();
+    const char *tt = reinterpret_cast<const char *>(TT);
+#pragma unroll
+    for (int it = 0; it < kShaperIters; it++) {
+        const unsigned long long g = ((unsigned long long)blockIdx.x * kShaperIters + it) * 256 + threadIdx.x;
+        const unsigned long long base = g * 8;
+        if (base >= nsamples) break;
+        const long long M0 = ((long long)(first_sample + base) - 17) >> 3;                 // floor
+        const unsigned Q = data_window10(bits, m0, navail, source, M0);
+        const shu32x4 A = *reinterpret_cast<const shu32x4 *>(tt + ((Q & 255u) << 4));
+        const shu32x4 B = *reinterpret_cast<const shu32x4 *>(tt + (((Q >> 1) & 255u) << 4));
+        shu32x4 v;
+#pragma unroll
+        for (unsigned d = 0; d < 4; d++) v[d] = (A[d] & sel[d]) | (B[d] & ~sel[d]);       // samples 2d, 2d+1
+        if (base + 8 <= nsamples) {
+            *reinterpret_cast<shu32x4 *>(out + base) = v;
+        } else {
+            for (unsigned e = 0; base + e < nsamples; e++) out[base + e] = (int16_t)((e & 1) ? (v[e >> 1] >> 16) : (v[e >> 1] & 0xffffu));
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256)
 tx_waveform_kernel(Coeffs64 cf, const unsigned long long *__restrict bits, long long m0, unsigned long long navail, int source,
                    const int8_t *__restrict noise, int noise_var, int bit_en, int noise_en,
@@ -47,32 +134,7 @@ tx_waveform_kernel(Coeffs64 cf, const unsigned long long *__restrict bits, long 
         const unsigned long long base = g * 16;
         const long long np0 = (long long)(first_sample + base) - 17;        // n - 17 of the first sample
         const long long M0 = np0 >> 3;                                      // floor
-        // Q bit j = data bit M0-7+j, j = 0..9 (bits before the first one are 0: the reset shift register)
-        unsigned Q = 0;
-        // `bits` holds data bits m0 .. m0+navail-1 and nothing else may be read: a window reaching past them
-        // (only bits that no sample of the request needs) takes the bit-by-bit path, which reads 0 there
-        if (source == 0 && M0 - 7 >= m0 && (unsigned long long)(M0 - 7 - m0) + 10 <= navail) {
-            const unsigned long long rel = (unsigned long long)(M0 - 7 - m0);
-            const unsigned sh = (unsigned)(rel & 63);
-            unsigned long long w = bits[rel >> 6] >> sh;
-            if (sh > 54) w |= bits[(rel >> 6) + 1] << (64 - sh);
-            Q = (unsigned)w & 0x3ffu;
-        } else {
-#pragma unroll 1
-            for (int j = 0; j < 10; j++) {
-                const long long m = M0 - 7 + j;
-                unsigned b = 0;
-                if (m >= 0) {
-                    if (source == 0) {
-                        const unsigned long long rel = (unsigned long long)(m - m0);
-                        if (m >= m0 && rel < navail) b = (unsigned)((bits[rel >> 6] >> (rel & 63)) & 1ull);
-                    } else {
-                        b = (m & 255) == 0;                                  // Pulser: counter == 0 (tx.py:28-30)
-                    }
-                }
-                Q |= b << j;
-            }
-        }
+        const unsigned Q = data_window10(bits, m0, navail, source, M0);
         const bool full = base + 16 <= nsamples;
         typedef unsigned long long u2 __attribute__((ext_vector_type(2)));
         u2 nz = {0, 0};
@@ -112,6 +174,22 @@ int tx_waveform_launch(const int16_t *coeffs, const uint64_t *d_bits, int64_t m0
     const uint64_t groups = (nsamples + 15) / 16;
     uint64_t blocks = (groups + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
+    if (!noise_en && bit_en) {
+        const uint64_t groups8 = (nsamples + 7) / 8;
+        const uint64_t nblk = (groups8 + 256 * kShaperIters - 1) / (256 * kShaperIters);
+        if (nblk > 0x7fffffffull) return fail(BBB_EINVAL, "nsamples too large for one call: split it");
+        uint16_t *d_tt = nullptr;
+        BBB_HIP(hipMallocAsync((void **)&d_tt, 256 * 8 * sizeof(uint16_t), st));
+        const unsigned c0 = (unsigned)(((int64_t)first_sample - 17) & 7);
+        hipLaunchKernelGGL(shaper_table_kernel, dim3(1), dim3(256), 0, st, cf, c0, d_tt);
+        hipLaunchKernelGGL(shaper_only_kernel, dim3((unsigned)nblk), dim3(256), 0, st, (const uint16_t *)d_tt,
+                           (const unsigned long long *)d_bits, (long long)m0, (unsigned long long)(d_bits ? navail : 0), source, c0,
+                           (unsigned long long)first_sample, (unsigned long long)nsamples, d_out);
+        const hipError_t e = hipGetLastError();
+        (void)hipFreeAsync(d_tt, st);
+        if (e != hipSuccess) return fail(BBB_EHIP, hipGetErrorString(e));
+        return BBB_OK;
+    }
     hipLaunchKernelGGL(tx_waveform_kernel, dim3((unsigned)blocks), dim3(256), 0, st, cf,
                        (const unsigned long long *)d_bits, (long long)m0, (unsigned long long)(d_bits ? navail : 0), source, d_noise, noise_var, bit_en, noise_en,
                        (unsigned long long)first_sample, (unsigned long long)nsamples, d_out);

@@ -448,6 +448,23 @@ def main():
         r = hbm("awgn256_kernel<true, true> + unstage_kernel<32> (whole bbb_tx_fill_i16 call)", 2.0 * ntx, tx_ms, "2 B per sample delivered (6 B of HBM traffic: staging write, mover read + write)")
         r["true_bound"] = "integer VALU of the noise generator at one wave per SIMD, slowed by its guests (mover, seeding, data bits) on the same CUs"
         other.append(r)
+        # PRBSShaper.x alone (noise off): PRBS fill + table rows, 2 B per sample written
+        txs = bbb.TX(31, 1, 0, 16, 0, 8, device=local_rank)
+        sbuf = torch.empty(1 << 30, dtype=torch.int16, device=dev)
+        for i in range(2):
+            txs.generate(1 << 30, first_sample=i << 30, out=sbuf)
+        torch.cuda.synchronize()
+        t0e, t1e = ev(), ev()
+        t0e.record()
+        for i in range(2, 8):
+            txs.generate(1 << 30, first_sample=i << 30, out=sbuf)
+        t1e.record()
+        torch.cuda.synchronize()
+        sh_ms = t0e.elapsed_time(t1e) / 6
+        del sbuf, txs
+        extra["shaper_only"] = {"samples": 1 << 30, "gsample_s": round((1 << 30) / sh_ms / 1e6, 1), "ms_per_call": round(sh_ms, 4)}
+        other.append(hbm("prbs_stream_kernel + shaper_table_kernel + shaper_only_kernel (whole call, noise off)", 2.0 * (1 << 30), sh_ms,
+                         "2 B per sample written"))
         # the reference's matrix search (software/rnghunt) on the GPU: candidates per second for k = 256
         from basebandboard_amd import gf2 as _gf2
         _gf2.search(256, seed=rank + 1, first=0, count=256, device=local_rank)
