@@ -88,6 +88,7 @@ struct bbb_lutopt {
     // kernel of call s still reads its own -- two buffers, each with the event of its last reader
     uint32_t *d_fbits[2] = {nullptr, nullptr}; size_t fbits_cap[2] = {0, 0};
     hipEvent_t fbits_read[2] = {nullptr, nullptr}, fbits_ready = nullptr;
+    hipEvent_t ber_fork = nullptr, ber_join = nullptr;       // ber_run: PRBS seeding on the side stream beside the generator's
     bool fbits_pending[2] = {false, false};
     int fbits_slot = 0;
     // which stream position the planes in d_planes currently describe
@@ -586,8 +587,8 @@ int ber_run(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, unsigned long lo
         if (L >= (1ull << 27)) return fail(BBB_EINVAL, "nbits too large for one trial (about 2^47): split it with first_bit");
         for (int j = 0; j < n; j++) { td[(size_t)(i + j)].L = (uint32_t)L; td[(size_t)(i + j)].G = G; td[(size_t)(i + j)].nbits = c.nbits; }
         int rc;
-        if ((rc = prepare_planes(h, c.warmup + c.first_bit, L, G, nlanes))) return rc;
-        // PRBS start states: the same doubling machinery with the k x k LFSR companion matrix
+        // PRBS start states: the same doubling machinery with the k x k LFSR companion matrix.  Queued on the side stream,
+        // so that its chain of small launches runs beside the generator's (both are latency, not work)
         JumpPlan *pp;
         if ((rc = get_prbs_plan(h, c.prbs_k, L, &pp))) return rc;
         if ((rc = grow(&h->d_pstates, &h->pstates_cap, (size_t)G))) return rc;
@@ -597,7 +598,15 @@ int ber_run(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, unsigned long lo
         uint64_t ps64[8] = {ps0};
         uint32_t ps16[256];
         first16(*pp, ps64, ps16);
-        if ((rc = awgn_seed_launch(c.prbs_k, pp->d_cols, ps16, G, h->d_pstates, G, nlanes, h->d_pplanes, h->cs))) return rc;
+        if (!h->side) BBB_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        for (hipEvent_t *e : {&h->ber_fork, &h->ber_join})
+            if (!*e) BBB_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        BBB_HIP(hipEventRecord(h->ber_fork, h->cs));                  // (the previous trial's kernel may still read d_pplanes)
+        BBB_HIP(hipStreamWaitEvent(h->side, h->ber_fork, 0));
+        if ((rc = awgn_seed_launch(c.prbs_k, pp->d_cols, ps16, G, h->d_pstates, G, nlanes, h->d_pplanes, h->side))) return rc;
+        BBB_HIP(hipEventRecord(h->ber_join, h->side));
+        if ((rc = prepare_planes(h, c.warmup + c.first_bit, L, G, nlanes))) return rc;
+        BBB_HIP(hipStreamWaitEvent(h->cs, h->ber_join, 0));
         if (h->specialised) {
             if ((rc = ber256_launch(h->d_planes, h->d_pplanes, &td[(size_t)i], n, nlanes, counters_dev + 2 * (size_t)i, h->cs))) return rc;
         } else {
@@ -742,7 +751,7 @@ int bbb_lutopt_destroy(bbb_lutopt *h) {
                     (void *)h->d_txbits, (void *)h->d_fbits[0], (void *)h->d_fbits[1], (void *)h->pf.d_states, (void *)h->pf.d_planes})
         (void)hipFree(p);
     for (hipEvent_t e : {h->pf.seeded, h->pf.last_read, h->cur_last_read, h->handover, h->stage_free[0], h->stage_free[1],
-                         h->stage_arith[0], h->stage_arith[1], h->ev_user, h->fbits_read[0], h->fbits_read[1], h->fbits_ready})
+                         h->stage_arith[0], h->stage_arith[1], h->ev_user, h->fbits_read[0], h->fbits_read[1], h->fbits_ready, h->ber_fork, h->ber_join})
         if (e) (void)hipEventDestroy(e);
     for (hipStream_t st : {h->side, h->xs, h->ys})
         if (st) (void)hipStreamDestroy(st);
