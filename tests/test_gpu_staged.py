@@ -252,3 +252,25 @@ def test_tx_look_ahead_equals_one_kernel_form(gpu, oracle, golden_shaper, fills)
     exp = oracle.tx(m, 1, golden_shaper["rcf_coeffs"][16], 31, 100_000, first_sample=3 * n, noise_var=8, warmup=16)
     assert np.array_equal(outs[3][:100_000].cpu().numpy(), exp)
     assert np.array_equal(a[:100_000].cpu().numpy(), m.awgn(1, 16, 100_000, fast=True))
+
+
+def test_look_ahead_at_the_bench_size(gpu):
+    """BASELINE configs[1] as bench.py runs it: 1e9 samples per step, look-ahead 2, prefetch hints, one output buffer.
+    Every step's whole buffer against the one-kernel form (which tests/test_gpu_awgn.py holds to the oracle byte for
+    byte at this size)."""
+    n = 1_000_000_000
+    u, g = _look_ahead_gen(gpu, fills=2)
+    d = gpu.CLTGRNG(gpu.LUTOPT.shipped(256))
+    buf = torch.empty(n, dtype=torch.int8, device="cuda")
+    ref = torch.empty(n, dtype=torch.int8, device="cuda")
+    first = lambda s: 16 + s * n
+    for s in range(5):
+        g.generate(n, first_step=first(s), out=buf)
+        g.prefetch(n, first_step=first(s + 1))
+        d.generate(n, first_step=first(s), out=ref)
+        assert torch.equal(buf, ref), s
+    # per-rank stretches of bench.py: a position 2^48 steps in
+    far = (3 << 48) + 16
+    g.generate(n, first_step=far, out=buf)
+    d.generate(n, first_step=far, out=ref)
+    assert torch.equal(buf, ref)
