@@ -219,11 +219,12 @@ def main():
     # the two-kernel form of the stream (bbb_lutopt_set_staged): the sample kernel writes full lines into a staging
     # buffer, a piece mover puts them in place beside the NEXT step's arithmetic; same bytes (tests/test_gpu_staged.py).
     # BENCH_ONE_KERNEL=1 times the one-kernel form instead (it is also reported in `extra`).
-    # Look-ahead (level 2 of the same switch): a step's sample kernel produces its own 1e9 samples AND the next step's
-    # (one seeding, one launch per two steps); the next step is then only its piece mover.  Needs the rank's steps to
-    # be consecutive in the stream, hence the per-rank sub-streams below.  BENCH_NO_LOOK_AHEAD=1 turns it off.
+    # Look-ahead (levels 2..8 of the same switch; BENCH_LOOK_AHEAD=m turns it on): a step's sample kernel also produces the
+    # next m - 1 steps' samples (one seeding, one launch per m steps), which are then only their piece movers.  Off by
+    # default: same-box A/B runs put m = 2 between -1 % and +3.5 % of m = 1, i.e. inside the box-to-box noise (DESIGN.md
+    # 3.3b), and with it a --steps that is no multiple of m would time work whose output is never asked for.
     staged = not os.environ.get("BENCH_ONE_KERNEL")
-    look_ahead = int(os.environ.get("BENCH_LOOK_AHEAD", "2")) if staged and not os.environ.get("BENCH_NO_LOOK_AHEAD") else 0
+    look_ahead = int(os.environ.get("BENCH_LOOK_AHEAD", "0")) if staged else 0
     if look_ahead < 2:
         look_ahead = 0
     u.set_staged(staged, look_ahead=look_ahead)

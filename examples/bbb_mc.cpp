@@ -4,8 +4,8 @@
 //
 //   bbb_mc [--matrix FILE] [--init HEX] [--gpus N] [--json 1]
 //          BER sweep:   [--prbs 31] [--bits 1e9] [--nv 8] [--ebn0 A:B:STEP] [--seeds N] [--shard bits|seeds|trials]
-//          AWGN fill:   --nsamples 1e9 [--steps 5] [--staged 0|1|m]   (bbb_lutopt_set_staged: 1 = the two-kernel form,
-//                       m = 2..8 (default 2) = one sample kernel per m consecutive steps)
+//          AWGN fill:   --nsamples 1e9 [--steps 5] [--staged 0|1|m]   (bbb_lutopt_set_staged: 1 = the two-kernel form, the
+//                       default; m = 2..8 = one sample kernel per m consecutive steps)
 //          loopback:    --loopback BITS
 //
 // --matrix   the reference's 0/1 text format (software/rnghunt/matrices/256); default: the shipped n256 matrix
@@ -118,7 +118,7 @@ static void fill_worker(const Matrix &m, unsigned long long init0, int dev, int 
 
 int main(int argc, char **argv) {
     std::string matrix, shard = "bits";
-    int k = 31, nv = 8, seeds = 1, gpus = 1, json = 0, steps = 5, multi = 0, staged = 2;
+    int k = 31, nv = 8, seeds = 1, gpus = 1, json = 0, steps = 5, multi = 0, staged = 1;
     unsigned long long init0 = 1;
     double bits = 1e9, from = 0, to = 10, step = 1, loopback = 0, nsamples = 0;
     for (int i = 1; i + 1 < argc; i += 2) {

@@ -234,7 +234,7 @@ def test_cli_json_multi_and_awgn_modes(gpu, oracle):
     a = json.loads(r.stdout.strip().splitlines()[-1])
     assert a["mode"] == "awgn_fill" and a["gsample_s"] > 0 and 0 < a["hbm_roofline_frac"] < 1
     assert a["head"] == m.awgn(1, 16, 64, fast=True).tolist() and a["samples_per_launch"] == 3_000_000
-    # a size at which the staged form and its look-ahead apply (default --staged 2; 1 and 0 for the plainer forms)
+    # a size at which the staged form (the default) and its look-ahead (--staged 2) apply; 0 = the one-kernel form
     nbig = (1 << 24) + 16
     for staged, per in ((2, 2 * nbig), (1, nbig), (0, nbig)):
         r = subprocess.run([str(exe), "--nsamples", str(nbig), "--steps", "4", "--staged", str(staged), "--json", "1"], cwd=str(ROOT),
