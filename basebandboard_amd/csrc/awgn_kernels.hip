@@ -452,7 +452,8 @@ awgn256_kernel(const uint32_t *__restrict planes, void *__restrict dst_, unsigne
 // Residency: this kernel runs beside the NEXT fill's sample kernel, whose waves need 416 of a SIMD's 512 registers and
 // 32 of a CU's 160 KiB of LDS each and must ALL be resident at once (one generation, static partition).  A grid of many
 // small blocks would keep refilling every freed slot and starve those big waves (measured: the two kernels then run one
-// after the other).  So the mover is persistent and narrow: one block of four waves per CU (<= 96 registers per lane, and
+// after the other).  So the mover is persistent and narrow: one block per CU -- two waves for the int8 stream, four for the int16 TX stream:
+// see unstage_launch -- (<= 96 registers per lane, and
 // an unused 32 KiB of dynamic LDS so that no second block fits beside four sample-kernel waves), each wave looping over
 // its share of the generator groups with 16 loads of 16 bytes in flight per lane.
 // the mover's accesses (experiments build: -DBBB_UNSTAGE_NT_LOAD / -DBBB_UNSTAGE_NT_STORE make them non-temporal)
@@ -471,10 +472,11 @@ __device__ __forceinline__ void mover_store(char *p, const u32x4 &v) {
 #endif
 }
 
+constexpr unsigned kUnstagePause = 0;      // s_sleep(4) repeats after every tile of a trip (experiments: BBB_UNSTAGE_PAUSE)
 template <int PIECE>
 __global__ void __launch_bounds__(256, 5)
 unstage_kernel(const char *__restrict stg, char *__restrict dst_, unsigned long long win_lo, unsigned long long nbytes_,
-               unsigned Lb, unsigned long long G, unsigned long long Gpad, unsigned rounds) {
+               unsigned Lb, unsigned long long G, unsigned long long Gpad, unsigned rounds, unsigned pause) {
     // the staged stream may be longer than what this call delivers (look-ahead: two fills' worth per sample kernel):
     // bytes [win_lo, win_lo + nbytes_) of it go to dst_[0 .. nbytes_).  Only generator groups that touch the window.
     char *const dst = dst_ - win_lo;                       // indexed by stream offset below, within [win_lo, nbytes)
@@ -517,6 +519,7 @@ unstage_kernel(const char *__restrict stg, char *__restrict dst_, unsigned long 
                     for (unsigned t = 0; t < 4; t++) mover_store(out0 + k * gstride_dst + t * dstride, v[k][t]);
                 src0 += 4 * sstride;
                 out0 += 4 * dstride;
+                for (unsigned z = 0; z < pause; z++) __builtin_amdgcn_s_sleep(4);      // 256 cycles each
             }
             for (; r < rounds; r += RT) {
                 u32x4 v[NG];
@@ -561,12 +564,17 @@ int unstage_launch(const void *stg, void *dst, uint64_t win_lo, uint64_t nbytes,
     if (env_knob("BBB_UNSTAGE_BLOCKS", 0) > 0) blocks = (uint64_t)env_knob("BBB_UNSTAGE_BLOCKS", 0);
     if (blocks > (ntrips + 3) / 4) blocks = (ntrips + 3) / 4;
     const size_t lds = static_cast<size_t>(env_knob("BBB_UNSTAGE_LDS_KB", 0)) * 1024;
+    // two waves per CU for the int8 stream: with four the mover finishes sooner (0.45 against ~0.8 ms per 1e9) but costs the
+    // sample kernel more than it is worth -- same box, alternating: 767-773 Gsample/s with 128 threads, 744-757 with 192,
+    // 731-739 with 256, 650 with 64 (the mover then takes longer than the fill it runs beside)
+    const unsigned threads = (unsigned)(piece == 16 ? env_knob("BBB_UNSTAGE_THREADS", 128) : env_knob("BBB_UNSTAGE_THREADS32", 256));
+    const unsigned pause = (unsigned)env_knob("BBB_UNSTAGE_PAUSE", kUnstagePause);
     if (piece == 16)
-        hipLaunchKernelGGL(unstage_kernel<16>, dim3((unsigned)blocks), dim3(256), lds, st, (const char *)stg, (char *)dst,
-                           (unsigned long long)win_lo, (unsigned long long)nbytes, Lb, (unsigned long long)G, (unsigned long long)Gpad, rounds);
+        hipLaunchKernelGGL(unstage_kernel<16>, dim3((unsigned)blocks), dim3(threads), lds, st, (const char *)stg, (char *)dst,
+                           (unsigned long long)win_lo, (unsigned long long)nbytes, Lb, (unsigned long long)G, (unsigned long long)Gpad, rounds, pause);
     else
-        hipLaunchKernelGGL(unstage_kernel<32>, dim3((unsigned)blocks), dim3(256), lds, st, (const char *)stg, (char *)dst,
-                           (unsigned long long)win_lo, (unsigned long long)nbytes, Lb, (unsigned long long)G, (unsigned long long)Gpad, rounds);
+        hipLaunchKernelGGL(unstage_kernel<32>, dim3((unsigned)blocks), dim3(threads), lds, st, (const char *)stg, (char *)dst,
+                           (unsigned long long)win_lo, (unsigned long long)nbytes, Lb, (unsigned long long)G, (unsigned long long)Gpad, rounds, pause);
     BBB_HIP(hipGetLastError());
     return BBB_OK;
 }
