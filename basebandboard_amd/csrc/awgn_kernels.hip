@@ -365,10 +365,12 @@ awgn256_kernel(const uint32_t *__restrict planes, void *__restrict dst_, unsigne
                     int8_t *dst = (int8_t *)dst_;
                     const u32x4 v = {o[0][q], o[1][q], o[2][q], o[3][q]};
                     if (STAGED) {
-#if defined(BBB_EXPERIMENTS) && defined(BBB_STAGE_NT_STORE)
-                        __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(dst_) + slot);
-#else
+                        // non-temporal: written once, read once by the mover a fill later (same box, three alternations:
+                        // 775-783 Gsample/s against 761-773 with plain stores)
+#if defined(BBB_EXPERIMENTS) && defined(BBB_STAGE_PLAIN_STORE)
                         reinterpret_cast<u32x4 *>(dst_)[slot] = v;
+#else
+                        __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(dst_) + slot);
 #endif
                     } else if (FULL || off + 16 <= nsamples) {
                         *reinterpret_cast<u32x4 *>(dst + off) = v;
@@ -397,8 +399,13 @@ awgn256_kernel(const uint32_t *__restrict planes, void *__restrict dst_, unsigne
                     }
                     if (STAGED) {
                         const u32x4 lo = {x[0], x[1], x[2], x[3]}, hi = {x[4], x[5], x[6], x[7]};
+#if defined(BBB_EXPERIMENTS) && defined(BBB_STAGE_PLAIN_STORE)
                         reinterpret_cast<u32x4 *>(dst_)[2 * slot] = lo;
                         reinterpret_cast<u32x4 *>(dst_)[2 * slot + 1] = hi;
+#else
+                        __builtin_nontemporal_store(lo, reinterpret_cast<u32x4 *>(dst_) + 2 * slot);
+                        __builtin_nontemporal_store(hi, reinterpret_cast<u32x4 *>(dst_) + 2 * slot + 1);
+#endif
                     } else if (FULL || off + 16 <= nsamples) {
                         const u32x4 lo = {x[0], x[1], x[2], x[3]}, hi = {x[4], x[5], x[6], x[7]};
                         reinterpret_cast<u32x4 *>(dst + off)[0] = lo;
@@ -456,12 +463,13 @@ awgn256_kernel(const uint32_t *__restrict planes, void *__restrict dst_, unsigne
 // see unstage_launch -- (<= 96 registers per lane, and
 // an unused 32 KiB of dynamic LDS so that no second block fits beside four sample-kernel waves), each wave looping over
 // its share of the generator groups with 16 loads of 16 bytes in flight per lane.
-// the mover's accesses (experiments build: -DBBB_UNSTAGE_NT_LOAD / -DBBB_UNSTAGE_NT_STORE make them non-temporal)
+// the mover's accesses: loads non-temporal (the staging buffer is read exactly once; same box, three alternations: 777-787
+// Gsample/s against 768-780 with plain loads); experiments build: -DBBB_UNSTAGE_PLAIN_LOAD, -DBBB_UNSTAGE_NT_STORE
 __device__ __forceinline__ u32x4 mover_load(const char *p) {
-#if defined(BBB_EXPERIMENTS) && defined(BBB_UNSTAGE_NT_LOAD)
-    return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
-#else
+#if defined(BBB_EXPERIMENTS) && defined(BBB_UNSTAGE_PLAIN_LOAD)
     return *reinterpret_cast<const u32x4 *>(p);
+#else
+    return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
 #endif
 }
 __device__ __forceinline__ void mover_store(char *p, const u32x4 &v) {
