@@ -274,3 +274,53 @@ def test_look_ahead_at_the_bench_size(gpu):
     g.generate(n, first_step=far, out=buf)
     d.generate(n, first_step=far, out=ref)
     assert torch.equal(buf, ref)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_mix_of_calls_on_one_staged_handle(gpu, oracle, seed):
+    """Soak: a random sequence of noise fills (sequential and not, hinted and not, two output buffers and two caller
+    streams), TX fills, BER trials and level changes on ONE handle; every output equals what a fresh handle in the
+    one-kernel form produces.  Aimed at the stream / event plumbing between the arithmetic stream, the mover stream, the
+    seeding stream and the caller's."""
+    rng = np.random.default_rng(seed)
+    m = oracle.Lutopt(path=oracle.data_path(256))
+    x = gpu.TX(31, 1, 0, 16, 1, 8)
+    u = x.urng
+    g = gpu.CLTGRNG(u)
+    y = gpu.TX(31, 1, 0, 16, 1, 8)
+    d = gpu.CLTGRNG(y.urng)
+    side = torch.cuda.Stream()
+    bufs = [torch.empty(BIG + 8192, dtype=torch.int8, device="cuda") for _ in range(2)]
+    pos, checks = 16, []
+    u.set_staged(True, look_ahead=2)
+    for it in range(120):
+        op = rng.integers(0, 10)
+        n = BIG + 16 * int(rng.integers(0, 512))
+        if op < 5:                                          # the next stretch of the stream, usually hinted
+            out = bufs[it & 1][:n]
+            ctx = torch.cuda.stream(side) if rng.integers(0, 4) == 0 else torch.cuda.stream(torch.cuda.current_stream())
+            with ctx:
+                g.generate(n, first_step=pos, out=out)
+                snap = out.clone()
+            if rng.integers(0, 3):
+                g.prefetch(n, first_step=pos + n)
+            checks.append(("awgn", n, pos, snap))
+            pos += n
+        elif op == 5:                                       # somewhere else, odd size
+            n2 = n + int(rng.integers(1, 16))
+            p2 = int(rng.integers(0, 1 << 40))
+            checks.append(("awgn", n2, p2, g.generate(n2, first_step=p2)))
+        elif op == 6:
+            checks.append(("tx", n, pos, x.generate(n, first_sample=pos)))
+        elif op == 7:
+            t = gpu.Trial(nbits=200_000 + it, amp=90, noise_var=8, first_bit=it)
+            got = gpu.run_trials(u, [t])[0]
+            assert got == m.ber_trial(1, 31, 1, 90, 8, 16, it, 200_000 + it)
+        elif op == 8:
+            u.set_staged(True, look_ahead=int(rng.integers(1, 4)) if rng.integers(0, 2) else False)
+        else:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    for kind, n, p, got in checks:
+        ref = d.generate(n, first_step=p) if kind == "awgn" else y.generate(n, first_sample=p)
+        assert torch.equal(got, ref), (kind, n, p)
