@@ -399,6 +399,20 @@ int staged_fill(bbb_lutopt *h, void *dst, uint64_t nbytes, int piece, uint64_t L
     return queue_mover(h, slot, dst, 0, nbytes, piece, L, G, nlanes);
 }
 
+// the packed n512 kernel's partition: 16 generators per lane, 1024 per wave, segments in multiples of 8 samples (16-byte
+// stores); false if the segment length does not fit 32 bits
+bool partition512(const bbb_lutopt *h, uint64_t nsamples, uint64_t *L, uint64_t *G, unsigned *nlanes) {
+    const uint64_t gmax = (uint64_t)h->max_waves * 1024;
+    uint64_t l = (nsamples + gmax - 1) / gmax;
+    if (l < 64) l = 64;
+    l = (l + 7) / 8 * 8;
+    if (l > 0xffffff00ull) return false;
+    *L = l;
+    *G = (nsamples + l - 1) / l;
+    *nlanes = (unsigned)((*G + 1023) / 1024 * 64);
+    return true;
+}
+
 int awgn_fill(bbb_lutopt *h, void *dst, int elem_size, uint64_t nsamples, uint64_t first_step) {
     if (!h) return fail(BBB_EINVAL, "null handle");
     if (nsamples == 0) return BBB_OK;
@@ -411,26 +425,29 @@ int awgn_fill(bbb_lutopt *h, void *dst, int elem_size, uint64_t nsamples, uint64
     uint64_t L, G;
     unsigned nlanes;
     if (h->fast512 && elem_size == 2) {
-        // packed state, 16 generators per lane: 1024 per wave, segments in multiples of 8 samples (16-byte stores)
-        const uint64_t gmax = (uint64_t)h->max_waves * 1024;
-        L = (nsamples + gmax - 1) / gmax;
-        if (L < 64) L = 64;
-        L = (L + 7) / 8 * 8;
-        if (L > 0xffffff00ull) return fail(BBB_EINVAL, "nsamples too large for one call (segment length must fit 32 bits): split it");
-        G = (nsamples + L - 1) / L;
-        nlanes = (unsigned)((G + 1023) / 1024 * 64);
+        if (!partition512(h, nsamples, &L, &G, &nlanes))
+            return fail(BBB_EINVAL, "nsamples too large for one call (segment length must fit 32 bits): split it");
         int rc5 = begin_op(h, false);
         if (rc5) return rc5;
-        JumpPlan *plan;
-        if ((rc5 = get_plan(h, L, &plan))) return rc5;
-        if ((rc5 = grow(&h->d_states, &h->states_cap, (size_t)G * h->W32))) return rc5;
-        if ((rc5 = grow(&h->d_planes, &h->planes_cap, (size_t)2 * h->k * nlanes))) return rc5;
-        uint64_t s0[8];
-        h->pw->apply(first_step, h->init, s0);
-        uint32_t s16[256];
-        first16(*plan, s0, s16);
         h->planes_valid = false;                 // (another layout than the one prepare_planes caches)
-        if ((rc5 = awgn_seed_launch(h->k, plan->d_cols, s16, G, h->d_states, G, nlanes, h->d_planes, h->cs, 1))) return rc5;
+        if (h->pf.valid && h->pf.first == first_step && h->pf.L == L && h->pf.G == G) {
+            // announced (bbb_awgn_prefetch): the start states were seeded on the side stream -- swap them in
+            BBB_HIP(hipStreamWaitEvent(h->cs, h->pf.seeded, 0));
+            std::swap(h->d_states, h->pf.d_states); std::swap(h->states_cap, h->pf.states_cap);
+            std::swap(h->d_planes, h->pf.d_planes); std::swap(h->planes_cap, h->pf.planes_cap);
+            std::swap(h->cur_last_read, h->pf.last_read); std::swap(h->cur_read_pending, h->pf.read_pending);
+            h->pf.valid = false;
+        } else {
+            JumpPlan *plan;
+            if ((rc5 = get_plan(h, L, &plan))) return rc5;
+            if ((rc5 = grow(&h->d_states, &h->states_cap, (size_t)G * h->W32))) return rc5;
+            if ((rc5 = grow(&h->d_planes, &h->planes_cap, (size_t)2 * h->k * nlanes))) return rc5;
+            uint64_t s0[8];
+            h->pw->apply(first_step, h->init, s0);
+            uint32_t s16[256];
+            first16(*plan, s0, s16);
+            if ((rc5 = awgn_seed_launch(h->k, plan->d_cols, s16, G, h->d_states, G, nlanes, h->d_planes, h->cs, 1))) return rc5;
+        }
         if ((rc5 = awgn512p_fill_launch(h->d_planes, (int16_t *)dst, nsamples, (unsigned)L, G, nlanes, h->cs))) return rc5;
         return mark_planes_read(h);
     }
@@ -841,7 +858,7 @@ int bbb_lutopt_state_at(bbb_lutopt *h, uint64_t nsteps, uint64_t *state_words) {
 int bbb_awgn_prefetch(bbb_lutopt *h, uint64_t nsamples, uint64_t first_step) {
     if (!h) return fail(BBB_EINVAL, "null handle");
     if (h->device < 0) return fail(BBB_ENODEV, "host-only handle (device -1)");
-    if (!h->specialised || nsamples == 0) return BBB_OK;          // a hint: nothing to do for the table-driven path
+    if ((!h->specialised && !h->fast512) || nsamples == 0) return BBB_OK;          // a hint: nothing to do for the table-driven path
     BBB_HIP(hipSetDevice(h->device));
     uint64_t L, G;
     unsigned nlanes;
@@ -859,7 +876,11 @@ int bbb_awgn_prefetch(bbb_lutopt *h, uint64_t nsamples, uint64_t first_step) {
         const uint64_t cap = h->last_fill_tx ? (1ull << 31) : (1ull << 40);
         if (m * nsamples < cap && first_step + m * nsamples > first_step) nsamples *= m;
     }
-    partition(h, nsamples, 16, &L, &G, &nlanes);
+    if (h->fast512) {
+        if (!partition512(h, nsamples, &L, &G, &nlanes)) return BBB_OK;
+    } else {
+        partition(h, nsamples, 16, &L, &G, &nlanes);
+    }
     if (L > 0xffffff00ull) return BBB_OK;                         // the matching fill will refuse; nothing to prepare
     if (h->pf.valid && h->pf.first == first_step && h->pf.L == L && h->pf.G == G) return BBB_OK;      // already under way
     JumpPlan *plan;
@@ -891,7 +912,7 @@ int bbb_awgn_prefetch(bbb_lutopt *h, uint64_t nsamples, uint64_t first_step) {
     uint32_t s16[256];
     first16(*plan, s0, s16);
     // (this seeding runs beside the kernel of the fill before: the transmitter variant leaves LDS for 8 KiB pieces only)
-    if ((rc = awgn_seed_launch(h->k, plan->d_cols, s16, G, pf.d_states, G, nlanes, pf.d_planes, side, 0, h->last_fill_tx ? 4 : 2))) return rc;
+    if ((rc = awgn_seed_launch(h->k, plan->d_cols, s16, G, pf.d_states, G, nlanes, pf.d_planes, side, h->fast512 ? 1 : 0, h->last_fill_tx ? 4 : 2))) return rc;
     BBB_HIP(hipEventRecord(pf.seeded, side));
     pf.valid = true;
     pf.first = first_step; pf.L = L; pf.G = G; pf.nlanes = nlanes;

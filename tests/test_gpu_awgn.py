@@ -303,6 +303,31 @@ def test_n512_generated_kernel_matches_oracle(gpu, oracle, nsamples, first):
             assert np.array_equal(got[-5000:].astype(np.int64), texp)
 
 
+def test_n512_stream_with_prefetch_hints(gpu, oracle):
+    """bbb_awgn_prefetch on the n512 handle (start states of the next fill seeded on the side stream): right hints, a wrong
+    one and none; every fill equals an un-hinted handle's, and a stretch of a hinted fill the oracle."""
+    m = oracle.Lutopt(path=oracle.data_path(512))
+    u = gpu.LUTOPT.shipped(512, init=5)
+    g = gpu.CLTGRNG(u)
+    d = gpu.CLTGRNG(gpu.LUTOPT.shipped(512, init=5))
+    n = 3_000_008
+    outs = []
+    for s in range(6):
+        outs.append(g.generate(n, first_step=18 + s * n))
+        if s in (0, 1, 4):
+            g.prefetch(n, first_step=18 + (s + 1) * n)
+        elif s == 2:
+            g.prefetch(n, first_step=99)                    # wrong
+    outs.append(g.generate(n + 8, first_step=7))
+    torch.cuda.synchronize()
+    for s, o in enumerate(outs[:6]):
+        assert torch.equal(o, d.generate(n, first_step=18 + s * n)), s
+    assert torch.equal(outs[6], d.generate(n + 8, first_step=7))
+    st = m.states(u.state_at(18 + 2 * n), 0, 10_000)
+    exp = ((m.clt_tree_bulk(st).astype(np.int64) + 256) % 512) - 256
+    assert np.array_equal(outs[2][:10_000].cpu().numpy().astype(np.int64), exp)
+
+
 def test_n512_rate_and_moments(gpu):
     """2^28 samples: variance 2^(9-2) = 128, mean 0 (rng.py:63-65); and the generated kernel is an order of magnitude
     faster than the table-driven one it replaces (~6 Gsample/s)."""
