@@ -171,18 +171,32 @@ __device__ __forceinline__ bool det_equal(const DetState &a, const DetState &b) 
 typedef u64 u64x2 __attribute__((ext_vector_type(2)));
 
 // one input word: the word-at-once path when it applies, else clock by clock; counters when EMIT
-template <int K, bool EMIT>
+// FULL: the caller knows that all 64 bits of the word lie inside the stream (the tiled path: whole chunks), which saves the
+// 64-bit bookkeeping of the tail on every word
+template <int K, bool EMIT, bool FULL = false>
 __device__ __forceinline__ void det_core(DetState &s, DetAux &a, u64 w, u64 word, u64 nbits, u64 &ew, u64 &rw, DetCount &cnt) {
-    const u64 left = nbits - w * 64;
-    const int nvalid = left >= 64 ? 64 : (int)left;
+    int nvalid = 64;
+    if (!FULL) {
+        const u64 left = nbits - w * 64;
+        nvalid = left >= 64 ? 64 : (int)left;
+    }
     ew = 0; rw = 0;
     unsigned trig = 0;
-    if (nvalid != 64 || !det_word_fast<K, EMIT>(s, a, word, ew)) { a.n = 0; det_word<K, EMIT>(s, word, nvalid, ew, rw, trig); }
+    bool fast = false;
+    if (FULL || nvalid == 64) fast = det_word_fast<K, EMIT>(s, a, word, ew);
+    if (!fast) { a.n = 0; det_word<K, EMIT>(s, word, nvalid, ew, rw, trig); }
     if (EMIT) {
-        cnt.err_raw += __builtin_popcountll(ew);
-        cnt.reload_clocks += __builtin_popcountll(rw);
-        cnt.err_synced += __builtin_popcountll(ew & ~rw);
-        cnt.resyncs += trig;
+        if (fast) {
+            // rw = 0 and trig = 0 on the locked path: one popcount serves both error counters
+            const u64 pe = (u64)__builtin_popcountll(ew);
+            cnt.err_raw += pe;
+            cnt.err_synced += pe;
+        } else {
+            cnt.err_raw += __builtin_popcountll(ew);
+            cnt.reload_clocks += __builtin_popcountll(rw);
+            cnt.err_synced += __builtin_popcountll(ew & ~rw);
+            cnt.resyncs += trig;
+        }
     }
 }
 
@@ -248,8 +262,8 @@ __device__ __forceinline__ void det_span_tiled(DetState &s, const u64 *__restric
 #pragma unroll
         for (int p = 0; p < 8; p++) {
             u64 e0, r0, e1, r1;
-            det_core<K, EMIT>(s, a, my_first + off + 2 * p, in[p].x, nbits, e0, r0, cnt);
-            det_core<K, EMIT>(s, a, my_first + off + 2 * p + 1, in[p].y, nbits, e1, r1, cnt);
+            det_core<K, EMIT, true>(s, a, my_first + off + 2 * p, in[p].x, nbits, e0, r0, cnt);
+            det_core<K, EMIT, true>(s, a, my_first + off + 2 * p + 1, in[p].y, nbits, e1, r1, cnt);
             eo[p].x = e0; eo[p].y = e1; ro[p].x = r0; ro[p].y = r1;
         }
         if (EMIT && err) {
@@ -356,12 +370,19 @@ det_reduce_kernel(u64 nchunks, const DetCount *__restrict counts, u64 *__restric
         v[0] += lo.x; v[1] += lo.y; v[2] += hi.x; v[3] += hi.y;
         if (c >= 1 && !det_equal(spec[c], endst[c - 1])) list[atomicAdd(nlist, 1u)] = (unsigned)c;
     }
+    // wave sums, then ONE atomic per block and counter (the atomics on four addresses were the kernel's cost: 0.05-0.12 ms)
+    __shared__ u64 part[4][4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         u64 x = v[q];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
-        if ((threadIdx.x & 63) == 0 && x) atomicAdd(&totals[q], x);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][q] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const u64 x = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        if (x) atomicAdd(&totals[threadIdx.x], x);
     }
 }
 
@@ -385,7 +406,7 @@ static int detector_stream_k(const u64 *src, u64 nbits, u64 *err, u64 *reload, b
     unsigned *nlist = (unsigned *)(tail + 4), *nlist2 = (unsigned *)(tail2 + 4);
     auto cleanup = [&]() { (void)hipFreeAsync(ws, st); };
     const unsigned grid = (unsigned)((nchunks + 255) / 256);
-    const unsigned rgrid = grid < 2048 ? grid : 2048;
+    const unsigned rgrid = grid < 512 ? grid : 512;
     // cooperative 128-byte loads need chunks and warm-up in whole 16-word rows on 16-byte aligned data
     const int tiles_ok = chunk_words % 16 == 0 && warm_words % 16 == 0 && warm_words > 0 && ((uintptr_t)src & 15) == 0;
     hipLaunchKernelGGL(det_chunk_kernel<K>, dim3(grid), dim3(256), 0, st, 0, src, nbits, nwords, chunk_words, warm_words,
