@@ -811,6 +811,135 @@ int pulse_bits_launch(uint64_t *dst, int64_t m_first, uint64_t nwords, hipStream
     return BBB_OK;
 }
 
+// The transmitter as "noise kernel + SHAPING mover" (bbb_tx_fill_i16 on a staged handle): the plain int8 sample kernel
+// fills the staging buffer [round][generator slot][16 bytes] as for the noise stream, and this mover turns every piece into
+// the 16 int16 samples x = wrap12(bit_en shaped + g noise_var) at their final place while it moves them -- the arithmetic of
+// the fused kernel's round end (TxFuse, the table TT and the window / select / multiply-add scheme described above
+// awgn256_kernel), done by a guest with a few waves per CU instead of by the kernel that owns every SIMD's issue slots.
+// 4 B of HBM traffic per sample (1 written + 1 read as noise, 2 written as output) against 6 for the fused staged form,
+// the sample kernel keeps its 32 KiB of LDS per wave (so the two-piece seeding fits beside it), and it is the plain noise
+// kernel's 1.2 ms per 1e9 samples that bounds the call, not the 1.54 of the fused one.
+// Tile as in unstage_kernel: 8 generators x 8 rounds per wave and trip, lane = (round, generator); a lane reads 16 bytes
+// (lanes of a round: 128 consecutive bytes) and writes 32 (lanes of a generator: 256 consecutive bytes).
+__global__ void __launch_bounds__(256, 5)
+tx_unstage_kernel(const char *__restrict stg, int16_t *__restrict dst, unsigned long long nsamples, unsigned L,
+                  unsigned long long G, unsigned long long Gpad, unsigned rounds, TxFuse tx) {
+    __shared__ __attribute__((aligned(16))) uint16_t TT[256 * 8];
+    for (int e = (int)threadIdx.x; e < 256 * 8; e += (int)blockDim.x) {
+        const int q = e >> 3, j = e & 7, ph = (int)((tx.c0 + (unsigned)j) & 7u);
+        int sum = 0;
+#pragma unroll
+        for (int idx = 0; idx < 8; idx++) {
+            const int c = tx.coeffs[8 * idx + ph];
+            sum += ((q >> (7 - idx)) & 1) ? c : -c;
+        }
+        const int shaped = tx.bit_en ? ((int)((unsigned)sum << 20) >> 20) : 0;
+        TT[e] = (uint16_t)((unsigned)((shaped - 128 * tx.noise_var) * 16) & 0xffffu);
+    }
+    uint32_t selmask[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++)
+        selmask[d] = (tx.c0 + 2u * (unsigned)d < 8u ? 0x0000ffffu : 0u) | (tx.c0 + 2u * (unsigned)d + 1u < 8u ? 0xffff0000u : 0u);
+    __syncthreads();
+    const u16x2 nv16 = {(uint16_t)(tx.noise_var * 16), (uint16_t)(tx.noise_var * 16)};
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned long long wave0 = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned long long nwaves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
+    const unsigned gl = lane & 7, rl = lane >> 3;
+    const unsigned long long ntrips = (G + 7) / 8;
+    for (unsigned long long trip = wave0; trip < ntrips; trip += nwaves) {
+        const unsigned long long g = trip * 8 + gl;
+        if (g >= G) continue;
+        const char *src = stg + ((unsigned long long)rl * Gpad + g) * 16;
+        const unsigned long long seg = g * (unsigned long long)L;
+        const unsigned long long rstride = 8ull * Gpad * 16;
+        // four tiles (32 rounds) per pass: their noise pieces and data windows are requested together, then shaped one
+        // after the other -- with ~80 instructions per piece a single load in flight would leave the wave waiting on memory
+        for (unsigned r0 = rl; r0 < rounds; r0 += 32, src += 4 * rstride) {
+            u32x4 v[4];
+            uint32_t win[4], relv[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const unsigned r = r0 + 8u * (unsigned)t;
+                const unsigned long long off = seg + (unsigned long long)r * 16;
+                v[t] = (u32x4){0u, 0u, 0u, 0u};
+                win[t] = 0;
+                relv[t] = ((uint32_t)off >> 3) + tx.rel_base;                                  // fits 32 bits (host check)
+                if (r < rounds && off < nsamples) {
+                    v[t] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + (unsigned long long)t * rstride));
+                    if (tx.use_bits) {
+                        const uint32_t byte = min(relv[t] >> 3, tx.last_word * 4u - 4u);
+                        typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+                        win[t] = *reinterpret_cast<const u32_unaligned *>(reinterpret_cast<const char *>(tx.bits) + byte);
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const unsigned r = r0 + 8u * (unsigned)t;
+                const unsigned long long off = seg + (unsigned long long)r * 16;                  // first sample of the piece
+                if (r >= rounds || off >= nsamples) break;
+                // the piece's 10-bit data window (bit j = data bit M0 - 7 + j), as in the fused kernel
+                const uint32_t Q4 = ((win[t] >> (relv[t] & 7u)) & 0x3ffu) << 4;
+                const char *tt = reinterpret_cast<const char *>(TT);
+                const u32x4 A = *reinterpret_cast<const u32x4 *>(tt + (Q4 & 0xff0u));
+                const u32x4 B = *reinterpret_cast<const u32x4 *>(tt + ((Q4 >> 1) & 0xff0u));
+                const u32x4 C = *reinterpret_cast<const u32x4 *>(tt + ((Q4 >> 2) & 0xff0u));
+                uint32_t x[8];
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    const uint32_t u = v[t][w] ^ 0x80808080u;                        // bytes g + 128 of samples 4w .. 4w+3
+                    const uint32_t u01 = __builtin_amdgcn_perm(0u, u, 0x0c010c00u);  // [u0, 0, u1, 0]
+                    const uint32_t u23 = __builtin_amdgcn_perm(0u, u, 0x0c030c02u);
+                    const int d0 = (2 * w) & 3, d1 = (2 * w + 1) & 3;
+                    const uint32_t s01 = w < 2 ? bfi_uniform(selmask[d0], A[d0], B[d0]) : bfi_uniform(selmask[d0], B[d0], C[d0]);
+                    const uint32_t s23 = w < 2 ? bfi_uniform(selmask[d1], A[d1], B[d1]) : bfi_uniform(selmask[d1], B[d1], C[d1]);
+                    const u16x2 m01 = __builtin_bit_cast(u16x2, u01) * nv16 + __builtin_bit_cast(u16x2, s01);
+                    const u16x2 m23 = __builtin_bit_cast(u16x2, u23) * nv16 + __builtin_bit_cast(u16x2, s23);
+                    x[2 * w] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(i16x2, m01) >> 4);
+                    x[2 * w + 1] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(i16x2, m23) >> 4);
+                }
+                int16_t *out = dst + off;
+                if (off + 16 <= nsamples) {
+                    const u32x4 lo = {x[0], x[1], x[2], x[3]}, hi = {x[4], x[5], x[6], x[7]};
+                    reinterpret_cast<u32x4 *>(out)[0] = lo;
+                    reinterpret_cast<u32x4 *>(out)[1] = hi;
+                } else {
+                    const unsigned n = (unsigned)(nsamples - off);
+                    for (unsigned e = 0; e < n; e++) out[e] = (int16_t)((x[e >> 1] >> (16 * (e & 1))) & 0xffff);
+                }
+            }
+        }
+    }
+}
+
+int tx_unstage_launch(const void *stg, int16_t *dst, uint64_t nsamples, unsigned L, uint64_t G, uint64_t Gpad, const int16_t *coeffs,
+                      const uint32_t *d_bits, uint32_t nwords32, uint32_t rel_base, uint32_t c0, int noise_var, int bit_en, int use_bits,
+                      hipStream_t st) {
+    TxFuse tx;
+    for (int i = 0; i < 64; i++) tx.coeffs[i] = coeffs[i];
+    tx.bits = d_bits;
+    tx.rel_base = rel_base;
+    tx.c0 = c0;
+    tx.noise_var = noise_var;
+    tx.bit_en = bit_en;
+    tx.use_bits = use_bits && nwords32 >= 2;
+    tx.last_word = nwords32 ? nwords32 - 1 : 1;
+    int dev = 0, ncu = 256;
+    BBB_HIP(hipGetDevice(&dev));
+    BBB_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    const uint64_t ntrips = (G + 7) / 8;
+    // three waves per CU: same box, alternating, 1e9 samples per call: 612-615 Gsample/s against 546-570 with four and 510
+    // with two (the mover then takes longer than the noise kernel it runs beside)
+    const unsigned threads = (unsigned)env_knob("BBB_TXMOVER_THREADS", 192);
+    uint64_t blocks = (uint64_t)ncu;
+    if (blocks > ntrips) blocks = ntrips;
+    hipLaunchKernelGGL(tx_unstage_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, (const char *)stg, dst, (unsigned long long)nsamples, L,
+                       (unsigned long long)G, (unsigned long long)Gpad, L / 16, tx);
+    BBB_HIP(hipGetLastError());
+    return BBB_OK;
+}
+
 int awgn256_tx_launch(const uint32_t *d_planes, int16_t *dst, uint64_t nsamples, unsigned L, uint64_t G, unsigned nlanes,
                       const int16_t *coeffs, const uint32_t *d_bits, uint32_t nwords32, uint32_t rel_base, uint32_t c0, int noise_var,
                       int bit_en, int use_bits, bool staged, hipStream_t st) {

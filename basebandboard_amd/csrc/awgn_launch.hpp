@@ -27,6 +27,10 @@ int unstage_launch(const void *stg, void *dst, uint64_t win_lo, uint64_t nbytes,
                    unsigned rounds, int piece, hipStream_t st);
 // the transmitter's output fused into the sample kernel: x = wrap12(bit_en * shaped + g * noise_var) as int16.
 // d_bits: packed data bits (32-bit words); rel_base = window bit offset of output position 0; c0 = (first_sample - 17) & 7
+// the shaping mover: int8 staging buffer of the plain sample kernel -> the TX waveform at its final place (awgn_kernels.hip)
+int tx_unstage_launch(const void *stg, int16_t *dst, uint64_t nsamples, unsigned L, uint64_t G, uint64_t Gpad, const int16_t *coeffs,
+                      const uint32_t *d_bits, uint32_t nwords32, uint32_t rel_base, uint32_t c0, int noise_var, int bit_en, int use_bits,
+                      hipStream_t st);
 int awgn256_tx_launch(const uint32_t *d_planes, int16_t *dst, uint64_t nsamples, unsigned L, uint64_t G, unsigned nlanes,
                       const int16_t *coeffs, const uint32_t *d_bits, uint32_t nwords32, uint32_t rel_base, uint32_t c0, int noise_var,
                       int bit_en, int use_bits, bool staged, hipStream_t st);

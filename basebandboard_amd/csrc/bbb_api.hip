@@ -349,16 +349,15 @@ int acquire_planes(bbb_lutopt *h, uint64_t first_step, uint64_t L, uint64_t G, u
 
 // the piece mover of staging slot `slot`: stream bytes [win_lo, win_lo + nbytes) -> dst; behind the slot's sample kernel
 // and behind everything the caller has queued so far; the caller's stream then waits for it
-int queue_mover(bbb_lutopt *h, int slot, void *dst, uint64_t win_lo, uint64_t nbytes, int piece, uint64_t L, uint64_t G,
-                unsigned nlanes) {
-    const uint64_t Gpad = (uint64_t)nlanes * 32;
-    const unsigned rounds = (unsigned)(L / 16);
+// `launch_mover(staging buffer, stream)` queues the kernel that empties the slot
+template <typename LaunchMover>
+int queue_mover_with(bbb_lutopt *h, int slot, LaunchMover launch_mover) {
     for (hipEvent_t *e : {&h->stage_free[slot], &h->ev_user})
         if (!*e) BBB_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     BBB_HIP(hipEventRecord(h->ev_user, h->stream));
     BBB_HIP(hipStreamWaitEvent(h->ys, h->ev_user, 0));
     BBB_HIP(hipStreamWaitEvent(h->ys, h->stage_arith[slot], 0));
-    int rc = unstage_launch(h->d_stage[slot], dst, win_lo, nbytes, (unsigned)(L * (uint64_t)piece / 16), G, Gpad, rounds, piece, h->ys);
+    int rc = launch_mover((const void *)h->d_stage[slot], h->ys);
     if (rc) return rc;
     BBB_HIP(hipEventRecord(h->stage_free[slot], h->ys));
     h->stage_busy[slot] = true;
@@ -366,14 +365,23 @@ int queue_mover(bbb_lutopt *h, int slot, void *dst, uint64_t win_lo, uint64_t nb
     return BBB_OK;
 }
 
+int queue_mover(bbb_lutopt *h, int slot, void *dst, uint64_t win_lo, uint64_t nbytes, int piece, uint64_t L, uint64_t G,
+                unsigned nlanes) {
+    const uint64_t Gpad = (uint64_t)nlanes * 32;
+    const unsigned rounds = (unsigned)(L / 16);
+    return queue_mover_with(h, slot, [&](const void *stage, hipStream_t ys) {
+        return unstage_launch(stage, dst, win_lo, nbytes, (unsigned)(L * (uint64_t)piece / 16), G, Gpad, rounds, piece, ys);
+    });
+}
+
 // planes_seeded_after_mover: the start states came from a prefetch whose seeding had itself waited for the mover that last
 // read this staging buffer (bbb_awgn_prefetch on a staged handle), so the arithmetic need not wait for it again -- every
 // event wait is a barrier packet of several microseconds between two sample kernels.
 // The sample kernel produces `total_bytes` of stream (L, G, nlanes are ITS partition); `nbytes` of them, from offset 0, are
 // delivered to dst now (look-ahead: total_bytes = 2 nbytes, the rest waits in the slot).  *slot_out = the slot used.
-template <typename LaunchArith>
-int staged_fill(bbb_lutopt *h, void *dst, uint64_t nbytes, int piece, uint64_t L, uint64_t G, unsigned nlanes,
-                bbb_lutopt::ProfEv *ev, bool planes_seeded_after_mover, LaunchArith launch_arith, int *slot_out = nullptr) {
+template <typename LaunchArith, typename LaunchMover>
+int staged_fill_with(bbb_lutopt *h, int piece, uint64_t L, unsigned nlanes, bbb_lutopt::ProfEv *ev, bool planes_seeded_after_mover,
+                     LaunchArith launch_arith, LaunchMover launch_mover, int *slot_out = nullptr) {
     const uint64_t Gpad = (uint64_t)nlanes * 32;
     const unsigned rounds = (unsigned)(L / 16);
     const size_t need_words = (size_t)(Gpad * rounds * (uint64_t)piece / 4);
@@ -396,7 +404,18 @@ int staged_fill(bbb_lutopt *h, void *dst, uint64_t nbytes, int piece, uint64_t L
     if ((rc = mark_planes_read(h))) return rc;
     if (ev) BBB_HIP(hipEventRecord(ev->e2, h->cs));
     BBB_HIP(hipEventRecord(h->stage_arith[slot], h->cs));
-    return queue_mover(h, slot, dst, 0, nbytes, piece, L, G, nlanes);
+    return queue_mover_with(h, slot, launch_mover);
+}
+
+template <typename LaunchArith>
+int staged_fill(bbb_lutopt *h, void *dst, uint64_t nbytes, int piece, uint64_t L, uint64_t G, unsigned nlanes,
+                bbb_lutopt::ProfEv *ev, bool planes_seeded_after_mover, LaunchArith launch_arith, int *slot_out = nullptr) {
+    const uint64_t Gpad = (uint64_t)nlanes * 32;
+    const unsigned rounds = (unsigned)(L / 16);
+    return staged_fill_with(h, piece, L, nlanes, ev, planes_seeded_after_mover, launch_arith,
+                            [&](const void *stage, hipStream_t ys) {
+                                return unstage_launch(stage, dst, 0, nbytes, (unsigned)(L * (uint64_t)piece / 16), G, Gpad, rounds, piece, ys);
+                            }, slot_out);
 }
 
 // the packed n512 kernel's partition: 16 generators per lane, 1024 per wave, segments in multiples of 8 samples (16-byte
@@ -1159,7 +1178,19 @@ int bbb_tx_fill_i16(bbb_lutopt *h, const bbb_tx_cfg *cfg, int16_t *out_dev, uint
                                      (uint32_t)(words64 * 2), rel_base, (uint32_t)(F & 7), cfg->noise_var, cfg->bit_en, use_bits ? 1 : 0,
                                      to_stage, h->cs);
         };
-        if (staged) {
+        if (staged && !ahead) {
+            // noise kernel + shaping mover: the plain int8 sample kernel into the staging buffer, the transmitter's
+            // arithmetic in the mover (tx_unstage_kernel) -- the call is then bounded by the noise kernel (1.2 ms per 1e9
+            // samples alone) instead of the fused one (1.54), and moves 4 instead of 6 bytes per sample through HBM
+            h->last_fill_tx = false;            // (what runs on the SIMDs is the plain kernel: the seeding may use 16 KiB pieces)
+            const uint64_t Gpad = (uint64_t)nlanes * 32;
+            rc = staged_fill_with(h, 16, L, nlanes, nullptr, from_pf,
+                                  [&](void *stage) { return awgn256_fill_launch(h->d_planes, (int8_t *)stage, nsamples, (unsigned)L, G, nlanes, true, h->cs); },
+                                  [&](const void *stage, hipStream_t ys) {
+                                      return tx_unstage_launch(stage, out_dev, nsamples, (unsigned)L, G, Gpad, cfg->coeffs, d_bits, (uint32_t)(words64 * 2),
+                                                               rel_base, (uint32_t)(F & 7), cfg->noise_var, cfg->bit_en, use_bits ? 1 : 0, ys);
+                                  });
+        } else if (staged) {
             int slot = 0;
             rc = staged_fill(h, out_dev, nsamples * 2, 32, L, G, nlanes, nullptr, from_pf, [&](void *stage) { return arith(stage, true); }, &slot);
             if (!rc && ahead) {
@@ -1174,7 +1205,8 @@ int bbb_tx_fill_i16(bbb_lutopt *h, const bbb_tx_cfg *cfg, int16_t *out_dev, uint
             if (!rc) rc = mark_planes_read(h);
         }
         if (rc) return rc;
-        BBB_HIP(hipEventRecord(h->fbits_read[bs], h->cs));        // (staged: the piece mover does not read the bits)
+        // the last reader of the data bits: the shaping mover (on ys) in the noise-kernel + mover form, else the fused kernel
+        BBB_HIP(hipEventRecord(h->fbits_read[bs], (staged && !ahead) ? h->ys : h->cs));
         h->fbits_pending[bs] = true;
         return BBB_OK;
     }

@@ -420,9 +420,9 @@ def main():
         other.append(r)
         del pbuf
         # TX output stream: shaped PRBS-31 + scaled CLT noise, int16, 8 samples/bit
-        # 2^30 samples per call in the staged form (full-line stores + piece mover; the seeding of call s+1, the data bits
-        # of call s+1 and the mover of call s-1 run beside the sample kernel of call s), and 2^29 per call in the
-        # one-kernel form as in round 1 (the size those figures were quoted on)
+        # 1e9 samples per call in the staged form (the plain int8 noise kernel into the staging buffer, the transmitter's
+        # arithmetic in the SHAPING mover that empties it beside the next call's noise kernel), and 2^29 per call in the
+        # one-kernel form (shaper fused into the sample kernel) as in round 1 (the size those figures were quoted on)
         def tx_rate(ntx, staged_tx):
             tx = bbb.TX(31, 1, 0, 16, 1, 8, device=local_rank)
             tx.urng.set_staged(staged_tx)
@@ -438,16 +438,16 @@ def main():
             torch.cuda.synchronize()
             del txbuf
             return t0e.elapsed_time(t1e) / 8
-        ntx = 1 << 30
+        ntx = 1_000_000_000
         tx_ms = tx_rate(ntx, True)
         tx_ms_1k = tx_rate(1 << 29, False)
         extra["tx_waveform"] = {"samples": ntx, "gsample_s": round(ntx / tx_ms / 1e6, 1), "ms_per_call": round(tx_ms, 4),
-                                "form": "staged (bbb_lutopt_set_staged on the TX's generator handle)",
+                                "form": "staged (bbb_lutopt_set_staged on the TX's generator handle): noise kernel + shaping mover",
                                 "one_kernel_form_2p29_per_call": {"gsample_s": round((1 << 29) / tx_ms_1k / 1e6, 1), "ms_per_call": round(tx_ms_1k, 4)},
                                 "note": "bbb_tx_fill_i16: PRBS fill + the sample kernel with the shaper fused into its round end "
                                         "(int16 out, the int8 noise never goes through HBM)"}
-        r = hbm("awgn256_kernel<true, true> + unstage_kernel<32> (whole bbb_tx_fill_i16 call)", 2.0 * ntx, tx_ms, "2 B per sample delivered (6 B of HBM traffic: staging write, mover read + write)")
-        r["true_bound"] = "integer VALU of the noise generator at one wave per SIMD, slowed by its guests (mover, seeding, data bits) on the same CUs"
+        r = hbm("awgn256_kernel<false, true> + tx_unstage_kernel (whole bbb_tx_fill_i16 call)", 2.0 * ntx, tx_ms, "2 B per sample delivered (4 B of HBM traffic: int8 staging write and read, int16 output write)")
+        r["true_bound"] = "integer VALU of the noise generator at one wave per SIMD, slowed by its guests (shaping mover, seeding, data bits) on the same CUs"
         other.append(r)
         # PRBSShaper.x alone (noise off): PRBS fill + table rows, 2 B per sample written
         txs = bbb.TX(31, 1, 0, 16, 0, 8, device=local_rank)
