@@ -324,3 +324,19 @@ def test_random_mix_of_calls_on_one_staged_handle(gpu, oracle, seed):
     for kind, n, p, got in checks:
         ref = d.generate(n, first_step=p) if kind == "awgn" else y.generate(n, first_sample=p)
         assert torch.equal(got, ref), (kind, n, p)
+
+
+@pytest.mark.parametrize("bit_en,src,nv,first", [(1, 0, 8, 0), (1, 0, 15, 5), (0, 0, 3, 1001), (1, 1, 1, 17), (1, 0, 0, 12345),
+                                                 (1, 1, 8, 2047), (1, 0, 8, (1 << 31) + 3)])
+def test_staged_tx_configurations(gpu, bit_en, src, nv, first):
+    """The noise kernel + shaping mover form of bbb_tx_fill_i16 over the transmitter's switches (bits off, pulse source,
+    every phase c0 = (first - 17) & 7 through the start positions, noise_var 0 .. 15, a ragged length) against the
+    one-kernel form, which tests/test_gpu_tx.py holds to the oracle."""
+    n = BIG + 16 * 37 + 5
+    x = gpu.TX(31, bit_en, src, 16, 1, nv)
+    x.urng.set_staged(True)
+    y = gpu.TX(31, bit_en, src, 16, 1, nv)
+    for i in range(2):
+        a = x.generate(n, first_sample=first + i * n)
+        b = y.generate(n, first_sample=first + i * n)
+        assert torch.equal(a, b), i
