@@ -821,9 +821,10 @@ int pulse_bits_launch(uint64_t *dst, int64_t m_first, uint64_t nwords, hipStream
 // kernel's 1.2 ms per 1e9 samples that bounds the call, not the 1.54 of the fused one.
 // Tile as in unstage_kernel: 8 generators x 8 rounds per wave and trip, lane = (round, generator); a lane reads 16 bytes
 // (lanes of a round: 128 consecutive bytes) and writes 32 (lanes of a generator: 256 consecutive bytes).
+template <int TILES>
 __global__ void __launch_bounds__(256, 5)
 tx_unstage_kernel(const char *__restrict stg, int16_t *__restrict dst, unsigned long long nsamples, unsigned L,
-                  unsigned long long G, unsigned long long Gpad, unsigned rounds, TxFuse tx) {
+                  unsigned long long G, unsigned long long Gpad, unsigned rounds, TxFuse tx, unsigned pause) {
     __shared__ __attribute__((aligned(16))) uint16_t TT[256 * 8];
     for (int e = (int)threadIdx.x; e < 256 * 8; e += (int)blockDim.x) {
         const int q = e >> 3, j = e & 7, ph = (int)((tx.c0 + (unsigned)j) & 7u);
@@ -855,11 +856,12 @@ tx_unstage_kernel(const char *__restrict stg, int16_t *__restrict dst, unsigned 
         const unsigned long long rstride = 8ull * Gpad * 16;
         // four tiles (32 rounds) per pass: their noise pieces and data windows are requested together, then shaped one
         // after the other -- with ~80 instructions per piece a single load in flight would leave the wave waiting on memory
-        for (unsigned r0 = rl; r0 < rounds; r0 += 32, src += 4 * rstride) {
-            u32x4 v[4];
-            uint32_t win[4], relv[4];
+        for (unsigned r0 = rl; r0 < rounds; r0 += 8 * TILES, src += TILES * rstride) {
+            for (unsigned z = 0; z < pause; z++) __builtin_amdgcn_s_sleep(4);
+            u32x4 v[TILES];
+            uint32_t win[TILES], relv[TILES];
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
+            for (int t = 0; t < TILES; t++) {
                 const unsigned r = r0 + 8u * (unsigned)t;
                 const unsigned long long off = seg + (unsigned long long)r * 16;
                 v[t] = (u32x4){0u, 0u, 0u, 0u};
@@ -875,7 +877,7 @@ tx_unstage_kernel(const char *__restrict stg, int16_t *__restrict dst, unsigned 
                 }
             }
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
+            for (int t = 0; t < TILES; t++) {
                 const unsigned r = r0 + 8u * (unsigned)t;
                 const unsigned long long off = seg + (unsigned long long)r * 16;                  // first sample of the piece
                 if (r >= rounds || off >= nsamples) break;
@@ -934,8 +936,13 @@ int tx_unstage_launch(const void *stg, int16_t *dst, uint64_t nsamples, unsigned
     const unsigned threads = (unsigned)env_knob("BBB_TXMOVER_THREADS", 192);
     uint64_t blocks = (uint64_t)ncu;
     if (blocks > ntrips) blocks = ntrips;
-    hipLaunchKernelGGL(tx_unstage_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, (const char *)stg, dst, (unsigned long long)nsamples, L,
-                       (unsigned long long)G, (unsigned long long)Gpad, L / 16, tx);
+    const unsigned pause = (unsigned)env_knob("BBB_TXMOVER_PAUSE", 0);
+    if (env_knob("BBB_TXMOVER_TILES", 4) == 2)
+        hipLaunchKernelGGL(tx_unstage_kernel<2>, dim3((unsigned)blocks), dim3(threads), 0, st, (const char *)stg, dst, (unsigned long long)nsamples, L,
+                           (unsigned long long)G, (unsigned long long)Gpad, L / 16, tx, pause);
+    else
+        hipLaunchKernelGGL(tx_unstage_kernel<4>, dim3((unsigned)blocks), dim3(threads), 0, st, (const char *)stg, dst, (unsigned long long)nsamples, L,
+                           (unsigned long long)G, (unsigned long long)Gpad, L / 16, tx, pause);
     BBB_HIP(hipGetLastError());
     return BBB_OK;
 }
