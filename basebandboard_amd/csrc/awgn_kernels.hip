@@ -200,6 +200,11 @@ bitslice_kernel(const uint32_t *__restrict S, unsigned long long G, unsigned lon
 // ---------------------------------------------------------------------------------------------
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef BBB_EXPERIMENTS
+static void *g_exp_awgn_debug = nullptr;      // u64[4 * waves], device memory, or null
+extern "C" void bbb_exp_set_awgn_debug(void *dev_ptr) { g_exp_awgn_debug = dev_ptr; }
+#endif
+
 // The transmitter's output fused into the sample kernel (tx.py:60-81; bitshaper.py:25-86): instead of the
 // int8 noise stream the round end writes x = wrap12(bit_en * shaped + wrap12(g * noise_var)) as int16, 32
 // bytes per generator and round, and the noise never goes through HBM.
@@ -254,6 +259,12 @@ awgn256_kernel(const uint32_t *__restrict planes, void *__restrict dst_, unsigne
     // highest wave priority: when the seeding of the next fill (bbb_awgn_prefetch) shares the SIMD it gets the
     // issue slots this wave leaves free instead of every other one
     __builtin_amdgcn_s_setprio(3);
+#ifdef BBB_EXPERIMENTS
+    // per-wave time stamps (experiments/wave_clock.py): shader-clock ticks (s_memtime) and the constant 100 MHz counter
+    // (s_memrealtime) at both ends of the wave -- cycles per wave and the clock they ran at, alone and beside guests
+    unsigned long long dbg_t0 = 0, dbg_r0 = 0, dbg_round_end = 0;
+    if (!TX && tx.bits) { dbg_t0 = __builtin_amdgcn_s_memtime(); dbg_r0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
 
     uint32_t selmask[4] = {0, 0, 0, 0};
     if (TX) {
@@ -447,9 +458,23 @@ awgn256_kernel(const uint32_t *__restrict planes, void *__restrict dst_, unsigne
                 }
             }
         };
+#ifdef BBB_EXPERIMENTS
+        unsigned long long dbg_ta = 0;
+        if (!TX && tx.bits) dbg_ta = __builtin_amdgcn_s_memtime();
+#endif
         if (wave_full) all_iterations(std::true_type{});
         else all_iterations(std::false_type{});
+#ifdef BBB_EXPERIMENTS
+        if (!TX && tx.bits) dbg_round_end += __builtin_amdgcn_s_memtime() - dbg_ta;
+#endif
     }
+#ifdef BBB_EXPERIMENTS
+    if (!TX && tx.bits && lane == 0) {
+        unsigned long long *d = (unsigned long long *)tx.bits + 4 * wave;
+        d[0] = dbg_t0; d[1] = __builtin_amdgcn_s_memtime(); d[2] = dbg_r0; d[3] = __builtin_amdgcn_s_memrealtime();
+        ((unsigned long long *)tx.bits)[4 * 1024 + wave] = dbg_round_end;       // cycles inside the round ends
+    }
+#endif
 }
 
 // Staging buffer [round][generator slot][PIECE bytes] -> the sequential stream (generator g owns bytes [g Lb, (g+1) Lb)).
@@ -779,7 +804,10 @@ int awgn_seed_launch(int k, const uint32_t *d_tabs, const uint32_t *s16, uint64_
 int awgn256_fill_launch(const uint32_t *d_planes, int8_t *dst, uint64_t nsamples, unsigned L, uint64_t G,
                         unsigned nlanes, bool staged, hipStream_t st) {
     const unsigned nwaves = nlanes / 64;
-    const TxFuse none{};
+    TxFuse none{};
+#ifdef BBB_EXPERIMENTS
+    none.bits = (const uint32_t *)g_exp_awgn_debug;      // per-wave time stamps, see the kernel
+#endif
     if (staged)
         hipLaunchKernelGGL((awgn256_kernel<false, true>), dim3(nwaves), dim3(64), 0, st, d_planes, (void *)dst, (unsigned long long)nsamples, L,
                            (unsigned long long)G, nlanes, none);

@@ -122,6 +122,8 @@ struct bbb_lutopt {
     int stage_slot = 0;
     hipEvent_t ev_user = nullptr;
     int pf_waited_slot = -1;              // staging slot whose mover the pending prefetch's seeding waited for
+    uint64_t stage_gen[2] = {0, 0};       // movers queued on the slot so far
+    uint64_t pf_waited_gen = 0;           // stage_gen[pf_waited_slot] when that seeding was queued: a later mover voids the skip
     hipEvent_t stage_arith[2] = {nullptr, nullptr};   // recorded behind the sample kernel that filled the slot
     // look-ahead (bbb_lutopt_set_staged(h, m), m >= 2): the sample kernel of a fill also produced the next m - 1 fills'
     // samples, which wait in its staging slot: `left` more fills of n samples, the next one at stream position `first`
@@ -361,6 +363,7 @@ int queue_mover_with(bbb_lutopt *h, int slot, LaunchMover launch_mover) {
     if (rc) return rc;
     BBB_HIP(hipEventRecord(h->stage_free[slot], h->ys));
     h->stage_busy[slot] = true;
+    h->stage_gen[slot]++;
     BBB_HIP(hipStreamWaitEvent(h->stream, h->stage_free[slot], 0));
     return BBB_OK;
 }
@@ -396,7 +399,11 @@ int staged_fill_with(bbb_lutopt *h, int piece, uint64_t L, unsigned nlanes, bbb_
         int rc = grow(&h->d_stage[slot], &h->stage_cap[slot], need_words);
         if (rc) return rc;
     }
-    if (h->stage_busy[slot] && !(planes_seeded_after_mover && h->pf_waited_slot == slot))
+    // (the skip holds only while no LATER mover was queued on the slot: a prefetch stays valid across fills that do not
+    // match it, and those may have put new movers on this very slot since its seeding waited)
+    const bool seeding_saw_last_mover = planes_seeded_after_mover && h->pf_waited_slot == slot && h->pf_waited_gen == h->stage_gen[slot];
+    if (planes_seeded_after_mover) h->pf_waited_slot = -1;          // consumed
+    if (h->stage_busy[slot] && !seeding_saw_last_mover)
         BBB_HIP(hipStreamWaitEvent(h->cs, h->stage_free[slot], 0));   // its last mover has read it
     if (ev) BBB_HIP(hipEventRecord(ev->e1, h->cs));
     int rc = launch_arith((void *)h->d_stage[slot]);
@@ -916,6 +923,7 @@ int bbb_awgn_prefetch(bbb_lutopt *h, uint64_t nsamples, uint64_t first_step) {
     if (h->staged_mode && h->stage_busy[h->stage_slot ^ 1]) {
         BBB_HIP(hipStreamWaitEvent(side, h->stage_free[h->stage_slot ^ 1], 0));
         h->pf_waited_slot = h->stage_slot ^ 1;
+        h->pf_waited_gen = h->stage_gen[h->stage_slot ^ 1];
     }
     if (!pf.seeded) BBB_HIP(hipEventCreateWithFlags(&pf.seeded, hipEventDisableTiming));
     // the buffers may still be read by the sample kernel that used them last (main stream)

@@ -340,3 +340,29 @@ def test_staged_tx_configurations(gpu, bit_en, src, nv, first):
         a = x.generate(n, first_sample=first + i * n)
         b = y.generate(n, first_sample=first + i * n)
         assert torch.equal(a, b), i
+
+
+def test_prefetch_survives_unrelated_fills_on_its_slot(gpu, oracle):
+    """A prefetch stays valid across fills that do not match it (bbb.h).  Its seeding waited for the mover that read the
+    staging slot at the time; the unrelated fills in between put NEW movers on both slots, so the announced fill must
+    wait for those again before its sample kernel overwrites the slot (round-2 advisor finding: a stale skip let it
+    overwrite a buffer the newer mover was still reading)."""
+    m = oracle.Lutopt(path=oracle.data_path(256))
+    u = gpu.LUTOPT.shipped(256, init=0x5EED)
+    u.set_staged(True)
+    g = gpu.CLTGRNG(u)
+    n = BIG + 4096
+    big = 8 * BIG                      # long movers: still running when the announced fill's kernel is queued
+    a = g.generate(n, first_step=16)
+    g.prefetch(n, first_step=16 + n)                   # P: announced, its seeding waits for the mover of `a`'s slot partner
+    x = g.generate(big, first_step=10_000_000_019)     # unrelated: slot 0 / 1 get new movers
+    y = g.generate(big, first_step=20_000_000_033)
+    b = g.generate(n, first_step=16 + n)               # the announced fill, straight behind them
+    torch.cuda.synchronize()
+    ref = m.awgn(0x5EED, 16, 2 * n, fast=True)
+    assert np.array_equal(a.cpu().numpy(), ref[:n])
+    assert np.array_equal(b.cpu().numpy(), ref[n:])
+    for buf, first in ((x, 10_000_000_019), (y, 20_000_000_033)):
+        got = buf.cpu().numpy()
+        for off in (0, big // 2 - 77, big - 300_000):
+            assert np.array_equal(got[off:off + 300_000], m.awgn(u.state_at(first + off), 0, 300_000, fast=True)), (first, off)
