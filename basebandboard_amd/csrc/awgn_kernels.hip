@@ -612,6 +612,244 @@ int unstage_launch(const void *stg, void *dst, uint64_t win_lo, uint64_t nbytes,
     return BBB_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The PLANES form of the staged stream (round 3).  awgn256_kernel<*, true> still spends ~12 % of its issue slots on
+// turning count planes into bytes: 47 shift / BFI butterflies per step, 8 LDS stores per step, and per round 128 LDS
+// reads, 256 V_PERM, 32 stores and the waits on them -- all of it on the one wave per SIMD that issues a vector
+// instruction every 4 cycles.  None of that needs the state: it is a transposition of data that is already final.
+// So this kernel stores the 8 count planes of every step as they are -- two 16-byte stores per lane and step, 1 KiB
+// per store instruction, no LDS, no round end -- and the transposition moves into the mover (unplane_kernel), a guest
+// with two waves per CU that runs in the issue slots the sample kernel cannot use.
+// Staging layout: u32x4 stage[wave][step][half][lane], half 0 = planes 0..3, half 1 = planes 4..7 (plane 7 already
+// complemented: the int8 two's complement form).  Every wave runs all L steps (generators beyond G are padding).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+awgn256_planes_kernel(const uint32_t *__restrict planes, u32x4 *__restrict stage, unsigned L, unsigned nlanes
+#ifdef BBB_EXPERIMENTS
+                      , unsigned long long *dbg
+#endif
+) {
+    const unsigned lane = threadIdx.x;
+    const unsigned long long wave = blockIdx.x;
+    const unsigned long long LG = wave * 64 + lane;
+    __builtin_amdgcn_s_setprio(3);
+#ifdef BBB_EXPERIMENTS
+    unsigned long long dbg_t0 = 0, dbg_r0 = 0;
+    if (dbg) { dbg_t0 = __builtin_amdgcn_s_memtime(); dbg_r0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
+    uint32_t a[256], b[256], pa[256], pb[256], cnt[8];
+#pragma unroll
+    for (int p = 0; p < 256; p++) b[p] = planes[(size_t)p * nlanes + LG];
+    lutopt256_advance(b, a);
+#define BBB_PARK(p) BBB_ACC_WRITE(pa[p], a[p]);
+    LUTOPT256_FOR_PARKED_HI(BBB_PARK)
+#undef BBB_PARK
+    u32x4 *out = stage + (wave * L) * 128 + lane;
+#pragma unroll 1
+    for (unsigned t = 0; t < L; t += 2) {
+        lutopt256_step_parked_hi(a, pa, b, pb, cnt);
+        __builtin_nontemporal_store((u32x4){cnt[0], cnt[1], cnt[2], cnt[3]}, out);
+        __builtin_nontemporal_store((u32x4){cnt[4], cnt[5], cnt[6], cnt[7]}, out + 64);
+        lutopt256_step_parked_hi(b, pb, a, pa, cnt);
+        __builtin_nontemporal_store((u32x4){cnt[0], cnt[1], cnt[2], cnt[3]}, out + 128);
+        __builtin_nontemporal_store((u32x4){cnt[4], cnt[5], cnt[6], cnt[7]}, out + 192);
+        out += 256;
+    }
+#ifdef BBB_EXPERIMENTS
+    if (dbg && lane == 0) {
+        unsigned long long *d = dbg + 4 * wave;
+        d[0] = dbg_t0; d[1] = __builtin_amdgcn_s_memtime(); d[2] = dbg_r0; d[3] = __builtin_amdgcn_s_memrealtime();
+        dbg[4 * 1024 + wave] = 0;
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        dbg[5 * 1024 + wave] = ((hwid >> 4) & 0x3ff) | ((unsigned long long)(xcc & 15) << 10);      // simd, pipe, cu, sh, se | xcc
+    }
+#endif
+}
+
+int awgn256_planes_launch(const uint32_t *d_planes, void *stage, unsigned L, unsigned nlanes, hipStream_t st) {
+    if (L & 1) return fail(BBB_EINVAL, "segment length must be even");
+#ifdef BBB_EXPERIMENTS
+    hipLaunchKernelGGL(awgn256_planes_kernel, dim3(nlanes / 64), dim3(64), 0, st, d_planes, (u32x4 *)stage, L, nlanes,
+                       (unsigned long long *)g_exp_awgn_debug);
+#else
+    hipLaunchKernelGGL(awgn256_planes_kernel, dim3(nlanes / 64), dim3(64), 0, st, d_planes, (u32x4 *)stage, L, nlanes);
+#endif
+    BBB_HIP(hipGetLastError());
+    return BBB_OK;
+}
+
+// The mover of the PLANES form: count planes -> the sequential byte stream.
+// It runs BESIDE the next fill's sample kernel, whose wave leaves a SIMD 72 registers and every issue slot but one in
+// four: a guest there is bound by latency, not by work -- so the loads are LDS-DMA (global_load_lds_dwordx4: no
+// destination registers, a whole unit in flight per workgroup while the previous one is processed).
+// Unit of work = (source wave w, 8 of its lanes, 128 steps): 32 KiB of planes in, 256 generators x 128 bytes out.
+//   DMA      32 wave-instructions of 1 KiB (8 per wave): a lane fetches 16 bytes of one (step, half) row (8 lanes = one full
+//            128-byte line); the LDS image is laid out for the readers, raw[c = 2 s + half][quad-step qs][lane8][16 B]
+//            (the DMA's destination is lane-linear, its per-lane SOURCE address is free);
+//   phase 1  thread (qs, lane8): 8 x ds_read_b128 (a wave reads 1 KiB contiguous), planes8_to_bytes per step, eight 4x4
+//            byte transposes -> for each of the lane's 32 generators the 4 sample bytes of steps 4qs..4qs+3, one
+//            ds_write_b32 each into the generator's 128-byte row of the tile (row = j * 8 + lane8; 16-byte chunk c of a
+//            row sits at chunk position c ^ 2 * ((lane8 >> 1) & 3): a wave's store hits all 64 banks once);
+//   phase 2  thread (row, chunk): ds_read_b128 + one 16-byte store; the 8 lanes of a generator write 128 consecutive
+//            bytes of its segment, a wave 8 consecutive segments.
+// LDS (dynamic, ONE array: 2 x 32 KiB raw + 32 KiB tile): the DMA of unit u+1 is in flight while unit u is processed;
+// raw barriers and counted vmcnt (a __syncthreads() would drain the DMA: cdna_hip_programming.md, "Pipelining across barriers").
+// One block of four waves per CU, persistent over its share of the units.
+constexpr unsigned kUnplaneRaw = 32 * 1024, kUnplaneLds = 3 * 32 * 1024;
+
+template <bool TXM>
+__global__ void __launch_bounds__(256, 7)      // <= 72 registers: a wave of this kernel must fit beside the sample kernel's (<= 440 of 512)
+unplane_kernel(const u32x4 *__restrict stage, char *__restrict dst, unsigned long long win_lo, unsigned long long nbytes_, unsigned L,
+               unsigned long long G, unsigned w_lo, unsigned w_n, TxFuse tx) {
+    // DYNAMIC shared memory: with a static array of this size hipcc derives "at most one wave per SIMD" from the LDS size
+    // and enforces it by declaring 257 registers for this kernel -- which then cannot share a SIMD with the sample
+    // kernel's wave (measured: half of the sample waves waited for the mover to leave)
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    typedef __attribute__((address_space(3))) void *lds_void_ptr;
+    const unsigned tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const unsigned ngroups = (L + 127) / 128;
+    const unsigned long long nunits = (unsigned long long)w_n * ngroups * 8;
+    // the stream window [win_lo, win_lo + nbytes_) of the staged segments goes to dst[0 ..): dst is indexed by stream offset
+    char *const dstw = dst - win_lo;
+    const unsigned long long nbytes = win_lo + nbytes_;
+    // phase 1: quad-step and lane of eight
+    const unsigned l8 = tid & 7, qs = tid >> 3;
+    const unsigned wr0 = l8 * 32 + ((((qs >> 2) ^ (2 * ((l8 >> 1) & 3))) << 2) | (qs & 3));      // word of (row j*8 + l8, steps 4qs..)
+    // phase 2: rows (4 k + (tid >> 6)) * 8 + lq, k = 0..7; chunk c2
+    const unsigned lq = (tid >> 3) & 7, c2 = tid & 7;
+    const unsigned rd0 = ((tid >> 6) * 8 + lq) * 32 + ((c2 ^ (2 * ((lq >> 1) & 3))) << 2);
+    uint32_t *const tile = lds + 2 * (kUnplaneRaw / 4);
+#ifdef BBB_EXPERIMENTS
+    if (!TXM && tx.bits && lane == 0) {      // which SIMD this mover wave sits on, and when it ran
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long *d = (unsigned long long *)tx.bits + 6 * 1024 + 2 * ((blockIdx.x * 4 + wv) & 1023);
+        d[0] = (((hwid >> 4) & 0x3ff) | ((unsigned long long)(xcc & 15) << 10)) | (1ull << 63);
+        d[1] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+    // the 8 DMA instructions of this wave for unit u into raw buffer `buf`: 1 KiB block b = wv * 8 + k holds
+    // c = b >> 2 (step-in-quad s = c >> 1, half = c & 1) of quad-steps (b & 3) * 8 .. + 8
+    auto dma_unit = [&](unsigned long long u, unsigned buf) {
+        const unsigned q8 = (unsigned)(u & 7);
+        const unsigned step0 = (unsigned)((u >> 3) % ngroups) * 128;
+        const unsigned long long w = w_lo + (u >> 3) / ngroups;
+        const u32x4 *src = stage + (w * L) * 128 + q8 * 8 + (lane & 7);
+#pragma unroll
+        for (unsigned k = 0; k < 8; k++) {
+            const unsigned b = wv * 8 + k, c = b >> 2;
+            unsigned st = step0 + 4 * ((b & 3) * 8 + (lane >> 3)) + (c >> 1);
+            st = st < L ? st : L - 1;                       // (a segment's last unit may be short: phase 2 never writes those steps)
+            const u32x4 *g = src + ((size_t)st * 2 + (c & 1)) * 64;
+            __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)(uintptr_t)(lds + buf * (kUnplaneRaw / 4) + b * 256), 16, 0, 0);
+        }
+    };
+    unsigned buf = 0;
+    if (blockIdx.x < nunits) dma_unit(blockIdx.x, 0);
+    for (unsigned long long u = blockIdx.x; u < nunits; u += gridDim.x, buf ^= 1) {
+        const unsigned q8 = (unsigned)(u & 7);
+        const unsigned rg = (unsigned)((u >> 3) % ngroups);
+        const unsigned long long w = w_lo + (u >> 3) / ngroups;
+        const unsigned step0 = rg * 128;
+        const bool more = u + gridDim.x < nunits;
+        if (more) dma_unit(u + gridDim.x, buf ^ 1);
+        // this unit's DMA (and the previous unit's stores, which are older) done: all but the 8 instructions just issued
+        if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 1
+        {
+            const uint32_t *raw = lds + buf * (kUnplaneRaw / 4) + (qs * 8 + l8) * 4;
+            uint32_t Z[4][8];
+#pragma unroll
+            for (unsigned s = 0; s < 4; s++) {
+                const u32x4 lo = *reinterpret_cast<const u32x4 *>(raw + (2 * s) * 1024);
+                const u32x4 hi = *reinterpret_cast<const u32x4 *>(raw + (2 * s + 1) * 1024);
+                Z[s][0] = lo[0]; Z[s][1] = lo[1]; Z[s][2] = lo[2]; Z[s][3] = lo[3];
+                Z[s][4] = hi[0]; Z[s][5] = hi[1]; Z[s][6] = hi[2]; Z[s][7] = hi[3];
+            }
+#pragma unroll
+            for (unsigned s = 0; s < 4; s++) planes8_to_bytes(Z[s]);
+#pragma unroll
+            for (unsigned i = 0; i < 8; i++) {
+                uint32_t z[4] = {Z[0][i], Z[1][i], Z[2][i], Z[3][i]};
+                transpose4x4_bytes(z);                                  // z[q] = bytes (steps 4qs..4qs+3) of generator j = 8q + i
+#pragma unroll
+                for (unsigned q = 0; q < 4; q++) tile[wr0 + (8 * q + i) * 256] = z[q];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 2: row (4 k + wv) * 8 + lq = generator (w * 32 + 4 k + wv) * 64 + q8 * 8 + lq, its bytes step0 + 16 c2 ..
+        const unsigned inseg = step0 + c2 * 16;
+        const unsigned long long g0 = (w * 32 + wv) * 64 + q8 * 8 + lq;
+        unsigned long long off = g0 * (unsigned long long)L + inseg;
+        const unsigned long long goff = 256ull * L;
+        if (inseg < L) {
+            if (g0 + 7 * 256 < G && off >= win_lo && off + 7 * goff + 16 <= nbytes) {
+                // every generator of this thread exists and its chunk lies inside the window
+#pragma unroll
+                for (unsigned k = 0; k < 8; k++) {
+                    const u32x4 v = *reinterpret_cast<const u32x4 *>(&tile[rd0 + k * 1024]);
+                    *reinterpret_cast<u32x4 *>(dstw + off) = v;
+                    off += goff;
+                }
+            } else {
+                for (unsigned k = 0; k < 8; k++, off += goff) {
+                    if (g0 + 256ull * k >= G || off >= nbytes) break;
+                    if (off < win_lo) continue;                    // (the window starts on a 16-byte boundary of the stream)
+                    const u32x4 v = *reinterpret_cast<const u32x4 *>(&tile[rd0 + k * 1024]);
+                    if (off + 16 <= nbytes) {
+                        *reinterpret_cast<u32x4 *>(dstw + off) = v;
+                    } else {
+                        const unsigned n = (unsigned)(nbytes - off);
+                        for (unsigned e = 0; e < n; e++) dstw[off + e] = (char)((v[e >> 2] >> (8 * (e & 3))) & 0xff);
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();           // the tile and raw[buf] are free for the next unit
+    }
+}
+
+int unplane_launch(const void *stage, void *dst, uint64_t win_lo, uint64_t nbytes, unsigned L, uint64_t G, unsigned nlanes, hipStream_t st) {
+    if (win_lo & 15) return fail(BBB_EINVAL, "window must start on a 16-byte boundary of the staged stream");
+    if (nbytes == 0) return BBB_OK;
+    int dev = 0, ncu = 256;
+    BBB_HIP(hipGetDevice(&dev));
+    BBB_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    // only the source waves whose generators touch the window: generator g owns [g L, (g + 1) L), wave w generators [2048 w, 2048 (w + 1))
+    const uint64_t seg = (uint64_t)L * 2048;
+    const unsigned w_lo = (unsigned)(win_lo / seg);
+    uint64_t w_hi = (win_lo + nbytes + seg - 1) / seg;
+    if (w_hi > nlanes / 64) w_hi = nlanes / 64;
+    const unsigned w_n = (unsigned)(w_hi - w_lo);
+    const uint64_t nunits = (uint64_t)w_n * ((L + 127) / 128) * 8;
+    uint64_t blocks = (uint64_t)ncu * (uint64_t)env_knob("BBB_UNPLANE_BLOCKS_PER_CU", 1);
+    if (blocks > nunits) blocks = nunits;
+    {
+        static std::mutex mu;
+        static bool attr_set[64] = {false};
+        std::lock_guard<std::mutex> g(mu);
+        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+            BBB_HIP(hipFuncSetAttribute((const void *)unplane_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kUnplaneLds));
+            if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        }
+    }
+    TxFuse none{};
+#ifdef BBB_EXPERIMENTS
+    none.bits = (const uint32_t *)g_exp_awgn_debug;
+#endif
+    hipLaunchKernelGGL(unplane_kernel<false>, dim3((unsigned)blocks), dim3(256), kUnplaneLds, st, (const u32x4 *)stage, (char *)dst,
+                       (unsigned long long)win_lo, (unsigned long long)nbytes, L, (unsigned long long)G, w_lo, w_n, none);
+    BBB_HIP(hipGetLastError());
+    return BBB_OK;
+}
+
 // int8 -> int16 (sign extension), 16 samples per lane: the int16 form of the k = 256 stream is the fast
 // int8 fill followed by this pass
 __global__ void __launch_bounds__(256)

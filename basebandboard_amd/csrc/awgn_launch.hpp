@@ -21,6 +21,11 @@ int awgn512p_fill_launch(const uint32_t *d_planes, int16_t *dst, uint64_t nsampl
 // staged: dst is a staging buffer [L/16 rounds][nlanes * 32 generator slots][16 bytes], to be moved by unstage_launch
 int awgn256_fill_launch(const uint32_t *d_planes, int8_t *dst, uint64_t nsamples, unsigned L, uint64_t G,
                         unsigned nlanes, bool staged, hipStream_t st);
+// PLANES form of the staged stream: the sample kernel leaves the 8 count planes of every step, u32x4 stage[wave][step][half][lane]
+// (nlanes / 64 waves x L steps x 2 KiB), unplane_launch turns them into the byte stream at dst
+int awgn256_planes_launch(const uint32_t *d_planes, void *stage, unsigned L, unsigned nlanes, hipStream_t st);
+// bytes [win_lo, win_lo + nbytes) of the staged stream (generator g owns [g L, (g + 1) L)) go to dst[0 .. nbytes)
+int unplane_launch(const void *stage, void *dst, uint64_t win_lo, uint64_t nbytes, unsigned L, uint64_t G, unsigned nlanes, hipStream_t st);
 // staging buffer [rounds][Gpad][piece bytes] holds a sequential stream, generator g owning [g Lb, (g+1) Lb): its bytes
 // [win_lo, win_lo + nbytes) go to dst[0 .. nbytes)
 int unstage_launch(const void *stg, void *dst, uint64_t win_lo, uint64_t nbytes, unsigned Lb, uint64_t G, uint64_t Gpad,

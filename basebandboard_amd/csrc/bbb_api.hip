@@ -512,6 +512,16 @@ int awgn_fill(bbb_lutopt *h, void *dst, int elem_size, uint64_t nsamples, uint64
     if (rc) return rc;
     if (staged) {
         int slot = 0;
+        if (!ahead && env_knob("BBB_PLANES_FORM", 1)) {
+            // PLANES form (round 3): the sample kernel stores its count planes as they are, the mover transposes them
+            // into bytes (awgn_kernels.hip: awgn256_planes_kernel / unplane_kernel); same staging size
+            rc = staged_fill_with(h, 16, L, nlanes, h->profiling ? &ev : nullptr, from_pf,
+                                  [&](void *stage) { return awgn256_planes_launch(h->d_planes, stage, (unsigned)L, nlanes, h->cs); },
+                                  [&](const void *stage, hipStream_t ys) { return unplane_launch(stage, dst, 0, nsamples, (unsigned)L, G, nlanes, ys); },
+                                  &slot);
+            if (h->profiling) h->prof_pending.push_back(ev);
+            return rc;
+        }
         rc = staged_fill(h, dst, nsamples, 16, L, G, nlanes, h->profiling ? &ev : nullptr, from_pf, [&](void *stage) {
             return awgn256_fill_launch(h->d_planes, (int8_t *)stage, ntotal, (unsigned)L, G, nlanes, true, h->cs);
         }, &slot);

@@ -421,7 +421,11 @@ def generate_packed512(taps):
 
 # (suffix, planes resident in VGPRs at any point) of the parked variants (n = 256 only).  180 is the
 # measured optimum for the sample kernel: above it hipcc adds its own AGPR spills on top
-PARK_VARIANTS = (("", 180),)
+# for the sample kernel with its plane -> byte round end.  The PLANES kernel (round 3: no LDS staging, no round end, hence far
+# fewer other live values) takes 230: 71 parked planes instead of 121, and hipcc adds no spills of its own up to there
+# (budget -> registers / VALU per step: 180 -> 436 / 1185, 200 -> 422 / 1120, 220 -> 432 / 1080, 230 -> 434 / 1060,
+# 240 -> 460 / 1054: the guests beside the kernel need 72 of the 512)
+PARK_VARIANTS = (("", 180), ("_hi", 230))
 
 
 def generate(n, taps):

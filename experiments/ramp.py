@@ -3,6 +3,8 @@ steady state the sample kernel then runs at.  Events on the caller's stream behi
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from basebandboard_amd import _lib as _l
+if os.environ.get('BBB_EXP'): _l.select_build('experiments')
 import basebandboard_amd as bbb
 N = 1_000_000_000
 u = bbb.LUTOPT.shipped(256); u.set_staged(True); g = bbb.CLTGRNG(u)
@@ -12,7 +14,7 @@ for s in range(3):
 torch.cuda.synchronize()
 for idle in (2.0, 0.2, 0.0):
     time.sleep(idle)
-    K = 600
+    K = int(os.environ.get("RAMP_K", "600"))
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
     ev[0].record()
     for s in range(K):

@@ -10,7 +10,7 @@ L = _lib.lib()
 L.bbb_exp_set_awgn_debug.argtypes = [C.c_void_p]; L.bbb_exp_set_awgn_debug.restype = None
 N = 1_000_000_000
 K = 60
-dbg = torch.zeros(K, 5 * 1024, dtype=torch.int64, device="cuda")
+dbg = torch.zeros(K, 8 * 1024, dtype=torch.int64, device="cuda")
 buf = torch.empty(N, dtype=torch.int8, device="cuda")
 u = bbb.LUTOPT.shipped(256); u.set_staged(True); g = bbb.CLTGRNG(u)
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
@@ -42,4 +42,4 @@ def run(tag, idle):
 
 
 run("hot start (sync, then straight on)", 0)
-run("after 1 s idle", 1.0)
+

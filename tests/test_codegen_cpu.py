@@ -37,6 +37,15 @@ extern "C" void step_parked(const uint32_t* a, uint32_t* b, uint32_t* cnt) {
   for (int i = 0; i < LUTOPT256_NPARKED; i++) B[LUTOPT256_PARKED[i]] = PB[LUTOPT256_PARKED[i]];
   memcpy(b, B, sizeof B); memcpy(cnt, Cn, sizeof Cn);
 }
+// the second placement (budget 230, the PLANES kernel's): lutopt256_step_parked_hi with its own parked set
+extern "C" void step_parked_hi(const uint32_t* a, uint32_t* b, uint32_t* cnt) {
+  uint32_t A[NN], PA[NN], B[NN], PB[NN], Cn[LOGN];
+  memcpy(A, a, sizeof A); memcpy(PA, a, sizeof PA);
+  for (int i = 0; i < LUTOPT256_NPARKED_HI; i++) A[LUTOPT256_PARKED_HI[i]] = 0xdeadbeefu;
+  lutopt256_step_parked_hi(A, PA, B, PB, Cn);
+  for (int i = 0; i < LUTOPT256_NPARKED_HI; i++) B[LUTOPT256_PARKED_HI[i]] = PB[LUTOPT256_PARKED_HI[i]];
+  memcpy(b, B, sizeof B); memcpy(cnt, Cn, sizeof Cn);
+}
 #endif
 extern "C" void step_new(const uint32_t* a, uint32_t* b, uint32_t* cnt) {
   uint32_t A[NN], B[NN], Cn[LOGN]; memcpy(A, a, sizeof A); STEPNEWFN(A, B, Cn); memcpy(b, B, sizeof B); memcpy(cnt, Cn, sizeof Cn);
@@ -89,6 +98,9 @@ def test_generated_network_matches_oracle(oracle, tmp_path, n):
             b3, cnt3 = np.zeros(n, dtype=np.uint32), np.zeros(logn, dtype=np.uint32)
             lib.step_parked(P(a), P(b3), P(cnt3))
             assert np.array_equal(b, b3) and np.array_equal(cnt, cnt3)
+            b5, cnt5 = np.zeros(n, dtype=np.uint32), np.zeros(logn, dtype=np.uint32)
+            lib.step_parked_hi(P(a), P(b5), P(cnt5))
+            assert np.array_equal(b, b5) and np.array_equal(cnt, cnt5)
         b4, cnt4 = np.zeros(n, dtype=np.uint32), np.zeros(logn, dtype=np.uint32)
         lib.step_new(P(a), P(b4), P(cnt4))    # cnt4 = sample of the NEW state
         assert np.array_equal(b, b4)
