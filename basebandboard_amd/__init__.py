@@ -4,7 +4,7 @@ fused BPSK bit-error trial, and the pulse shaper / transmitter output stream.  C
 mirror the reference's Python interface (gateware/bbb/rng.py, prbs.py, bitshaper.py, tx.py, rx.py).
 """
 from .prbs import PRBS, PRBSErrorDetector, TAPS          # noqa: F401
-from .rng import CLTGRNG, LUTOPT                        # noqa: F401
+from .rng import CLTGRNG, LUTOPT, SampleStream          # noqa: F401
 from .channel import Trial, run_trials, run_trials_into, sweep, gpu_runner, shard  # noqa: F401
 from .bitshaper import PRBSShaper, Pulser                # noqa: F401
 from .tx import TX                                       # noqa: F401

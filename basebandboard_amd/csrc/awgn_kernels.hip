@@ -231,6 +231,21 @@ struct TxFuse {
     uint32_t last_word;       // index of the last 32-bit word of the buffer that may be read
 };
 
+// fills a TxFuse from a call's arguments (the fused one-kernel transmitter and the shaping mover share it)
+static TxFuse make_txfuse(const int16_t *coeffs, const uint32_t *d_bits, uint32_t nwords32, uint32_t rel_base, uint32_t c0, int noise_var,
+                          int bit_en, int use_bits) {
+    TxFuse tx;
+    for (int i = 0; i < 64; i++) tx.coeffs[i] = coeffs[i];
+    tx.bits = d_bits;
+    tx.rel_base = rel_base;
+    tx.c0 = c0;
+    tx.noise_var = noise_var;
+    tx.bit_en = bit_en;
+    tx.use_bits = use_bits && nwords32 >= 2;
+    tx.last_word = nwords32 ? nwords32 - 1 : 1;
+    return tx;
+}
+
 // (mask & a) | (~mask & b) with a wave-uniform mask: ONE V_BFI_B32 (left to itself hipcc turns the uniform mask into
 // s_not + v_and + v_and_or)
 __device__ __forceinline__ uint32_t bfi_uniform(uint32_t mask, uint32_t a, uint32_t b) {
@@ -242,12 +257,8 @@ __device__ __forceinline__ uint32_t bfi_uniform(uint32_t mask, uint32_t a, uint3
 typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
 typedef int16_t i16x2 __attribute__((ext_vector_type(2)));
 
-// STAGED: the pieces go to a staging buffer laid out [round][generator slot][piece] instead of their final place
-// g L + 16 r: a store instruction then writes 64 consecutive pieces (full lines) where the final layout makes it
-// touch 64 different lines, L bytes apart -- 62.5 M scattered 16-byte pieces per 1e9 samples, which cost one DRAM
-// row activation each and bound the kernel together with its arithmetic.  unstage_kernel moves the pieces to
-// their final place with full-line reads AND writes, beside the next fill's arithmetic (bbb_api.hip).
-template <bool TX, bool STAGED>
+// (The two-kernel "staged" form of the stream no longer goes through this kernel: awgn256_planes_kernel below.)
+template <bool TX>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 awgn256_kernel(const uint32_t *__restrict planes, void *__restrict dst_, unsigned long long nsamples,
                unsigned L, unsigned long long G, unsigned nlanes, TxFuse tx) {
@@ -371,19 +382,10 @@ awgn256_kernel(const uint32_t *__restrict planes, void *__restrict dst_, unsigne
                 const unsigned long long g = gen_index(wave, lane, 8 * q + i);
                 const unsigned long long off = g * L + (unsigned long long)r * 16;
                 if (!FULL && !(g < G && off < nsamples)) continue;   // (the q loop)
-                const unsigned long long slot = (unsigned long long)r * ((unsigned long long)nlanes * 32) + g;   // STAGED
                 if (!TX) {
                     int8_t *dst = (int8_t *)dst_;
                     const u32x4 v = {o[0][q], o[1][q], o[2][q], o[3][q]};
-                    if (STAGED) {
-                        // non-temporal: written once, read once by the mover a fill later (same box, three alternations:
-                        // 775-783 Gsample/s against 761-773 with plain stores)
-#if defined(BBB_EXPERIMENTS) && defined(BBB_STAGE_PLAIN_STORE)
-                        reinterpret_cast<u32x4 *>(dst_)[slot] = v;
-#else
-                        __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(dst_) + slot);
-#endif
-                    } else if (FULL || off + 16 <= nsamples) {
+                    if (FULL || off + 16 <= nsamples) {
                         *reinterpret_cast<u32x4 *>(dst + off) = v;
                     } else {
                         const unsigned n = (unsigned)(nsamples - off);
@@ -408,16 +410,7 @@ awgn256_kernel(const uint32_t *__restrict planes, void *__restrict dst_, unsigne
                         x[2 * w] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(i16x2, m01) >> 4);
                         x[2 * w + 1] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(i16x2, m23) >> 4);
                     }
-                    if (STAGED) {
-                        const u32x4 lo = {x[0], x[1], x[2], x[3]}, hi = {x[4], x[5], x[6], x[7]};
-#if defined(BBB_EXPERIMENTS) && defined(BBB_STAGE_PLAIN_STORE)
-                        reinterpret_cast<u32x4 *>(dst_)[2 * slot] = lo;
-                        reinterpret_cast<u32x4 *>(dst_)[2 * slot + 1] = hi;
-#else
-                        __builtin_nontemporal_store(lo, reinterpret_cast<u32x4 *>(dst_) + 2 * slot);
-                        __builtin_nontemporal_store(hi, reinterpret_cast<u32x4 *>(dst_) + 2 * slot + 1);
-#endif
-                    } else if (FULL || off + 16 <= nsamples) {
+                    if (FULL || off + 16 <= nsamples) {
                         const u32x4 lo = {x[0], x[1], x[2], x[3]}, hi = {x[4], x[5], x[6], x[7]};
                         reinterpret_cast<u32x4 *>(dst + off)[0] = lo;
                         reinterpret_cast<u32x4 *>(dst + off)[1] = hi;
@@ -475,141 +468,6 @@ awgn256_kernel(const uint32_t *__restrict planes, void *__restrict dst_, unsigne
         ((unsigned long long *)tx.bits)[4 * 1024 + wave] = dbg_round_end;       // cycles inside the round ends
     }
 #endif
-}
-
-// Staging buffer [round][generator slot][PIECE bytes] -> the sequential stream (generator g owns bytes [g Lb, (g+1) Lb)).
-// A wave moves a tile of 8 generators x RT rounds, 16 bytes per lane: lanes that share a round read 128+ consecutive
-// bytes of the staging buffer, lanes that share a generator write 128 consecutive bytes of its segment -- full lines on
-// both sides.  One wave per group of 8 generators, looping over the rounds.
-// Residency: this kernel runs beside the NEXT fill's sample kernel, whose waves need 416 of a SIMD's 512 registers and
-// 32 of a CU's 160 KiB of LDS each and must ALL be resident at once (one generation, static partition).  A grid of many
-// small blocks would keep refilling every freed slot and starve those big waves (measured: the two kernels then run one
-// after the other).  So the mover is persistent and narrow: one block per CU -- two waves for the int8 stream, four for the int16 TX stream:
-// see unstage_launch -- (<= 96 registers per lane, and
-// an unused 32 KiB of dynamic LDS so that no second block fits beside four sample-kernel waves), each wave looping over
-// its share of the generator groups with 16 loads of 16 bytes in flight per lane.
-// the mover's accesses: loads non-temporal (the staging buffer is read exactly once; same box, three alternations: 777-787
-// Gsample/s against 768-780 with plain loads); experiments build: -DBBB_UNSTAGE_PLAIN_LOAD, -DBBB_UNSTAGE_NT_STORE
-__device__ __forceinline__ u32x4 mover_load(const char *p) {
-#if defined(BBB_EXPERIMENTS) && defined(BBB_UNSTAGE_PLAIN_LOAD)
-    return *reinterpret_cast<const u32x4 *>(p);
-#else
-    return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
-#endif
-}
-__device__ __forceinline__ void mover_store(char *p, const u32x4 &v) {
-#if defined(BBB_EXPERIMENTS) && defined(BBB_UNSTAGE_NT_STORE)
-    __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p));
-#else
-    *reinterpret_cast<u32x4 *>(p) = v;
-#endif
-}
-
-constexpr unsigned kUnstagePause = 0;      // s_sleep(4) repeats after every tile of a trip (experiments: BBB_UNSTAGE_PAUSE)
-template <int PIECE>
-__global__ void __launch_bounds__(256, 5)
-unstage_kernel(const char *__restrict stg, char *__restrict dst_, unsigned long long win_lo, unsigned long long nbytes_,
-               unsigned Lb, unsigned long long G, unsigned long long Gpad, unsigned rounds, unsigned pause) {
-    // the staged stream may be longer than what this call delivers (look-ahead: two fills' worth per sample kernel):
-    // bytes [win_lo, win_lo + nbytes_) of it go to dst_[0 .. nbytes_).  Only generator groups that touch the window.
-    char *const dst = dst_ - win_lo;                       // indexed by stream offset below, within [win_lo, nbytes)
-    const unsigned long long nbytes = win_lo + nbytes_;
-    const unsigned long long trip0 = win_lo / ((unsigned long long)Lb * 32);
-    constexpr unsigned CP = PIECE / 16;          // 16-byte chunks per piece
-    constexpr unsigned RT = 8 / CP;              // rounds per tile
-    constexpr unsigned NG = 4;                   // groups of 8 generators per trip: with 4 round tiles, 16 loads in flight per lane
-    const unsigned lane = threadIdx.x & 63;
-    const unsigned long long wave0 = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const unsigned long long nwaves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
-    const unsigned c = lane % CP, m = lane / CP, gl = m & 7, rl = m >> 3;
-    const unsigned long long sstride = (unsigned long long)RT * Gpad * PIECE;
-    constexpr unsigned dstride = RT * PIECE;
-    const unsigned long long gstride_src = 8ull * PIECE, gstride_dst = 8ull * Lb;
-    unsigned long long ntrips = (G + 8 * NG - 1) / (8 * NG);
-    {
-        const unsigned long long last = (nbytes + (unsigned long long)Lb * 32 - 1) / ((unsigned long long)Lb * 32);
-        if (last < ntrips) ntrips = last;
-    }
-    for (unsigned long long trip = trip0 + wave0; trip < ntrips; trip += nwaves) {
-        const unsigned long long g0 = trip * (8 * NG) + gl;
-        if (g0 >= G) continue;
-        // all 64-bit address arithmetic once per trip; the loops below only add (wave-uniform) strides
-        const char *src0 = stg + ((unsigned long long)rl * Gpad + g0) * PIECE + c * 16;
-        const unsigned long long seg0 = g0 * (unsigned long long)Lb;
-        char *out0 = dst + seg0 + rl * PIECE + c * 16;
-        // fast path: all NG groups exist and end inside the request -- no bounds inside the loops
-        if (g0 + 8 * (NG - 1) < G && seg0 >= win_lo && seg0 + (NG - 1) * gstride_dst + Lb <= nbytes) {
-            unsigned r = rl;
-            for (; r + 3 * RT < rounds; r += 4 * RT) {
-                u32x4 v[NG][4];
-#pragma unroll
-                for (unsigned k = 0; k < NG; k++)
-#pragma unroll
-                    for (unsigned t = 0; t < 4; t++) v[k][t] = mover_load(src0 + k * gstride_src + t * sstride);
-#pragma unroll
-                for (unsigned k = 0; k < NG; k++)
-#pragma unroll
-                    for (unsigned t = 0; t < 4; t++) mover_store(out0 + k * gstride_dst + t * dstride, v[k][t]);
-                src0 += 4 * sstride;
-                out0 += 4 * dstride;
-                for (unsigned z = 0; z < pause; z++) __builtin_amdgcn_s_sleep(4);      // 256 cycles each
-            }
-            for (; r < rounds; r += RT) {
-                u32x4 v[NG];
-#pragma unroll
-                for (unsigned k = 0; k < NG; k++) v[k] = mover_load(src0 + k * gstride_src);
-#pragma unroll
-                for (unsigned k = 0; k < NG; k++) mover_store(out0 + k * gstride_dst, v[k]);
-                src0 += sstride;
-                out0 += dstride;
-            }
-            continue;
-        }
-        for (unsigned k = 0; k < NG; k++) {       // the last groups: generators may be missing, the request may end inside
-            const unsigned long long g = g0 + 8ull * k;
-            if (g >= G) break;
-            const unsigned long long seg = g * (unsigned long long)Lb;
-            const char *src = src0 + k * gstride_src;
-            for (unsigned r = rl; r < rounds; r += RT, src += sstride) {
-                const unsigned long long off = seg + (unsigned long long)r * PIECE + c * 16;
-                if (off >= nbytes) break;
-                if (off < win_lo) continue;                // (win_lo is a multiple of 16: whole chunks)
-                const u32x4 v = *reinterpret_cast<const u32x4 *>(src);
-                if (off + 16 <= nbytes) {
-                    *reinterpret_cast<u32x4 *>(dst + off) = v;
-                } else {
-                    const unsigned n = (unsigned)(nbytes - off);
-                    for (unsigned e = 0; e < n; e++) dst[off + e] = (char)((v[e >> 2] >> (8 * (e & 3))) & 0xff);
-                }
-            }
-        }
-    }
-}
-
-int unstage_launch(const void *stg, void *dst, uint64_t win_lo, uint64_t nbytes, unsigned Lb, uint64_t G, uint64_t Gpad,
-                   unsigned rounds, int piece, hipStream_t st) {
-    if (win_lo & 15) return fail(BBB_EINVAL, "window must start on a 16-byte boundary of the staged stream");
-    int dev = 0, ncu = 256;
-    BBB_HIP(hipGetDevice(&dev));
-    BBB_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-    const uint64_t ntrips = (G + 31) / 32;
-    uint64_t blocks = (uint64_t)ncu * (uint64_t)env_knob("BBB_UNSTAGE_BLOCKS_PER_CU", 1);
-    if (env_knob("BBB_UNSTAGE_BLOCKS", 0) > 0) blocks = (uint64_t)env_knob("BBB_UNSTAGE_BLOCKS", 0);
-    if (blocks > (ntrips + 3) / 4) blocks = (ntrips + 3) / 4;
-    const size_t lds = static_cast<size_t>(env_knob("BBB_UNSTAGE_LDS_KB", 0)) * 1024;
-    // two waves per CU for the int8 stream: with four the mover finishes sooner (0.45 against ~0.8 ms per 1e9) but costs the
-    // sample kernel more than it is worth -- same box, alternating: 767-773 Gsample/s with 128 threads, 744-757 with 192,
-    // 731-739 with 256, 650 with 64 (the mover then takes longer than the fill it runs beside)
-    const unsigned threads = (unsigned)(piece == 16 ? env_knob("BBB_UNSTAGE_THREADS", 128) : env_knob("BBB_UNSTAGE_THREADS32", 256));
-    const unsigned pause = (unsigned)env_knob("BBB_UNSTAGE_PAUSE", kUnstagePause);
-    if (piece == 16)
-        hipLaunchKernelGGL(unstage_kernel<16>, dim3((unsigned)blocks), dim3(threads), lds, st, (const char *)stg, (char *)dst,
-                           (unsigned long long)win_lo, (unsigned long long)nbytes, Lb, (unsigned long long)G, (unsigned long long)Gpad, rounds, pause);
-    else
-        hipLaunchKernelGGL(unstage_kernel<32>, dim3((unsigned)blocks), dim3(threads), lds, st, (const char *)stg, (char *)dst,
-                           (unsigned long long)win_lo, (unsigned long long)nbytes, Lb, (unsigned long long)G, (unsigned long long)Gpad, rounds, pause);
-    BBB_HIP(hipGetLastError());
-    return BBB_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -697,7 +555,7 @@ int awgn256_planes_launch(const uint32_t *d_planes, void *stage, unsigned L, uns
 // LDS (dynamic, ONE array: 2 x 32 KiB raw + 32 KiB tile): the DMA of unit u+1 is in flight while unit u is processed;
 // raw barriers and counted vmcnt (a __syncthreads() would drain the DMA: cdna_hip_programming.md, "Pipelining across barriers").
 // One block of four waves per CU, persistent over its share of the units.
-constexpr unsigned kUnplaneRaw = 32 * 1024, kUnplaneLds = 3 * 32 * 1024;
+constexpr unsigned kUnplaneRaw = 32 * 1024, kUnplaneLds = 3 * 32 * 1024, kUnplaneLdsTx = kUnplaneLds + 256 * 8 * 2;
 
 template <bool TXM>
 __global__ void __launch_bounds__(256, 7)      // <= 72 registers: a wave of this kernel must fit beside the sample kernel's (<= 440 of 512)
@@ -721,6 +579,28 @@ unplane_kernel(const u32x4 *__restrict stage, char *__restrict dst, unsigned lon
     const unsigned lq = (tid >> 3) & 7, c2 = tid & 7;
     const unsigned rd0 = ((tid >> 6) * 8 + lq) * 32 + ((c2 ^ (2 * ((lq >> 1) & 3))) << 2);
     uint32_t *const tile = lds + 2 * (kUnplaneRaw / 4);
+    // TXM (the SHAPING mover of bbb_tx_fill_i16 on a staged handle): every 16-byte piece of noise leaves as the 16 int16
+    // samples x = wrap12(bit_en shaped + g noise_var) (tx.py:75-81), the arithmetic of the fused kernel's round end (TxFuse, the
+    // table TT and the window / select / multiply-add scheme described above awgn256_kernel) done here, by the guest
+    uint16_t *const TT = reinterpret_cast<uint16_t *>(lds + kUnplaneLds / 4);
+    uint32_t selmask[4] = {0, 0, 0, 0};
+    if (TXM) {
+        for (int e = (int)tid; e < 256 * 8; e += 256) {
+            const int q = e >> 3, j = e & 7, ph = (int)((tx.c0 + (unsigned)j) & 7u);
+            int sum = 0;
+#pragma unroll
+            for (int idx = 0; idx < 8; idx++) {
+                const int c = tx.coeffs[8 * idx + ph];
+                sum += ((q >> (7 - idx)) & 1) ? c : -c;
+            }
+            const int shaped = tx.bit_en ? ((int)((unsigned)sum << 20) >> 20) : 0;
+            TT[e] = (uint16_t)((unsigned)((shaped - 128 * tx.noise_var) * 16) & 0xffffu);
+        }
+#pragma unroll
+        for (int d = 0; d < 4; d++)
+            selmask[d] = (tx.c0 + 2u * (unsigned)d < 8u ? 0x0000ffffu : 0u) | (tx.c0 + 2u * (unsigned)d + 1u < 8u ? 0xffff0000u : 0u);
+        // (made visible to the other waves by the first barrier of the unit loop; no DMA touches this part of the LDS)
+    }
 #ifdef BBB_EXPERIMENTS
     if (!TXM && tx.bits && lane == 0) {      // which SIMD this mover wave sits on, and when it ran
         unsigned hwid, xcc;
@@ -788,7 +668,7 @@ unplane_kernel(const u32x4 *__restrict stage, char *__restrict dst, unsigned lon
         const unsigned long long g0 = (w * 32 + wv) * 64 + q8 * 8 + lq;
         unsigned long long off = g0 * (unsigned long long)L + inseg;
         const unsigned long long goff = 256ull * L;
-        if (inseg < L) {
+        if (!TXM && inseg < L) {
             if (g0 + 7 * 256 < G && off >= win_lo && off + 7 * goff + 16 <= nbytes) {
                 // every generator of this thread exists and its chunk lies inside the window
 #pragma unroll
@@ -811,12 +691,69 @@ unplane_kernel(const u32x4 *__restrict stage, char *__restrict dst, unsigned lon
                 }
             }
         }
+        if (TXM && inseg < L) {
+            // positions are relative to the window: sample p of this call = stream offset win_lo + p; dst holds int16
+            int16_t *const dst16 = reinterpret_cast<int16_t *>(dst);
+            const u16x2 nv16 = {(uint16_t)(tx.noise_var * 16), (uint16_t)(tx.noise_var * 16)};
+            // the data windows of this thread's 8 pieces first (8 loads in flight), then the shaping
+            uint32_t win[8];
+#pragma unroll
+            for (unsigned k = 0; k < 8; k++) {
+                const unsigned long long o = off + k * goff;
+                win[k] = 0;
+                if (g0 + 256ull * k < G && o >= win_lo && o < nbytes && tx.use_bits) {
+                    const uint32_t rel = ((uint32_t)(o - win_lo) >> 3) + tx.rel_base;           // fits 32 bits (host check)
+                    const uint32_t byte = min(rel >> 3, tx.last_word * 4u - 4u);
+                    typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+                    win[k] = *reinterpret_cast<const u32_unaligned *>(reinterpret_cast<const char *>(tx.bits) + byte);
+                }
+            }
+#pragma unroll
+            for (unsigned k = 0; k < 8; k++) {
+                const unsigned long long o = off + k * goff;
+                if (g0 + 256ull * k >= G || o >= nbytes) break;
+                if (o < win_lo) continue;
+                const unsigned long long p0 = o - win_lo;                                        // first sample of the piece, in this call
+                const uint32_t rel = ((uint32_t)p0 >> 3) + tx.rel_base;
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(&tile[rd0 + k * 1024]);
+                // the piece's 10-bit data window (bit j = data bit M0 - 7 + j), as in the fused kernel
+                const uint32_t Q4 = ((win[k] >> (rel & 7u)) & 0x3ffu) << 4;
+                const char *tt = reinterpret_cast<const char *>(TT);
+                const u32x4 A = *reinterpret_cast<const u32x4 *>(tt + (Q4 & 0xff0u));
+                const u32x4 B = *reinterpret_cast<const u32x4 *>(tt + ((Q4 >> 1) & 0xff0u));
+                const u32x4 C = *reinterpret_cast<const u32x4 *>(tt + ((Q4 >> 2) & 0xff0u));
+                uint32_t x[8];
+#pragma unroll
+                for (int w4 = 0; w4 < 4; w4++) {
+                    const uint32_t ub = v[w4] ^ 0x80808080u;                          // bytes g + 128 of samples 4w .. 4w+3
+                    const uint32_t u01 = __builtin_amdgcn_perm(0u, ub, 0x0c010c00u);  // [u0, 0, u1, 0]
+                    const uint32_t u23 = __builtin_amdgcn_perm(0u, ub, 0x0c030c02u);
+                    const int d0 = (2 * w4) & 3, d1 = (2 * w4 + 1) & 3;
+                    const uint32_t s01 = w4 < 2 ? bfi_uniform(selmask[d0], A[d0], B[d0]) : bfi_uniform(selmask[d0], B[d0], C[d0]);
+                    const uint32_t s23 = w4 < 2 ? bfi_uniform(selmask[d1], A[d1], B[d1]) : bfi_uniform(selmask[d1], B[d1], C[d1]);
+                    const u16x2 m01 = __builtin_bit_cast(u16x2, u01) * nv16 + __builtin_bit_cast(u16x2, s01);
+                    const u16x2 m23 = __builtin_bit_cast(u16x2, u23) * nv16 + __builtin_bit_cast(u16x2, s23);
+                    x[2 * w4] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(i16x2, m01) >> 4);
+                    x[2 * w4 + 1] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(i16x2, m23) >> 4);
+                }
+                int16_t *out = dst16 + p0;
+                if (o + 16 <= nbytes) {
+                    const u32x4 lo = {x[0], x[1], x[2], x[3]}, hi = {x[4], x[5], x[6], x[7]};
+                    reinterpret_cast<u32x4 *>(out)[0] = lo;
+                    reinterpret_cast<u32x4 *>(out)[1] = hi;
+                } else {
+                    const unsigned n = (unsigned)(nbytes - o);
+                    for (unsigned e = 0; e < n; e++) out[e] = (int16_t)((x[e >> 1] >> (16 * (e & 1))) & 0xffff);
+                }
+            }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();           // the tile and raw[buf] are free for the next unit
     }
 }
 
-int unplane_launch(const void *stage, void *dst, uint64_t win_lo, uint64_t nbytes, unsigned L, uint64_t G, unsigned nlanes, hipStream_t st) {
+static int unplane_launch_with(const void *stage, void *dst, uint64_t win_lo, uint64_t nbytes, unsigned L, uint64_t G, unsigned nlanes,
+                               const TxFuse *tx, hipStream_t st) {
     if (win_lo & 15) return fail(BBB_EINVAL, "window must start on a 16-byte boundary of the staged stream");
     if (nbytes == 0) return BBB_OK;
     int dev = 0, ncu = 256;
@@ -837,17 +774,34 @@ int unplane_launch(const void *stage, void *dst, uint64_t win_lo, uint64_t nbyte
         std::lock_guard<std::mutex> g(mu);
         if (dev < 0 || dev >= 64 || !attr_set[dev]) {
             BBB_HIP(hipFuncSetAttribute((const void *)unplane_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kUnplaneLds));
+            BBB_HIP(hipFuncSetAttribute((const void *)unplane_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kUnplaneLdsTx));
             if (dev >= 0 && dev < 64) attr_set[dev] = true;
         }
     }
-    TxFuse none{};
+    if (tx) {
+        hipLaunchKernelGGL(unplane_kernel<true>, dim3((unsigned)blocks), dim3(256), kUnplaneLdsTx, st, (const u32x4 *)stage, (char *)dst,
+                           (unsigned long long)win_lo, (unsigned long long)nbytes, L, (unsigned long long)G, w_lo, w_n, *tx);
+    } else {
+        TxFuse none{};
 #ifdef BBB_EXPERIMENTS
-    none.bits = (const uint32_t *)g_exp_awgn_debug;
+        none.bits = (const uint32_t *)g_exp_awgn_debug;
 #endif
-    hipLaunchKernelGGL(unplane_kernel<false>, dim3((unsigned)blocks), dim3(256), kUnplaneLds, st, (const u32x4 *)stage, (char *)dst,
-                       (unsigned long long)win_lo, (unsigned long long)nbytes, L, (unsigned long long)G, w_lo, w_n, none);
+        hipLaunchKernelGGL(unplane_kernel<false>, dim3((unsigned)blocks), dim3(256), kUnplaneLds, st, (const u32x4 *)stage, (char *)dst,
+                           (unsigned long long)win_lo, (unsigned long long)nbytes, L, (unsigned long long)G, w_lo, w_n, none);
+    }
     BBB_HIP(hipGetLastError());
     return BBB_OK;
+}
+
+int unplane_launch(const void *stage, void *dst, uint64_t win_lo, uint64_t nbytes, unsigned L, uint64_t G, unsigned nlanes, hipStream_t st) {
+    return unplane_launch_with(stage, dst, win_lo, nbytes, L, G, nlanes, nullptr, st);
+}
+
+int unplane_tx_launch(const void *stage, int16_t *dst, uint64_t win_lo, uint64_t nsamples, unsigned L, uint64_t G, unsigned nlanes,
+                      const int16_t *coeffs, const uint32_t *d_bits, uint32_t nwords32, uint32_t rel_base, uint32_t c0, int noise_var, int bit_en,
+                      int use_bits, hipStream_t st) {
+    const TxFuse tx = make_txfuse(coeffs, d_bits, nwords32, rel_base, c0, noise_var, bit_en, use_bits);
+    return unplane_launch_with(stage, dst, win_lo, nsamples, L, G, nlanes, &tx, st);
 }
 
 // int8 -> int16 (sign extension), 16 samples per lane: the int16 form of the k = 256 stream is the fast
@@ -1040,18 +994,14 @@ int awgn_seed_launch(int k, const uint32_t *d_tabs, const uint32_t *s16, uint64_
 }
 
 int awgn256_fill_launch(const uint32_t *d_planes, int8_t *dst, uint64_t nsamples, unsigned L, uint64_t G,
-                        unsigned nlanes, bool staged, hipStream_t st) {
+                        unsigned nlanes, hipStream_t st) {
     const unsigned nwaves = nlanes / 64;
     TxFuse none{};
 #ifdef BBB_EXPERIMENTS
     none.bits = (const uint32_t *)g_exp_awgn_debug;      // per-wave time stamps, see the kernel
 #endif
-    if (staged)
-        hipLaunchKernelGGL((awgn256_kernel<false, true>), dim3(nwaves), dim3(64), 0, st, d_planes, (void *)dst, (unsigned long long)nsamples, L,
-                           (unsigned long long)G, nlanes, none);
-    else
-        hipLaunchKernelGGL((awgn256_kernel<false, false>), dim3(nwaves), dim3(64), 0, st, d_planes, (void *)dst, (unsigned long long)nsamples, L,
-                           (unsigned long long)G, nlanes, none);
+    hipLaunchKernelGGL((awgn256_kernel<false>), dim3(nwaves), dim3(64), 0, st, d_planes, (void *)dst, (unsigned long long)nsamples, L,
+                       (unsigned long long)G, nlanes, none);
     BBB_HIP(hipGetLastError());
     return BBB_OK;
 }
@@ -1077,160 +1027,12 @@ int pulse_bits_launch(uint64_t *dst, int64_t m_first, uint64_t nwords, hipStream
     return BBB_OK;
 }
 
-// The transmitter as "noise kernel + SHAPING mover" (bbb_tx_fill_i16 on a staged handle): the plain int8 sample kernel
-// fills the staging buffer [round][generator slot][16 bytes] as for the noise stream, and this mover turns every piece into
-// the 16 int16 samples x = wrap12(bit_en shaped + g noise_var) at their final place while it moves them -- the arithmetic of
-// the fused kernel's round end (TxFuse, the table TT and the window / select / multiply-add scheme described above
-// awgn256_kernel), done by a guest with a few waves per CU instead of by the kernel that owns every SIMD's issue slots.
-// 4 B of HBM traffic per sample (1 written + 1 read as noise, 2 written as output) against 6 for the fused staged form,
-// the sample kernel keeps its 32 KiB of LDS per wave (so the two-piece seeding fits beside it), and it is the plain noise
-// kernel's 1.2 ms per 1e9 samples that bounds the call, not the 1.54 of the fused one.
-// Tile as in unstage_kernel: 8 generators x 8 rounds per wave and trip, lane = (round, generator); a lane reads 16 bytes
-// (lanes of a round: 128 consecutive bytes) and writes 32 (lanes of a generator: 256 consecutive bytes).
-template <int TILES>
-__global__ void __launch_bounds__(256, 5)
-tx_unstage_kernel(const char *__restrict stg, int16_t *__restrict dst, unsigned long long nsamples, unsigned L,
-                  unsigned long long G, unsigned long long Gpad, unsigned rounds, TxFuse tx, unsigned pause) {
-    __shared__ __attribute__((aligned(16))) uint16_t TT[256 * 8];
-    for (int e = (int)threadIdx.x; e < 256 * 8; e += (int)blockDim.x) {
-        const int q = e >> 3, j = e & 7, ph = (int)((tx.c0 + (unsigned)j) & 7u);
-        int sum = 0;
-#pragma unroll
-        for (int idx = 0; idx < 8; idx++) {
-            const int c = tx.coeffs[8 * idx + ph];
-            sum += ((q >> (7 - idx)) & 1) ? c : -c;
-        }
-        const int shaped = tx.bit_en ? ((int)((unsigned)sum << 20) >> 20) : 0;
-        TT[e] = (uint16_t)((unsigned)((shaped - 128 * tx.noise_var) * 16) & 0xffffu);
-    }
-    uint32_t selmask[4];
-#pragma unroll
-    for (int d = 0; d < 4; d++)
-        selmask[d] = (tx.c0 + 2u * (unsigned)d < 8u ? 0x0000ffffu : 0u) | (tx.c0 + 2u * (unsigned)d + 1u < 8u ? 0xffff0000u : 0u);
-    __syncthreads();
-    const u16x2 nv16 = {(uint16_t)(tx.noise_var * 16), (uint16_t)(tx.noise_var * 16)};
-    const unsigned lane = threadIdx.x & 63;
-    const unsigned long long wave0 = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const unsigned long long nwaves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
-    const unsigned gl = lane & 7, rl = lane >> 3;
-    const unsigned long long ntrips = (G + 7) / 8;
-    for (unsigned long long trip = wave0; trip < ntrips; trip += nwaves) {
-        const unsigned long long g = trip * 8 + gl;
-        if (g >= G) continue;
-        const char *src = stg + ((unsigned long long)rl * Gpad + g) * 16;
-        const unsigned long long seg = g * (unsigned long long)L;
-        const unsigned long long rstride = 8ull * Gpad * 16;
-        // four tiles (32 rounds) per pass: their noise pieces and data windows are requested together, then shaped one
-        // after the other -- with ~80 instructions per piece a single load in flight would leave the wave waiting on memory
-        for (unsigned r0 = rl; r0 < rounds; r0 += 8 * TILES, src += TILES * rstride) {
-            for (unsigned z = 0; z < pause; z++) __builtin_amdgcn_s_sleep(4);
-            u32x4 v[TILES];
-            uint32_t win[TILES], relv[TILES];
-#pragma unroll
-            for (int t = 0; t < TILES; t++) {
-                const unsigned r = r0 + 8u * (unsigned)t;
-                const unsigned long long off = seg + (unsigned long long)r * 16;
-                v[t] = (u32x4){0u, 0u, 0u, 0u};
-                win[t] = 0;
-                relv[t] = ((uint32_t)off >> 3) + tx.rel_base;                                  // fits 32 bits (host check)
-                if (r < rounds && off < nsamples) {
-                    v[t] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + (unsigned long long)t * rstride));
-                    if (tx.use_bits) {
-                        const uint32_t byte = min(relv[t] >> 3, tx.last_word * 4u - 4u);
-                        typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
-                        win[t] = *reinterpret_cast<const u32_unaligned *>(reinterpret_cast<const char *>(tx.bits) + byte);
-                    }
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < TILES; t++) {
-                const unsigned r = r0 + 8u * (unsigned)t;
-                const unsigned long long off = seg + (unsigned long long)r * 16;                  // first sample of the piece
-                if (r >= rounds || off >= nsamples) break;
-                // the piece's 10-bit data window (bit j = data bit M0 - 7 + j), as in the fused kernel
-                const uint32_t Q4 = ((win[t] >> (relv[t] & 7u)) & 0x3ffu) << 4;
-                const char *tt = reinterpret_cast<const char *>(TT);
-                const u32x4 A = *reinterpret_cast<const u32x4 *>(tt + (Q4 & 0xff0u));
-                const u32x4 B = *reinterpret_cast<const u32x4 *>(tt + ((Q4 >> 1) & 0xff0u));
-                const u32x4 C = *reinterpret_cast<const u32x4 *>(tt + ((Q4 >> 2) & 0xff0u));
-                uint32_t x[8];
-#pragma unroll
-                for (int w = 0; w < 4; w++) {
-                    const uint32_t u = v[t][w] ^ 0x80808080u;                        // bytes g + 128 of samples 4w .. 4w+3
-                    const uint32_t u01 = __builtin_amdgcn_perm(0u, u, 0x0c010c00u);  // [u0, 0, u1, 0]
-                    const uint32_t u23 = __builtin_amdgcn_perm(0u, u, 0x0c030c02u);
-                    const int d0 = (2 * w) & 3, d1 = (2 * w + 1) & 3;
-                    const uint32_t s01 = w < 2 ? bfi_uniform(selmask[d0], A[d0], B[d0]) : bfi_uniform(selmask[d0], B[d0], C[d0]);
-                    const uint32_t s23 = w < 2 ? bfi_uniform(selmask[d1], A[d1], B[d1]) : bfi_uniform(selmask[d1], B[d1], C[d1]);
-                    const u16x2 m01 = __builtin_bit_cast(u16x2, u01) * nv16 + __builtin_bit_cast(u16x2, s01);
-                    const u16x2 m23 = __builtin_bit_cast(u16x2, u23) * nv16 + __builtin_bit_cast(u16x2, s23);
-                    x[2 * w] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(i16x2, m01) >> 4);
-                    x[2 * w + 1] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(i16x2, m23) >> 4);
-                }
-                int16_t *out = dst + off;
-                if (off + 16 <= nsamples) {
-                    const u32x4 lo = {x[0], x[1], x[2], x[3]}, hi = {x[4], x[5], x[6], x[7]};
-                    reinterpret_cast<u32x4 *>(out)[0] = lo;
-                    reinterpret_cast<u32x4 *>(out)[1] = hi;
-                } else {
-                    const unsigned n = (unsigned)(nsamples - off);
-                    for (unsigned e = 0; e < n; e++) out[e] = (int16_t)((x[e >> 1] >> (16 * (e & 1))) & 0xffff);
-                }
-            }
-        }
-    }
-}
-
-int tx_unstage_launch(const void *stg, int16_t *dst, uint64_t nsamples, unsigned L, uint64_t G, uint64_t Gpad, const int16_t *coeffs,
-                      const uint32_t *d_bits, uint32_t nwords32, uint32_t rel_base, uint32_t c0, int noise_var, int bit_en, int use_bits,
-                      hipStream_t st) {
-    TxFuse tx;
-    for (int i = 0; i < 64; i++) tx.coeffs[i] = coeffs[i];
-    tx.bits = d_bits;
-    tx.rel_base = rel_base;
-    tx.c0 = c0;
-    tx.noise_var = noise_var;
-    tx.bit_en = bit_en;
-    tx.use_bits = use_bits && nwords32 >= 2;
-    tx.last_word = nwords32 ? nwords32 - 1 : 1;
-    int dev = 0, ncu = 256;
-    BBB_HIP(hipGetDevice(&dev));
-    BBB_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-    const uint64_t ntrips = (G + 7) / 8;
-    // three waves per CU: same box, alternating, 1e9 samples per call: 612-615 Gsample/s against 546-570 with four and 510
-    // with two (the mover then takes longer than the noise kernel it runs beside)
-    const unsigned threads = (unsigned)env_knob("BBB_TXMOVER_THREADS", 192);
-    uint64_t blocks = (uint64_t)ncu;
-    if (blocks > ntrips) blocks = ntrips;
-    const unsigned pause = (unsigned)env_knob("BBB_TXMOVER_PAUSE", 0);
-    if (env_knob("BBB_TXMOVER_TILES", 4) == 2)
-        hipLaunchKernelGGL(tx_unstage_kernel<2>, dim3((unsigned)blocks), dim3(threads), 0, st, (const char *)stg, dst, (unsigned long long)nsamples, L,
-                           (unsigned long long)G, (unsigned long long)Gpad, L / 16, tx, pause);
-    else
-        hipLaunchKernelGGL(tx_unstage_kernel<4>, dim3((unsigned)blocks), dim3(threads), 0, st, (const char *)stg, dst, (unsigned long long)nsamples, L,
-                           (unsigned long long)G, (unsigned long long)Gpad, L / 16, tx, pause);
-    BBB_HIP(hipGetLastError());
-    return BBB_OK;
-}
-
 int awgn256_tx_launch(const uint32_t *d_planes, int16_t *dst, uint64_t nsamples, unsigned L, uint64_t G, unsigned nlanes,
                       const int16_t *coeffs, const uint32_t *d_bits, uint32_t nwords32, uint32_t rel_base, uint32_t c0, int noise_var,
-                      int bit_en, int use_bits, bool staged, hipStream_t st) {
-    TxFuse tx;
-    for (int i = 0; i < 64; i++) tx.coeffs[i] = coeffs[i];
-    tx.bits = d_bits;
-    tx.rel_base = rel_base;
-    tx.c0 = c0;
-    tx.noise_var = noise_var;
-    tx.bit_en = bit_en;
-    tx.use_bits = use_bits && nwords32 >= 2;
-    tx.last_word = nwords32 ? nwords32 - 1 : 1;
-    if (staged)
-        hipLaunchKernelGGL((awgn256_kernel<true, true>), dim3(nlanes / 64), dim3(64), 0, st, d_planes, (void *)dst, (unsigned long long)nsamples, L,
-                           (unsigned long long)G, nlanes, tx);
-    else
-        hipLaunchKernelGGL((awgn256_kernel<true, false>), dim3(nlanes / 64), dim3(64), 0, st, d_planes, (void *)dst, (unsigned long long)nsamples, L,
-                           (unsigned long long)G, nlanes, tx);
+                      int bit_en, int use_bits, hipStream_t st) {
+    const TxFuse tx = make_txfuse(coeffs, d_bits, nwords32, rel_base, c0, noise_var, bit_en, use_bits);
+    hipLaunchKernelGGL((awgn256_kernel<true>), dim3(nlanes / 64), dim3(64), 0, st, d_planes, (void *)dst, (unsigned long long)nsamples, L,
+                       (unsigned long long)G, nlanes, tx);
     BBB_HIP(hipGetLastError());
     return BBB_OK;
 }

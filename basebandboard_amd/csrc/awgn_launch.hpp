@@ -18,27 +18,22 @@ bool awgn512p_matches(int k, const uint16_t *taps, const uint32_t *row_off);
 int bitslice512p_launch(const uint32_t *d_states, uint64_t G, uint64_t stride, unsigned nlanes, uint32_t *d_planes, hipStream_t st);
 int awgn512p_fill_launch(const uint32_t *d_planes, int16_t *dst, uint64_t nsamples, unsigned L, uint64_t G, unsigned nlanes,
                          hipStream_t st);
-// staged: dst is a staging buffer [L/16 rounds][nlanes * 32 generator slots][16 bytes], to be moved by unstage_launch
 int awgn256_fill_launch(const uint32_t *d_planes, int8_t *dst, uint64_t nsamples, unsigned L, uint64_t G,
-                        unsigned nlanes, bool staged, hipStream_t st);
+                        unsigned nlanes, hipStream_t st);
 // PLANES form of the staged stream: the sample kernel leaves the 8 count planes of every step, u32x4 stage[wave][step][half][lane]
-// (nlanes / 64 waves x L steps x 2 KiB), unplane_launch turns them into the byte stream at dst
+// (nlanes / 64 waves x L steps x 2 KiB); the mover turns them into bytes: bytes [win_lo, win_lo + nbytes) of the staged stream
+// (generator g owns [g L, (g + 1) L)) go to dst[0 .. nbytes)
 int awgn256_planes_launch(const uint32_t *d_planes, void *stage, unsigned L, unsigned nlanes, hipStream_t st);
-// bytes [win_lo, win_lo + nbytes) of the staged stream (generator g owns [g L, (g + 1) L)) go to dst[0 .. nbytes)
 int unplane_launch(const void *stage, void *dst, uint64_t win_lo, uint64_t nbytes, unsigned L, uint64_t G, unsigned nlanes, hipStream_t st);
-// staging buffer [rounds][Gpad][piece bytes] holds a sequential stream, generator g owning [g Lb, (g+1) Lb): its bytes
-// [win_lo, win_lo + nbytes) go to dst[0 .. nbytes)
-int unstage_launch(const void *stg, void *dst, uint64_t win_lo, uint64_t nbytes, unsigned Lb, uint64_t G, uint64_t Gpad,
-                   unsigned rounds, int piece, hipStream_t st);
-// the transmitter's output fused into the sample kernel: x = wrap12(bit_en * shaped + g * noise_var) as int16.
-// d_bits: packed data bits (32-bit words); rel_base = window bit offset of output position 0; c0 = (first_sample - 17) & 7
-// the shaping mover: int8 staging buffer of the plain sample kernel -> the TX waveform at its final place (awgn_kernels.hip)
-int tx_unstage_launch(const void *stg, int16_t *dst, uint64_t nsamples, unsigned L, uint64_t G, uint64_t Gpad, const int16_t *coeffs,
-                      const uint32_t *d_bits, uint32_t nwords32, uint32_t rel_base, uint32_t c0, int noise_var, int bit_en, int use_bits,
-                      hipStream_t st);
+// the SHAPING mover: the same window as the transmitter's int16 output x = wrap12(bit_en * shaped + g * noise_var) at dst[0 .. nsamples)
+// d_bits: packed data bits (32-bit words) of THIS window; rel_base = window bit offset of its sample 0; c0 = (first_sample - 17) & 7
+int unplane_tx_launch(const void *stage, int16_t *dst, uint64_t win_lo, uint64_t nsamples, unsigned L, uint64_t G, unsigned nlanes,
+                      const int16_t *coeffs, const uint32_t *d_bits, uint32_t nwords32, uint32_t rel_base, uint32_t c0, int noise_var, int bit_en,
+                      int use_bits, hipStream_t st);
+// the transmitter's output fused into the one-kernel form of the sample kernel (int16 straight to its place)
 int awgn256_tx_launch(const uint32_t *d_planes, int16_t *dst, uint64_t nsamples, unsigned L, uint64_t G, unsigned nlanes,
                       const int16_t *coeffs, const uint32_t *d_bits, uint32_t nwords32, uint32_t rel_base, uint32_t c0, int noise_var,
-                      int bit_en, int use_bits, bool staged, hipStream_t st);
+                      int bit_en, int use_bits, hipStream_t st);
 int pulse_bits_launch(uint64_t *dst, int64_t m_first, uint64_t nwords, hipStream_t st);
 int widen_i8_i16_launch(const int8_t *src, int16_t *dst, uint64_t n, hipStream_t st);   // n rounded up to 16 by the caller's buffers
 int awgn_generic_fill_launch(int k, const uint16_t *d_taps, const uint32_t *d_row_off, uint32_t *d_planes2,

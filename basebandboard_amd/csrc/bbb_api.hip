@@ -88,6 +88,7 @@ struct bbb_lutopt {
     // kernel of call s still reads its own -- two buffers, each with the event of its last reader
     uint32_t *d_fbits[2] = {nullptr, nullptr}; size_t fbits_cap[2] = {0, 0};
     hipEvent_t fbits_read[2] = {nullptr, nullptr}, fbits_ready = nullptr;
+    uint32_t *d_mbits = nullptr; size_t mbits_cap = 0;        // staged TX: this call's data bits, written and read on the mover's stream
     hipEvent_t ber_fork = nullptr, ber_join = nullptr;       // ber_run: PRBS seeding on the side stream beside the generator's
     bool fbits_pending[2] = {false, false};
     int fbits_slot = 0;
@@ -115,7 +116,12 @@ struct bbb_lutopt {
     bool cs_valid = false;
     hipEvent_t handover = nullptr;
     bool staged_mode = false;             // bbb_lutopt_set_staged
-    hipStream_t xs = nullptr, ys = nullptr;            // internal: arithmetic / piece mover
+    bool has_stream = false;              // a bbb_awgn_stream is open on this handle
+    // internal streams: arithmetic (one per staging slot: consecutive sample kernels go to alternate streams, so that the
+    // barrier packets in front of kernel s+1 -- the wait for its start states, the record behind kernel s -- are
+    // processed while kernel s still runs instead of between the two: 21-27 us per step in profiles/r03_ramp_clock_per_launch.log)
+    // and the piece mover
+    hipStream_t xs2[2] = {nullptr, nullptr}, ys = nullptr;
     uint32_t *d_stage[2] = {nullptr, nullptr}; size_t stage_cap[2] = {0, 0};
     hipEvent_t stage_free[2] = {nullptr, nullptr};     // recorded on ys after the mover that read the buffer
     bool stage_busy[2] = {false, false};
@@ -274,17 +280,34 @@ void partition(const bbb_lutopt *h, uint64_t n, unsigned granule, uint64_t *L, u
 // Choose the stream this call's plane-touching work goes to.  When it differs from the previous call's (the staged
 // fills use an internal stream; the caller may also have re-bound the handle), the new one first waits for
 // everything the library queued on the old one.
-int begin_op(bbb_lutopt *h, bool internal) {
-    if (internal && !h->xs) {
+int ensure_internal_streams(bbb_lutopt *h) {
+    if (!h->xs2[0]) {
         // (stream priorities -- arithmetic high, mover low -- made no measurable difference: profiles/README.md)
-        BBB_HIP(hipStreamCreateWithFlags(&h->xs, hipStreamNonBlocking));
+        BBB_HIP(hipStreamCreateWithFlags(&h->xs2[0], hipStreamNonBlocking));
+        BBB_HIP(hipStreamCreateWithFlags(&h->xs2[1], hipStreamNonBlocking));
         BBB_HIP(hipStreamCreateWithFlags(&h->ys, hipStreamNonBlocking));
     }
-    hipStream_t want = internal ? h->xs : h->stream;
+    return BBB_OK;
+}
+
+int begin_op(bbb_lutopt *h, bool internal, bool independent_of_previous_internal = false) {
+    if (internal) {
+        const int rc = ensure_internal_streams(h);
+        if (rc) return rc;
+    }
+    // an internal operation goes to the arithmetic stream of the staging slot it is about to take (staged_fill_with flips
+    // stage_slot next)
+    hipStream_t want = internal ? h->xs2[h->stage_slot ^ 1] : h->stream;
     if (h->cs_valid && h->cs != want) {
-        if (!h->handover) BBB_HIP(hipEventCreateWithFlags(&h->handover, hipEventDisableTiming));
-        BBB_HIP(hipEventRecord(h->handover, h->cs));
-        BBB_HIP(hipStreamWaitEvent(want, h->handover, 0));
+        // independent_of_previous_internal: the operation reads start states that were seeded elsewhere (a prefetch: its
+        // buffers are guarded by their own events) and writes a staging slot guarded by the slot's events -- nothing ties
+        // it to the work on the other arithmetic stream, so it does not wait for it
+        const bool from_internal = h->cs == h->xs2[0] || h->cs == h->xs2[1];
+        if (!(independent_of_previous_internal && internal && from_internal)) {
+            if (!h->handover) BBB_HIP(hipEventCreateWithFlags(&h->handover, hipEventDisableTiming));
+            BBB_HIP(hipEventRecord(h->handover, h->cs));
+            BBB_HIP(hipStreamWaitEvent(want, h->handover, 0));
+        }
     }
     h->cs = want;
     h->cs_valid = true;
@@ -340,18 +363,23 @@ int acquire_planes(bbb_lutopt *h, uint64_t first_step, uint64_t L, uint64_t G, u
     return prepare_planes(h, first_step, L, G, nlanes);
 }
 
-// The two-kernel form of a fill (bbb_lutopt_set_staged).  `launch_arith(stage_buffer)` queues the sample kernel,
-// which leaves its pieces in a staging buffer as full lines; the piece mover then writes `dst`.  Streams:
-//   arithmetic      internal stream xs  -- ordered after the previous library work, NOT after the caller's stream
-//   piece mover     internal stream ys  -- after the arithmetic, and after everything the caller had queued before
-//                                          this call (it may still be reading `dst`)
+// The two-kernel ("staged") form of a fill (bbb_lutopt_set_staged), PLANES form since round 3:
+//   produce   awgn256_planes_kernel: the sample kernel stores the 8 count planes of every step as they are into a staging
+//             slot (no LDS, no plane -> byte work on the one wave per SIMD that owns the issue slots);
+//   deliver   unplane_kernel: a mover with LDS-DMA loads transposes a WINDOW of the staged stream into bytes at `dst` (or, as
+//             the shaping mover, into the transmitter's int16 samples).
+// Streams (four in all: a fifth would share a hardware queue with one of them):
+//   arithmetic  xs2[slot]  start states (bbb_awgn_prefetch) and the sample kernel of the fill that takes staging slot `slot`;
+//                          ordered after the previous library work unless the start states were announced, NOT after the
+//                          caller's stream
+//   mover       ys         after the slot's sample kernel, and after everything the caller had queued before this call (it
+//                          may still be reading `dst`)
 //   caller's stream waits for the mover: whatever the caller queues next sees `dst` complete, as with one kernel.
-// Since the next call's arithmetic does not wait for this call's mover, the mover (HBM-bound, a few registers per
-// lane) runs beside it (integer-issue bound, one wave per SIMD).  Two staging buffers alternate.
+// Since the next call's arithmetic does not wait for this call's mover, the mover (latency bound, 64 registers, its
+// instructions in the issue slots the sample kernel's wave cannot use) runs beside it.  Two staging slots alternate.
 
-// the piece mover of staging slot `slot`: stream bytes [win_lo, win_lo + nbytes) -> dst; behind the slot's sample kernel
-// and behind everything the caller has queued so far; the caller's stream then waits for it
-// `launch_mover(staging buffer, stream)` queues the kernel that empties the slot
+// the mover of staging slot `slot`: behind the slot's sample kernel and behind everything the caller has queued so far;
+// the caller's stream then waits for it.  `launch_mover(staging buffer, stream)` queues the kernel
 template <typename LaunchMover>
 int queue_mover_with(bbb_lutopt *h, int slot, LaunchMover launch_mover) {
     for (hipEvent_t *e : {&h->stage_free[slot], &h->ev_user})
@@ -368,29 +396,21 @@ int queue_mover_with(bbb_lutopt *h, int slot, LaunchMover launch_mover) {
     return BBB_OK;
 }
 
-int queue_mover(bbb_lutopt *h, int slot, void *dst, uint64_t win_lo, uint64_t nbytes, int piece, uint64_t L, uint64_t G,
-                unsigned nlanes) {
-    const uint64_t Gpad = (uint64_t)nlanes * 32;
-    const unsigned rounds = (unsigned)(L / 16);
+// deliver bytes [win_lo, win_lo + n) of the stream staged in `slot` (partition L, G, nlanes) to dst
+int deliver_i8(bbb_lutopt *h, int slot, void *dst, uint64_t win_lo, uint64_t n, uint64_t L, uint64_t G, unsigned nlanes) {
     return queue_mover_with(h, slot, [&](const void *stage, hipStream_t ys) {
-        return unstage_launch(stage, dst, win_lo, nbytes, (unsigned)(L * (uint64_t)piece / 16), G, Gpad, rounds, piece, ys);
+        return unplane_launch(stage, dst, win_lo, n, (unsigned)L, G, nlanes, ys);
     });
 }
 
-// planes_seeded_after_mover: the start states came from a prefetch whose seeding had itself waited for the mover that last
-// read this staging buffer (bbb_awgn_prefetch on a staged handle), so the arithmetic need not wait for it again -- every
-// event wait is a barrier packet of several microseconds between two sample kernels.
-// The sample kernel produces `total_bytes` of stream (L, G, nlanes are ITS partition); `nbytes` of them, from offset 0, are
-// delivered to dst now (look-ahead: total_bytes = 2 nbytes, the rest waits in the slot).  *slot_out = the slot used.
-template <typename LaunchArith, typename LaunchMover>
-int staged_fill_with(bbb_lutopt *h, int piece, uint64_t L, unsigned nlanes, bbb_lutopt::ProfEv *ev, bool planes_seeded_after_mover,
-                     LaunchArith launch_arith, LaunchMover launch_mover, int *slot_out = nullptr) {
-    const uint64_t Gpad = (uint64_t)nlanes * 32;
-    const unsigned rounds = (unsigned)(L / 16);
-    const size_t need_words = (size_t)(Gpad * rounds * (uint64_t)piece / 4);
+// produce: the sample kernel for the stream positions the planes in h->d_planes describe, L steps per generator, into the
+// next staging slot.  planes_seeded_after_mover: the start states came from a prefetch whose seeding had itself waited for
+// the mover that last read this slot (bbb_awgn_prefetch on a staged handle), so the arithmetic need not wait for it again.
+int produce_planes(bbb_lutopt *h, uint64_t L, unsigned nlanes, bbb_lutopt::ProfEv *ev, bool planes_seeded_after_mover, int *slot_out) {
+    const size_t need_words = (size_t)nlanes * (size_t)L * 8;              // nlanes / 64 waves x L steps x 2 KiB
     const int slot = h->stage_slot ^= 1;
-    if (slot_out) *slot_out = slot;
-    if (h->ahead.valid && h->ahead.slot == slot) h->ahead.valid = false;            // its look-ahead half is overwritten now
+    *slot_out = slot;
+    if (h->ahead.valid && h->ahead.slot == slot) h->ahead.valid = false;            // what waited there is overwritten now
     for (hipEvent_t *e : {&h->stage_free[slot], &h->stage_arith[slot]})
         if (!*e) BBB_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     if (h->stage_cap[slot] < need_words) {
@@ -406,23 +426,12 @@ int staged_fill_with(bbb_lutopt *h, int piece, uint64_t L, unsigned nlanes, bbb_
     if (h->stage_busy[slot] && !seeding_saw_last_mover)
         BBB_HIP(hipStreamWaitEvent(h->cs, h->stage_free[slot], 0));   // its last mover has read it
     if (ev) BBB_HIP(hipEventRecord(ev->e1, h->cs));
-    int rc = launch_arith((void *)h->d_stage[slot]);
+    int rc = awgn256_planes_launch(h->d_planes, (void *)h->d_stage[slot], (unsigned)L, nlanes, h->cs);
     if (rc) return rc;
     if ((rc = mark_planes_read(h))) return rc;
     if (ev) BBB_HIP(hipEventRecord(ev->e2, h->cs));
     BBB_HIP(hipEventRecord(h->stage_arith[slot], h->cs));
-    return queue_mover_with(h, slot, launch_mover);
-}
-
-template <typename LaunchArith>
-int staged_fill(bbb_lutopt *h, void *dst, uint64_t nbytes, int piece, uint64_t L, uint64_t G, unsigned nlanes,
-                bbb_lutopt::ProfEv *ev, bool planes_seeded_after_mover, LaunchArith launch_arith, int *slot_out = nullptr) {
-    const uint64_t Gpad = (uint64_t)nlanes * 32;
-    const unsigned rounds = (unsigned)(L / 16);
-    return staged_fill_with(h, piece, L, nlanes, ev, planes_seeded_after_mover, launch_arith,
-                            [&](const void *stage, hipStream_t ys) {
-                                return unstage_launch(stage, dst, 0, nbytes, (unsigned)(L * (uint64_t)piece / 16), G, Gpad, rounds, piece, ys);
-                            }, slot_out);
+    return BBB_OK;
 }
 
 // the packed n512 kernel's partition: 16 generators per lane, 1024 per wave, segments in multiples of 8 samples (16-byte
@@ -490,7 +499,7 @@ int awgn_fill(bbb_lutopt *h, void *dst, int elem_size, uint64_t nsamples, uint64
         h->ahead.first += nsamples; h->ahead.step += nsamples;
         h->ahead.win_lo += nsamples;
         h->ahead.valid = --h->ahead.left > 0;
-        return queue_mover(h, a.slot, dst, a.win_lo, nsamples, 16, a.L, a.G, a.nlanes);
+        return deliver_i8(h, a.slot, dst, a.win_lo, nsamples, a.L, a.G, a.nlanes);
     }
     const uint64_t m = (uint64_t)h->staged_level;
     const bool ahead = staged && m >= 2 && (nsamples % 16) == 0 && m * nsamples < (1ull << 40) &&
@@ -500,7 +509,9 @@ int awgn_fill(bbb_lutopt *h, void *dst, int elem_size, uint64_t nsamples, uint64
         partition(h, ntotal, 16, &L, &G, &nlanes);
         if (L > 0xffffff00ull) return fail(BBB_EINVAL, "nsamples too large for one call (segment length must fit 32 bits): split it");
     }
-    int rc = begin_op(h, staged);
+    // (a fill that will take the announced start states does not depend on the previous sample kernel: see begin_op)
+    const bool takes_prefetch = fast256 && h->pf.valid && h->pf.first == first_step && h->pf.L == L && h->pf.G == G;
+    int rc = begin_op(h, staged, staged && takes_prefetch);
     if (rc) return rc;
     bbb_lutopt::ProfEv ev{};
     if (h->profiling) {
@@ -512,19 +523,8 @@ int awgn_fill(bbb_lutopt *h, void *dst, int elem_size, uint64_t nsamples, uint64
     if (rc) return rc;
     if (staged) {
         int slot = 0;
-        if (!ahead && env_knob("BBB_PLANES_FORM", 1)) {
-            // PLANES form (round 3): the sample kernel stores its count planes as they are, the mover transposes them
-            // into bytes (awgn_kernels.hip: awgn256_planes_kernel / unplane_kernel); same staging size
-            rc = staged_fill_with(h, 16, L, nlanes, h->profiling ? &ev : nullptr, from_pf,
-                                  [&](void *stage) { return awgn256_planes_launch(h->d_planes, stage, (unsigned)L, nlanes, h->cs); },
-                                  [&](const void *stage, hipStream_t ys) { return unplane_launch(stage, dst, 0, nsamples, (unsigned)L, G, nlanes, ys); },
-                                  &slot);
-            if (h->profiling) h->prof_pending.push_back(ev);
-            return rc;
-        }
-        rc = staged_fill(h, dst, nsamples, 16, L, G, nlanes, h->profiling ? &ev : nullptr, from_pf, [&](void *stage) {
-            return awgn256_fill_launch(h->d_planes, (int8_t *)stage, ntotal, (unsigned)L, G, nlanes, true, h->cs);
-        }, &slot);
+        rc = produce_planes(h, L, nlanes, h->profiling ? &ev : nullptr, from_pf, &slot);
+        if (!rc) rc = deliver_i8(h, slot, dst, 0, nsamples, L, G, nlanes);
         if (h->profiling) h->prof_pending.push_back(ev);
         if (!rc && ahead) {
             h->ahead.valid = true; h->ahead.kind = 0;
@@ -536,7 +536,7 @@ int awgn_fill(bbb_lutopt *h, void *dst, int elem_size, uint64_t nsamples, uint64
     }
     if (fast256) {
         if (h->profiling) BBB_HIP(hipEventRecord(ev.e1, h->cs));
-        rc = awgn256_fill_launch(h->d_planes, (int8_t *)dst, nsamples, (unsigned)L, G, nlanes, false, h->cs);
+        rc = awgn256_fill_launch(h->d_planes, (int8_t *)dst, nsamples, (unsigned)L, G, nlanes, h->cs);
         if (!rc) rc = mark_planes_read(h);
         if (h->profiling) {
             BBB_HIP(hipEventRecord(ev.e2, h->cs));
@@ -801,12 +801,12 @@ int bbb_lutopt_destroy(bbb_lutopt *h) {
     for (auto &p : h->prbs_plans) (void)hipFree(p.second.d_cols);
     for (void *p : {(void *)h->d_states, (void *)h->d_planes, (void *)h->d_pstates, (void *)h->d_pplanes,
                     (void *)h->d_taps, (void *)h->d_row_off, (void *)h->d_counters, (void *)h->d_txnoise,
-                    (void *)h->d_txbits, (void *)h->d_fbits[0], (void *)h->d_fbits[1], (void *)h->pf.d_states, (void *)h->pf.d_planes})
+                    (void *)h->d_txbits, (void *)h->d_fbits[0], (void *)h->d_fbits[1], (void *)h->d_mbits, (void *)h->pf.d_states, (void *)h->pf.d_planes})
         (void)hipFree(p);
     for (hipEvent_t e : {h->pf.seeded, h->pf.last_read, h->cur_last_read, h->handover, h->stage_free[0], h->stage_free[1],
                          h->stage_arith[0], h->stage_arith[1], h->ev_user, h->fbits_read[0], h->fbits_read[1], h->fbits_ready, h->ber_fork, h->ber_join})
         if (e) (void)hipEventDestroy(e);
-    for (hipStream_t st : {h->side, h->xs, h->ys})
+    for (hipStream_t st : {h->side, h->xs2[0], h->xs2[1], h->ys})
         if (st) (void)hipStreamDestroy(st);
     (void)hipFree(h->d_stage[0]);
     (void)hipFree(h->d_stage[1]);
@@ -909,8 +909,7 @@ int bbb_awgn_prefetch(bbb_lutopt *h, uint64_t nsamples, uint64_t first_step) {
             if (first_step + skip < first_step) return BBB_OK;
             first_step += skip;
         }
-        const uint64_t cap = h->last_fill_tx ? (1ull << 31) : (1ull << 40);
-        if (m * nsamples < cap && first_step + m * nsamples > first_step) nsamples *= m;
+        if (m * nsamples < (1ull << 40) && first_step + m * nsamples > first_step) nsamples *= m;
     }
     if (h->fast512) {
         if (!partition512(h, nsamples, &L, &G, &nlanes)) return BBB_OK;
@@ -924,11 +923,22 @@ int bbb_awgn_prefetch(bbb_lutopt *h, uint64_t nsamples, uint64_t first_step) {
     if (rc) return rc;
     bbb_lutopt::Prefetch &pf = h->pf;
     pf.valid = false;
-    if (!h->side) BBB_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-    // staged handles: the running sample kernel (fill s) shares its CUs with ONE guest kernel at a time -- with two, its
-    // waves, 416 registers each, wait for a SIMD.  The guests of fill s are the piece mover of fill s-1 and this seeding
+    // Which stream seeds.  A staged k = 256 handle: the ARITHMETIC stream of the staging slot the announced fill will take --
+    // the sample kernel then follows its start states on one stream, with no event between them, and the library keeps to
+    // four streams (the caller's, two arithmetic, the mover's).  A fifth shares a hardware queue with one of the others
+    // on this part and ties the kernels of both together: with the seeding on a stream of its own beside two arithmetic
+    // streams the mover and the seeding ran BETWEEN the sample kernels instead of beside them (1.05 -> 1.69 ms per step).
+    hipStream_t side = nullptr;
+    if (h->staged_mode && h->specialised) {
+        if ((rc = ensure_internal_streams(h))) return rc;
+        side = h->xs2[h->stage_slot ^ 1];
+    } else {
+        if (!h->side) BBB_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        side = h->side;
+    }
+    // staged handles: the running sample kernel (fill s) shares its CUs with ONE guest kernel at a time: a SIMD's registers
+    // hold the sample kernel's wave and one guest wave.  The guests of fill s are the piece mover of fill s-1 and this seeding
     // (for fill s+1): the seeding waits for that mover.  (The mover of fill s itself starts when fill s has finished.)
-    const hipStream_t side = h->side;
     h->pf_waited_slot = -1;
     if (h->staged_mode && h->stage_busy[h->stage_slot ^ 1]) {
         BBB_HIP(hipStreamWaitEvent(side, h->stage_free[h->stage_slot ^ 1], 0));
@@ -970,6 +980,79 @@ int bbb_awgn_fill_i16(bbb_lutopt *h, int16_t *dst_dev, uint64_t nsamples, uint64
         return widen_i8_i16_launch((const int8_t *)h->d_txnoise, dst_dev, nsamples, h->stream);
     }
     return awgn_fill(h, dst_dev, 2, nsamples, first_step);
+}
+
+/* ---- the sample stream as an object (include/bbb.h) ------------------------------------------------------------ */
+
+struct bbb_awgn_stream {
+    bbb_lutopt *h = nullptr;
+    uint64_t n = 0, pos = 0;
+    int elem = 1;
+    int saved_level = 0;          // the handle's bbb_lutopt_set_staged level before the stream was opened
+};
+
+int bbb_awgn_stream_open(bbb_lutopt *h, uint64_t nsamples_per_call, uint64_t first_step, int elem_bytes, bbb_awgn_stream **out) {
+    if (!h || !out) return fail(BBB_EINVAL, "null argument");
+    if (nsamples_per_call == 0) return fail(BBB_EINVAL, "nsamples_per_call must be positive");
+    if (elem_bytes != 1 && elem_bytes != 2) return fail(BBB_EINVAL, "elem_bytes must be 1 (int8) or 2 (int16)");
+    if (h->device < 0) return fail(BBB_ENODEV, "host-only handle (device -1) cannot generate samples");
+    if (h->k & (h->k - 1)) return fail(BBB_EUNSUP, "CLTGRNG needs k to be a power of two (rng.py:72-76)");
+    if (elem_bytes == 1 && h->k > 256) return fail(BBB_EUNSUP, "k > 256 needs the int16 output");
+    if (h->has_stream) return fail(BBB_EINVAL, "the handle already has an open stream");
+    if (first_step + nsamples_per_call < first_step) return fail(BBB_EINVAL, "first_step + nsamples_per_call overflows");
+    std::unique_ptr<bbb_awgn_stream> s(new bbb_awgn_stream);
+    s->h = h; s->n = nsamples_per_call; s->pos = first_step; s->elem = elem_bytes;
+    s->saved_level = h->staged_level;
+    if (h->staged_level == 0) {            // (a caller who chose a look-ahead level keeps it)
+        int rc = bbb_lutopt_set_staged(h, 1);
+        if (rc) return rc;
+    }
+    int rc = bbb_awgn_prefetch(h, s->n, s->pos);
+    if (rc) return rc;
+    h->has_stream = true;
+    *out = s.release();
+    return BBB_OK;
+}
+
+int bbb_awgn_stream_read(bbb_awgn_stream *s, void *dst_dev, uint64_t nsamples) {
+    if (!s || !s->h) return fail(BBB_EINVAL, "null stream");
+    if (s->pos + nsamples < s->pos) return fail(BBB_EINVAL, "the stream position overflows");
+    bbb_lutopt *h = s->h;
+    int rc = s->elem == 1 ? bbb_awgn_fill_i8(h, (int8_t *)dst_dev, nsamples, s->pos) : bbb_awgn_fill_i16(h, (int16_t *)dst_dev, nsamples, s->pos);
+    if (rc) return rc;
+    s->pos += nsamples;
+    // the next read is expected to be a whole one: its start states are derived now, beside this read's kernels
+    if (s->pos + s->n >= s->pos) rc = bbb_awgn_prefetch(h, s->n, s->pos);
+    return rc;
+}
+
+int bbb_awgn_stream_next(bbb_awgn_stream *s, void *dst_dev) {
+    if (!s) return fail(BBB_EINVAL, "null stream");
+    return bbb_awgn_stream_read(s, dst_dev, s->n);
+}
+
+int bbb_awgn_stream_seek(bbb_awgn_stream *s, uint64_t first_step) {
+    if (!s || !s->h) return fail(BBB_EINVAL, "null stream");
+    if (first_step + s->n < first_step) return fail(BBB_EINVAL, "first_step + nsamples_per_call overflows");
+    s->pos = first_step;
+    return bbb_awgn_prefetch(s->h, s->n, s->pos);
+}
+
+int bbb_awgn_stream_tell(const bbb_awgn_stream *s, uint64_t *next_step) {
+    if (!s || !next_step) return fail(BBB_EINVAL, "null argument");
+    *next_step = s->pos;
+    return BBB_OK;
+}
+
+int bbb_awgn_stream_close(bbb_awgn_stream *s) {
+    if (!s) return BBB_OK;
+    int rc = BBB_OK;
+    if (s->h) {
+        s->h->has_stream = false;
+        if (s->h->staged_level != s->saved_level) rc = bbb_lutopt_set_staged(s->h, s->saved_level);
+    }
+    delete s;
+    return rc;
 }
 
 int bbb_lutopt_fill_words(bbb_lutopt *h, uint32_t *dst_dev, uint64_t nstates, uint64_t first_step, int msb_first) {
@@ -1137,33 +1220,81 @@ int bbb_tx_fill_i16(bbb_lutopt *h, const bbb_tx_cfg *cfg, int16_t *out_dev, uint
     int64_t m0;
     uint64_t nbits;
     if (cfg->noise_en && h->specialised && first_sample + nsamples < (1ull << 62) && nsamples < (1ull << 31)) {
-        // the shaper fused into the sample kernel: the int8 noise stream never goes through HBM
         if (cfg->warmup + first_sample + nsamples < nsamples) return fail(BBB_EINVAL, "warmup + first_sample + nsamples overflows");
         uint64_t L, G;
         unsigned nlanes;
         const bool staged = h->staged_mode && nsamples >= (1ull << 24);
-        // look-ahead (bbb_lutopt_set_staged(h, m >= 2)): these very samples, of this very configuration, were produced by
-        // an earlier call's sample kernel and wait in its staging slot
-        if (staged && h->ahead.valid && h->ahead.kind == 1 && h->ahead.first == first_sample && h->ahead.n == nsamples &&
-            tx_cfg_equal(h->ahead.cfg, *cfg)) {
-            if ((rc = begin_op(h, true))) return rc;
-            h->last_fill_tx = true;
-            const bbb_lutopt::Ahead a = h->ahead;
-            h->ahead.first += nsamples; h->ahead.step += nsamples;
-            h->ahead.win_lo += 2 * nsamples;
-            h->ahead.valid = --h->ahead.left > 0;
-            return queue_mover(h, a.slot, out_dev, a.win_lo, 2 * nsamples, 32, a.L, a.G, a.nlanes);
-        }
-        const uint64_t mla = (uint64_t)h->staged_level;
-        const bool ahead = staged && mla >= 2 && (nsamples % 16) == 0 && mla * nsamples < (1ull << 31) &&
-                           first_sample + mla * nsamples < (1ull << 62) && cfg->warmup + first_sample + mla * nsamples >= mla * nsamples;
-        const uint64_t ntotal = ahead ? mla * nsamples : nsamples;        // what the sample kernel produces
-        tx_bit_range(first_sample, ntotal, &m0, &nbits);
-        partition(h, ntotal, 16, &L, &G, &nlanes);
-        if ((rc = begin_op(h, staged))) return rc;
-        h->last_fill_tx = true;
+        // the data bits of THIS call's samples, and where its sample 0 sits among them
+        tx_bit_range(first_sample, nsamples, &m0, &nbits);
         const int64_t F = (int64_t)first_sample - 17, FM = F >> 3;            // arithmetic shift = floor
         const bool use_bits = cfg->bit_en && nbits;
+        const uint32_t rel_base = (uint32_t)(FM - 7 - (m0 - 128));
+        if (staged) {
+            // Noise kernel + SHAPING mover: the plain sample kernel leaves its count planes in a staging slot, the mover turns
+            // this call's window of them into the transmitter's int16 samples (unplane_kernel<true>): the call is bounded by
+            // the noise kernel, and the int8 noise crosses HBM once each way instead of the int16 output doing so twice.
+            if ((rc = ensure_internal_streams(h))) return rc;
+            // the data bits go to the MOVER's stream: in order behind the previous mover (the buffer's last reader) and ahead
+            // of this call's; two zero 64-bit words lead (data bits before the first read as 0: the shaper's reset register)
+            const uint64_t words64 = 2 + (nbits + 63) / 64 + 3;
+            if (h->mbits_cap < (size_t)words64 * 2) {
+                BBB_HIP(hipStreamSynchronize(h->ys));                          // growing frees the old buffer
+                if ((rc = grow(&h->d_mbits, &h->mbits_cap, (size_t)words64 * 2))) return rc;
+            }
+            uint32_t *const d_bits = h->d_mbits;
+            if (use_bits) {
+                BBB_HIP(hipMemsetAsync(d_bits, 0, 16, h->ys));
+                uint64_t *bits64 = (uint64_t *)d_bits + 2;
+                if (cfg->source == 0) rc = prbs_fill_launch(cfg->prbs_k, cfg->prbs_state, (uint64_t)m0, nbits, bits64, h->ys);
+                else rc = pulse_bits_launch(bits64, m0, (nbits + 63) / 64, h->ys);
+                if (rc) return rc;
+            }
+            auto deliver_tx = [&](int slot, uint64_t win_lo, uint64_t Lk, uint64_t Gk, unsigned nl) {
+                return queue_mover_with(h, slot, [&](const void *stage, hipStream_t ys) {
+                    return unplane_tx_launch(stage, out_dev, win_lo, nsamples, (unsigned)Lk, Gk, nl, cfg->coeffs, d_bits, (uint32_t)(words64 * 2),
+                                             rel_base, (uint32_t)(F & 7), cfg->noise_var, cfg->bit_en, use_bits ? 1 : 0, ys);
+                });
+            };
+            // look-ahead (bbb_lutopt_set_staged(h, m >= 2)): the noise of these very samples was produced by an earlier call's
+            // sample kernel and waits in its staging slot (same configuration: the noise does not depend on it, but a reader
+            // who changes it mid-stream gets a fresh kernel, as before)
+            if (h->ahead.valid && h->ahead.kind == 1 && h->ahead.first == first_sample && h->ahead.n == nsamples &&
+                tx_cfg_equal(h->ahead.cfg, *cfg)) {
+                if ((rc = begin_op(h, true))) return rc;
+                const bbb_lutopt::Ahead a = h->ahead;
+                h->ahead.first += nsamples; h->ahead.step += nsamples;
+                h->ahead.win_lo += nsamples;
+                h->ahead.valid = --h->ahead.left > 0;
+                return deliver_tx(a.slot, a.win_lo, a.L, a.G, a.nlanes);
+            }
+            const uint64_t mla = (uint64_t)h->staged_level;
+            const bool ahead = mla >= 2 && (nsamples % 16) == 0 && mla * nsamples < (1ull << 40) &&
+                               first_sample + mla * nsamples < (1ull << 62) && cfg->warmup + first_sample + mla * nsamples >= mla * nsamples;
+            const uint64_t ntotal = ahead ? mla * nsamples : nsamples;        // what the sample kernel produces
+            partition(h, ntotal, 16, &L, &G, &nlanes);
+            if (L > 0xffffff00ull) return fail(BBB_EINVAL, "nsamples too large for one call (segment length must fit 32 bits): split it");
+            const uint64_t step0 = cfg->warmup + first_sample;                // tx.py:70-71
+            const bool takes_prefetch = h->pf.valid && h->pf.first == step0 && h->pf.L == L && h->pf.G == G;
+            if ((rc = begin_op(h, true, takes_prefetch))) return rc;
+            h->last_fill_tx = false;            // (what runs on the SIMDs is the plain kernel)
+            bool from_pf = false;
+            if ((rc = acquire_planes(h, step0, L, G, nlanes, true, &from_pf))) return rc;
+            int slot = 0;
+            if ((rc = produce_planes(h, L, nlanes, nullptr, from_pf, &slot))) return rc;
+            if ((rc = deliver_tx(slot, 0, L, G, nlanes))) return rc;
+            if (ahead) {
+                bbb_lutopt::Ahead &a = h->ahead;
+                a.valid = true; a.kind = 1; a.cfg = *cfg;
+                a.first = first_sample + nsamples; a.step = step0 + nsamples;
+                a.n = nsamples; a.win_lo = nsamples; a.left = (unsigned)mla - 1;
+                a.L = L; a.G = G; a.nlanes = nlanes; a.slot = slot;
+            }
+            return BBB_OK;
+        }
+        // one kernel: the shaper fused into the sample kernel's round end, int16 straight to its place
+        partition(h, nsamples, 16, &L, &G, &nlanes);
+        if ((rc = begin_op(h, false))) return rc;
+        h->last_fill_tx = true;
         // buffer: two zero 64-bit words (data bits before the first read as 0, the shaper's reset shift register), the
         // bits m0 .. m0+nbits-1, slack for the windows of rounds past the end of the request
         const uint64_t words64 = 2 + (nbits + 63) / 64 + (L / 8 + 63) / 64 + 2;
@@ -1188,43 +1319,12 @@ int bbb_tx_fill_i16(bbb_lutopt *h, const bbb_tx_cfg *cfg, int16_t *out_dev, uint
             BBB_HIP(hipEventRecord(h->fbits_ready, h->side));
             BBB_HIP(hipStreamWaitEvent(h->cs, h->fbits_ready, 0));
         }
-        bool from_pf = false;
-        if ((rc = acquire_planes(h, cfg->warmup + first_sample, L, G, nlanes, true, &from_pf))) return rc;      // tx.py:70-71
-        const uint32_t rel_base = (uint32_t)(FM - 7 - (m0 - 128));
-        auto arith = [&](void *dst, bool to_stage) {
-            return awgn256_tx_launch(h->d_planes, (int16_t *)dst, ntotal, (unsigned)L, G, nlanes, cfg->coeffs, d_bits,
-                                     (uint32_t)(words64 * 2), rel_base, (uint32_t)(F & 7), cfg->noise_var, cfg->bit_en, use_bits ? 1 : 0,
-                                     to_stage, h->cs);
-        };
-        if (staged && !ahead) {
-            // noise kernel + shaping mover: the plain int8 sample kernel into the staging buffer, the transmitter's
-            // arithmetic in the mover (tx_unstage_kernel) -- the call is then bounded by the noise kernel (1.2 ms per 1e9
-            // samples alone) instead of the fused one (1.54), and moves 4 instead of 6 bytes per sample through HBM
-            h->last_fill_tx = false;            // (what runs on the SIMDs is the plain kernel: the seeding may use 16 KiB pieces)
-            const uint64_t Gpad = (uint64_t)nlanes * 32;
-            rc = staged_fill_with(h, 16, L, nlanes, nullptr, from_pf,
-                                  [&](void *stage) { return awgn256_fill_launch(h->d_planes, (int8_t *)stage, nsamples, (unsigned)L, G, nlanes, true, h->cs); },
-                                  [&](const void *stage, hipStream_t ys) {
-                                      return tx_unstage_launch(stage, out_dev, nsamples, (unsigned)L, G, Gpad, cfg->coeffs, d_bits, (uint32_t)(words64 * 2),
-                                                               rel_base, (uint32_t)(F & 7), cfg->noise_var, cfg->bit_en, use_bits ? 1 : 0, ys);
-                                  });
-        } else if (staged) {
-            int slot = 0;
-            rc = staged_fill(h, out_dev, nsamples * 2, 32, L, G, nlanes, nullptr, from_pf, [&](void *stage) { return arith(stage, true); }, &slot);
-            if (!rc && ahead) {
-                bbb_lutopt::Ahead &a = h->ahead;
-                a.valid = true; a.kind = 1; a.cfg = *cfg;
-                a.first = first_sample + nsamples; a.step = cfg->warmup + first_sample + nsamples;
-                a.n = nsamples; a.win_lo = 2 * nsamples; a.left = (unsigned)mla - 1;
-                a.L = L; a.G = G; a.nlanes = nlanes; a.slot = slot;
-            }
-        } else {
-            rc = arith(out_dev, false);
-            if (!rc) rc = mark_planes_read(h);
-        }
+        if ((rc = acquire_planes(h, cfg->warmup + first_sample, L, G, nlanes, true))) return rc;      // tx.py:70-71
+        rc = awgn256_tx_launch(h->d_planes, out_dev, nsamples, (unsigned)L, G, nlanes, cfg->coeffs, d_bits, (uint32_t)(words64 * 2), rel_base,
+                               (uint32_t)(F & 7), cfg->noise_var, cfg->bit_en, use_bits ? 1 : 0, h->cs);
+        if (!rc) rc = mark_planes_read(h);
         if (rc) return rc;
-        // the last reader of the data bits: the shaping mover (on ys) in the noise-kernel + mover form, else the fused kernel
-        BBB_HIP(hipEventRecord(h->fbits_read[bs], (staged && !ahead) ? h->ys : h->cs));
+        BBB_HIP(hipEventRecord(h->fbits_read[bs], h->cs));            // the fused kernel is the last reader of the data bits
         h->fbits_pending[bs] = true;
         return BBB_OK;
     }

@@ -215,6 +215,13 @@ class CLTGRNG:
         side stream, beside whatever the GPU is running.  Purely a performance hint."""
         _lib.check(_lib.lib().bbb_awgn_prefetch(self.urng._h, int(nsamples), int(first_step)), "bbb_awgn_prefetch")
 
+    def stream(self, nsamples_per_call, first_step=0):
+        """The generator as what it is in the reference: ONE sequential stream, drained in order (rng.py:70-108 emits
+        one value per clock).  Returns a `SampleStream` (bbb_awgn_stream_*): `next()` delivers the following
+        nsamples_per_call samples; staging, the two-kernel form and the announcement of every next read are the
+        library's business."""
+        return SampleStream(self, nsamples_per_call, first_step)
+
     @staticmethod
     def tree(states, n):
         """Adder-tree value (un-truncated) of caller-supplied uniform words: `states` is an int64 CUDA
@@ -227,3 +234,66 @@ class CLTGRNG:
         _lib.check(_lib.lib().bbb_clt_tree_i16(n, C.c_void_p(states.data_ptr()), states.shape[0],
                                                C.c_void_p(out.data_ptr()), dev, _stream_ptr(dev)), "bbb_clt_tree_i16")
         return out
+
+
+class SampleStream:
+    """bbb_awgn_stream_*: the CLTGRNG sample stream read sequentially.  Context manager; closing restores the
+    generator handle's mode."""
+
+    def __init__(self, grng, nsamples_per_call, first_step=0):
+        self.grng = grng
+        self.n = int(nsamples_per_call)
+        u = grng.urng
+        s = C.c_void_p()
+        u._bind_stream()
+        _lib.check(_lib.lib().bbb_awgn_stream_open(u._h, self.n, int(first_step), 1 if grng.dtype == torch.int8 else 2, C.byref(s)),
+                   "bbb_awgn_stream_open")
+        self._s = s
+
+    def _out(self, n, out):
+        u = self.grng.urng
+        dev = torch.device("cuda", u.device)
+        if out is None:
+            out = torch.empty(n, dtype=self.grng.dtype, device=dev)
+        if out.dtype != self.grng.dtype or out.numel() < n or not out.is_contiguous() or out.device != dev:
+            raise ValueError(f"out must be a contiguous {self.grng.dtype} tensor on {dev} with >= {n} elements")
+        u._bind_stream()
+        return out
+
+    def next(self, out=None):
+        """The next nsamples_per_call samples (asynchronous on the current torch stream)."""
+        out = self._out(self.n, out)
+        _lib.check(_lib.lib().bbb_awgn_stream_next(self._s, C.c_void_p(out.data_ptr())), "bbb_awgn_stream_next")
+        return out[:self.n]
+
+    def read(self, nsamples, out=None):
+        """The next `nsamples` samples, any length; the stream continues behind them."""
+        n = int(nsamples)
+        out = self._out(n, out)
+        _lib.check(_lib.lib().bbb_awgn_stream_read(self._s, C.c_void_p(out.data_ptr()), n), "bbb_awgn_stream_read")
+        return out[:n]
+
+    def seek(self, first_step):
+        _lib.check(_lib.lib().bbb_awgn_stream_seek(self._s, int(first_step)), "bbb_awgn_stream_seek")
+
+    def tell(self):
+        v = C.c_uint64()
+        _lib.check(_lib.lib().bbb_awgn_stream_tell(self._s, C.byref(v)), "bbb_awgn_stream_tell")
+        return v.value
+
+    def close(self):
+        s, self._s = getattr(self, "_s", None), None
+        if s:
+            _lib.check(_lib.lib().bbb_awgn_stream_close(s), "bbb_awgn_stream_close")
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -130,6 +130,29 @@ int bbb_lutopt_set_staged(bbb_lutopt *h, int enable);
 /* Same stream as int16 (needed for k = 512, whose CLTGRNG output is 9 bits: rng.py:78). */
 int bbb_awgn_fill_i16(bbb_lutopt *h, int16_t *dst_dev, uint64_t nsamples, uint64_t first_step);
 
+/* The sample stream as an OBJECT that is drained sequentially -- what a CLTGRNG is: one value per clock, in order
+ * (gateware/bbb/rng.py:70-108; tx.py:70-71 is its only consumer).  The stream owns everything a fast sequential reader
+ * would otherwise have to choreograph with bbb_lutopt_set_staged / bbb_awgn_prefetch: it turns the two-kernel form on
+ * for the handle, announces every next read itself (so the start states of read i+1 are derived beside read i) and
+ * restores the handle's mode when it is closed.  A host simply calls bbb_awgn_stream_next in a loop.
+ *   open   nsamples_per_call = the length bbb_awgn_stream_next delivers (and the length the stream prepares for);
+ *          first_step = LUTOPT clocks before the first sample, as in bbb_awgn_fill_i8; elem_bytes 1 (int8, k <= 256)
+ *          or 2 (int16).  One stream per handle at a time (BBB_EINVAL otherwise); the handle must outlive it.
+ *   next   the next nsamples_per_call samples to dst_dev (16-byte aligned, elem_bytes * nsamples_per_call bytes),
+ *          asynchronous on the handle's stream like bbb_awgn_fill_i8.
+ *   read   the next `nsamples` samples, any length (a ragged tail, a short probe): the stream continues behind them.
+ *   seek   continue at another position (the announced read is re-announced there).
+ *   tell   *next_step = clocks before the sample the next read starts with.
+ * Other calls on the handle between two reads are allowed (they cost the pending announcement at most).  Every byte is
+ * the one bbb_awgn_fill_i8 / _i16 would deliver for the same position. */
+typedef struct bbb_awgn_stream bbb_awgn_stream;
+int bbb_awgn_stream_open(bbb_lutopt *h, uint64_t nsamples_per_call, uint64_t first_step, int elem_bytes, bbb_awgn_stream **s);
+int bbb_awgn_stream_next(bbb_awgn_stream *s, void *dst_dev);
+int bbb_awgn_stream_read(bbb_awgn_stream *s, void *dst_dev, uint64_t nsamples);
+int bbb_awgn_stream_seek(bbb_awgn_stream *s, uint64_t first_step);
+int bbb_awgn_stream_tell(const bbb_awgn_stream *s, uint64_t *next_step);
+int bbb_awgn_stream_close(bbb_awgn_stream *s);
+
 /* CLTGRNG adder tree on caller-supplied uniform words (the loop body of
  * software/clt-grng/clt-grng-evaluate.py:8-16): states_dev holds nstates states of
  * ceil(k/64) u64 words each; out_dev[i] = un-truncated tree value (int16). */

@@ -1,0 +1,116 @@
+"""bbb_awgn_stream_*: the CLTGRNG sample stream as an object that is drained sequentially (the reference's generator emits
+exactly one such stream, rng.py:70-108).  Byte-exact against the oracle for whole reads, ragged tails, a broken sequence
+(other calls on the handle between two reads, a seek), int16 / n512 and the table-driven path."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BIG = 1 << 24
+
+
+def test_stream_equals_oracle_whole_reads_and_ragged_tail(gpu, oracle):
+    m = oracle.Lutopt(path=oracle.data_path(256))
+    u = gpu.LUTOPT.shipped(256, init=0xC0FFEE)
+    g = gpu.CLTGRNG(u)
+    n = BIG + 4096 + 16
+    with g.stream(n, first_step=16) as st:
+        parts = [st.next() for _ in range(3)]
+        parts.append(st.read(1_000_003))              # a ragged read: the stream continues behind it
+        parts.append(st.next())
+        parts.append(st.read(17))
+        parts.append(st.read(BIG + 1))                # a large read of another length
+        assert st.tell() == 16 + 4 * n + 1_000_003 + 17 + BIG + 1
+        torch.cuda.synchronize()
+    total = sum(p.numel() for p in parts)
+    ref = m.awgn(0xC0FFEE, 16, total, fast=True)
+    off = 0
+    for i, p in enumerate(parts):
+        assert np.array_equal(p.cpu().numpy(), ref[off:off + p.numel()]), i
+        off += p.numel()
+
+
+def test_stream_survives_a_broken_sequence(gpu, oracle):
+    """Other calls on the handle between two reads (a fill elsewhere, BER trials, a word fill, a seek): the stream's
+    bytes are those of its positions whatever the announcement it had made has become."""
+    m = oracle.Lutopt(path=oracle.data_path(256))
+    u = gpu.LUTOPT.shipped(256)
+    g = gpu.CLTGRNG(u)
+    n = BIG + 48
+    st = g.stream(n, first_step=16)
+    a = st.next()
+    other = g.generate(2 * BIG + 5, first_step=7_000_000_001)              # steals the announced start states' slot
+    b = st.next()
+    t = gpu.Trial(nbits=300_001, amp=100, noise_var=8)
+    assert gpu.run_trials(u, [t])[0] == m.ber_trial(1, 31, 1, 100, 8, 16, 0, 300_001)
+    c = st.next()
+    w = u.generate_words(500, first_step=3)
+    st.seek(5_000_000_000)
+    d = st.next()
+    e = st.next()
+    st.close()
+    torch.cuda.synchronize()
+    ref = m.awgn(1, 16, 3 * n, fast=True)
+    for i, x in enumerate((a, b, c)):
+        assert np.array_equal(x.cpu().numpy(), ref[i * n:(i + 1) * n]), i
+    far = m.awgn(u.state_at(5_000_000_000), 0, 400_000, fast=True)
+    assert np.array_equal(d[:400_000].cpu().numpy(), far)
+    assert np.array_equal(e[:300_000].cpu().numpy(), m.awgn(u.state_at(5_000_000_000 + n), 0, 300_000, fast=True))
+    assert np.array_equal(other[:200_000].cpu().numpy(), m.awgn(u.state_at(7_000_000_001), 0, 200_000, fast=True))
+    assert np.array_equal(w.cpu().numpy().view(np.uint32), m.words_u32(1, 3, 500))
+
+
+def test_stream_owns_the_mode_and_restores_it(gpu):
+    l = gpu._lib.lib()
+    u = gpu.LUTOPT.shipped(256)
+    g = gpu.CLTGRNG(u)
+    plain = g.generate(BIG + 16, first_step=16)                          # one-kernel form (staged off)
+    st = g.stream(BIG + 16, first_step=16)
+    with pytest.raises(ValueError):
+        g.stream(BIG, first_step=0)                                       # one stream per handle
+    x = st.next()
+    st.close()
+    assert torch.equal(x, plain)
+    st2 = g.stream(BIG + 16, first_step=16)                               # ... and again after close
+    assert torch.equal(st2.next(), plain)
+    st2.close()
+    # a handle on which the caller chose look-ahead keeps it while a stream is open and afterwards
+    u.set_staged(True, look_ahead=2)
+    with g.stream(BIG + 16, first_step=16) as st3:
+        y = [st3.next() for _ in range(3)]
+    assert torch.equal(y[0], plain)
+    again = g.generate(BIG + 16, first_step=16)
+    assert torch.equal(again, plain)
+    # null / bad arguments
+    s = C.c_void_p()
+    assert l.bbb_awgn_stream_open(u._h, 0, 0, 1, C.byref(s)) == gpu._lib.BBB_EINVAL
+    assert l.bbb_awgn_stream_open(u._h, 100, 0, 3, C.byref(s)) == gpu._lib.BBB_EINVAL
+    assert l.bbb_awgn_stream_next(None, None) == gpu._lib.BBB_EINVAL
+    assert l.bbb_awgn_stream_close(None) == gpu._lib.BBB_OK
+
+
+@pytest.mark.parametrize("k", [32, 512])
+def test_stream_on_other_orders(gpu, oracle, k):
+    """The table-driven path (n32) and the packed n512 kernel (int16): the stream is the same object."""
+    m = oracle.Lutopt(path=oracle.data_path(k))
+    u = gpu.LUTOPT.shipped(k)
+    g = gpu.CLTGRNG(u)
+    n = 200_000 if k == 32 else (1 << 20) + 8
+    first = 2 * (k.bit_length() - 1)
+    with g.stream(n, first_step=first) as st:
+        parts = [st.next(), st.next(), st.read(1001)]
+        torch.cuda.synchronize()
+    pos = first
+    for p in parts:
+        got = p.cpu().numpy().astype(np.int64)
+        if k == 32:
+            exp = m.awgn(u.state_at(pos), 0, p.numel()).astype(np.int64)
+        else:
+            cnt = min(p.numel(), 20_000)
+            exp = ((m.clt_tree_bulk(m.states(u.state_at(pos), 0, cnt)).astype(np.int64) + 256) % 512) - 256
+            got = got[:cnt]
+        assert np.array_equal(got, exp)
+        pos += p.numel()
