@@ -555,7 +555,7 @@ int awgn256_planes_launch(const uint32_t *d_planes, void *stage, unsigned L, uns
 // LDS (dynamic, ONE array: 2 x 32 KiB raw + 32 KiB tile): the DMA of unit u+1 is in flight while unit u is processed;
 // raw barriers and counted vmcnt (a __syncthreads() would drain the DMA: cdna_hip_programming.md, "Pipelining across barriers").
 // One block of four waves per CU, persistent over its share of the units.
-constexpr unsigned kUnplaneRaw = 32 * 1024, kUnplaneLds = 3 * 32 * 1024, kUnplaneLdsTx = kUnplaneLds + 256 * 8 * 2;
+constexpr unsigned kUnplaneRaw = 32 * 1024, kUnplaneLds = 3 * 32 * 1024, kUnplaneLdsTx = kUnplaneLds + 256 * 8 * 2 + 2 * 2048;
 
 template <bool TXM>
 __global__ void __launch_bounds__(256, 7)      // <= 72 registers: a wave of this kernel must fit beside the sample kernel's (<= 440 of 512)
@@ -583,6 +583,7 @@ unplane_kernel(const u32x4 *__restrict stage, char *__restrict dst, unsigned lon
     // samples x = wrap12(bit_en shaped + g noise_var) (tx.py:75-81), the arithmetic of the fused kernel's round end (TxFuse, the
     // table TT and the window / select / multiply-add scheme described above awgn256_kernel) done here, by the guest
     uint16_t *const TT = reinterpret_cast<uint16_t *>(lds + kUnplaneLds / 4);
+    uint32_t *const winb = lds + kUnplaneLds / 4 + 1024;      // [2][256 generators][2 words]: the units' data-bit windows, by DMA
     uint32_t selmask[4] = {0, 0, 0, 0};
     if (TXM) {
         for (int e = (int)tid; e < 256 * 8; e += 256) {
@@ -626,6 +627,25 @@ unplane_kernel(const u32x4 *__restrict stage, char *__restrict dst, unsigned lon
             const u32x4 *g = src + ((size_t)st * 2 + (c & 1)) * 64;
             __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)(uintptr_t)(lds + buf * (kUnplaneRaw / 4) + b * 256), 16, 0, 0);
         }
+        if (TXM) {
+            // the data bits the unit's pieces will need: per generator the two 32-bit words that hold the windows of its 128
+            // samples (16 data bits + 10 of window), fetched like the planes: no registers, landed before phase 2 asks
+#pragma unroll
+            for (unsigned i = 0; i < 2; i++) {
+                const unsigned e = (wv * 2 + i) * 64 + lane, row = e >> 1;
+                const unsigned long long gq = (w * 32 + (row >> 3)) * 64 + q8 * 8 + (row & 7);
+                const unsigned long long o = gq * (unsigned long long)L + step0;
+                // (the window may start inside the unit: the unit's first sample then has a negative position in this call;
+                // the buffer leads with 128 zero bits, so the word index stays >= 0)
+                uint32_t word = 0;
+                if (o + 128 > win_lo && o < nbytes) {
+                    const long long pu = (long long)o - (long long)win_lo;
+                    word = ((uint32_t)((pu >> 3) + (long long)tx.rel_base) >> 5) + (e & 1);
+                }
+                word = word < tx.last_word ? word : tx.last_word;
+                __builtin_amdgcn_global_load_lds((const void *)(tx.bits + word), (lds_void_ptr)(uintptr_t)(winb + buf * 512 + (wv * 2 + i) * 64), 4, 0, 0);
+            }
+        }
     };
     unsigned buf = 0;
     if (blockIdx.x < nunits) dma_unit(blockIdx.x, 0);
@@ -637,7 +657,8 @@ unplane_kernel(const u32x4 *__restrict stage, char *__restrict dst, unsigned lon
         const bool more = u + gridDim.x < nunits;
         if (more) dma_unit(u + gridDim.x, buf ^ 1);
         // this unit's DMA (and the previous unit's stores, which are older) done: all but the 8 instructions just issued
-        if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (more && TXM) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         // ---- phase 1
@@ -695,19 +716,6 @@ unplane_kernel(const u32x4 *__restrict stage, char *__restrict dst, unsigned lon
             // positions are relative to the window: sample p of this call = stream offset win_lo + p; dst holds int16
             int16_t *const dst16 = reinterpret_cast<int16_t *>(dst);
             const u16x2 nv16 = {(uint16_t)(tx.noise_var * 16), (uint16_t)(tx.noise_var * 16)};
-            // the data windows of this thread's 8 pieces first (8 loads in flight), then the shaping
-            uint32_t win[8];
-#pragma unroll
-            for (unsigned k = 0; k < 8; k++) {
-                const unsigned long long o = off + k * goff;
-                win[k] = 0;
-                if (g0 + 256ull * k < G && o >= win_lo && o < nbytes && tx.use_bits) {
-                    const uint32_t rel = ((uint32_t)(o - win_lo) >> 3) + tx.rel_base;           // fits 32 bits (host check)
-                    const uint32_t byte = min(rel >> 3, tx.last_word * 4u - 4u);
-                    typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
-                    win[k] = *reinterpret_cast<const u32_unaligned *>(reinterpret_cast<const char *>(tx.bits) + byte);
-                }
-            }
 #pragma unroll
             for (unsigned k = 0; k < 8; k++) {
                 const unsigned long long o = off + k * goff;
@@ -715,9 +723,16 @@ unplane_kernel(const u32x4 *__restrict stage, char *__restrict dst, unsigned lon
                 if (o < win_lo) continue;
                 const unsigned long long p0 = o - win_lo;                                        // first sample of the piece, in this call
                 const uint32_t rel = ((uint32_t)p0 >> 3) + tx.rel_base;
+                // the generator's two window words (dma_unit), and where the unit's first sample sits in them
+                const unsigned row = (4 * k + wv) * 8 + lq;
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 ww = *reinterpret_cast<const u32x2 *>(&winb[buf * 512 + row * 2]);
+                const uint32_t rel_u = rel - 2u * c2;                                            // window position of the unit's first sample
+                const unsigned long long w64 = ((unsigned long long)ww[1] << 32) | ww[0];
+                const uint32_t wk = tx.use_bits ? (uint32_t)(w64 >> ((rel_u & 31u) + 2u * c2)) : 0u;
                 const u32x4 v = *reinterpret_cast<const u32x4 *>(&tile[rd0 + k * 1024]);
                 // the piece's 10-bit data window (bit j = data bit M0 - 7 + j), as in the fused kernel
-                const uint32_t Q4 = ((win[k] >> (rel & 7u)) & 0x3ffu) << 4;
+                const uint32_t Q4 = (wk & 0x3ffu) << 4;
                 const char *tt = reinterpret_cast<const char *>(TT);
                 const u32x4 A = *reinterpret_cast<const u32x4 *>(tt + (Q4 & 0xff0u));
                 const u32x4 B = *reinterpret_cast<const u32x4 *>(tt + ((Q4 >> 1) & 0xff0u));

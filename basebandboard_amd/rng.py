@@ -167,6 +167,13 @@ class LUTOPT:
                    "bbb_lutopt_profile_read")
         return a.value, b.value, n.value
 
+    def profile_read_mover(self, reset=True):
+        """(mover_ms, movers): the second kernel of the two-kernel form, timed on its own stream."""
+        a, n = C.c_double(), C.c_uint64()
+        _lib.check(_lib.lib().bbb_lutopt_profile_read_mover(self._h, C.byref(a), C.byref(n), int(reset)),
+                   "bbb_lutopt_profile_read_mover")
+        return a.value, n.value
+
     def _bind_stream(self):
         _lib.check(_lib.lib().bbb_lutopt_set_stream(self._h, _stream_ptr(self.device)), "bbb_lutopt_set_stream")
 

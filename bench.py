@@ -9,12 +9,15 @@
 
 One step = one pass of the hot path over one batch: 1e9 int8 CLT samples of the reference's
 LUTOPT-256 -> CLTGRNG generator (BASELINE.json configs[1]; the reference has no "CLT-12 /
-xorshift32" generator) written to HBM.  Step s of rank r generates
-stream positions [16 + (s*world + r)*1e9, +1e9): a different part of the SAME sequential stream
-every step and every rank, so nothing is cached between steps and ranks are independent shards
-(weak scaling, no data-path collective).  Seeding (GF(2) jump-ahead on the GPU) is inside the
-timed region; the seeding of step s+1 is announced with bbb_awgn_prefetch right after step s is
-launched, so that it runs beside step s's sample kernel (BENCH_NO_PREFETCH=1 turns that off).
+xorshift32" generator) written to HBM: one bbb_awgn_stream_next on the
+rank's sample stream (the C ABI's sequential-stream object).  Rank r reads its own contiguous
+stretch of the ONE sequential reference stream, 2^48 steps apart, a new part every step, so
+nothing is cached between steps and ranks are independent shards (weak scaling, no data-path
+collective).  Seeding (GF(2) jump-ahead on the GPU), sample kernels and movers are all inside
+the timed region.  Before the W warm-up steps the untimed region also holds BENCH_RAMP_STEPS
+(default 64) more of the same steps: this part's clock governor needs ~50 ms of load to leave
+its idle state (profiles/r03_ramp_clock_per_launch.log: 1.75 GHz at step 2 after an idle second,
+2.17 at step 10, 2.38 from step 40 on); `extra.cold_start` reports the K steps straight from idle.
 
 The JSON line also carries
   roofline     achieved HBM-write GB/s of the sample kernel (algorithmic 1 B/sample / its mean
@@ -140,6 +143,8 @@ def launch_ranks(n):
                                       stdout=None if r == 0 else sys.stderr))
     rc = 0
     pending = dict(enumerate(procs))
+    deadline = time.time() + float(os.environ.get("BENCH_LAUNCH_TIMEOUT_S", "1500"))      # the whole launch
+    kill_at = None                                                                          # after a failure: grace period, then SIGKILL
     while pending:
         for r, p in list(pending.items()):
             code = p.poll()
@@ -151,6 +156,17 @@ def launch_ranks(n):
                 print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
                 for q in pending.values():
                     q.terminate()           # exactly the PIDs started above
+                kill_at = time.time() + 20
+        if pending and rc == 0 and time.time() > deadline:
+            rc = 124
+            print("bench.py: launch timed out; stopping the ranks", file=sys.stderr)
+            for q in pending.values():
+                q.terminate()
+            kill_at = time.time() + 20
+        if pending and kill_at is not None and time.time() > kill_at:
+            for q in pending.values():      # a rank stuck in a rendezvous or a GPU call ignores SIGTERM
+                q.kill()
+            kill_at = time.time() + 3600
         time.sleep(0.05)
     return rc
 
@@ -216,18 +232,15 @@ def main():
     from basebandboard_amd import channel
     u = bbb.LUTOPT.shipped(256, init=1, device=local_rank)
     assert u.specialised, "bench must run the generated gfx950 kernel"
-    # the two-kernel form of the stream (bbb_lutopt_set_staged): the sample kernel writes full lines into a staging
-    # buffer, a piece mover puts them in place beside the NEXT step's arithmetic; same bytes (tests/test_gpu_staged.py).
-    # BENCH_ONE_KERNEL=1 times the one-kernel form instead (it is also reported in `extra`).
-    # Look-ahead (levels 2..8 of the same switch; BENCH_LOOK_AHEAD=m turns it on): a step's sample kernel also produces the
-    # next m - 1 steps' samples (one seeding, one launch per m steps), which are then only their piece movers.  Off by
-    # default: same-box A/B runs put m = 2 between -1 % and +3.5 % of m = 1, i.e. inside the box-to-box noise (DESIGN.md
-    # 3.3b), and with it a --steps that is no multiple of m would time work whose output is never asked for.
+    # The timed loop drains the rank's sample stream through the C ABI's stream object (bbb_awgn_stream_open / _next):
+    # the two-kernel form (sample kernel -> count planes in a staging slot, mover -> bytes beside the NEXT kernel), two reads
+    # per sample kernel, every next read announced by the library.  BENCH_ONE_KERNEL=1 times plain bbb_awgn_fill_i8 calls
+    # in the one-kernel form instead (also reported in `extra`); BENCH_LEVEL=1 / 4 ... picks another level of
+    # bbb_lutopt_set_staged for the stream (1: one read per sample kernel).
     staged = not os.environ.get("BENCH_ONE_KERNEL")
-    look_ahead = int(os.environ.get("BENCH_LOOK_AHEAD", "0")) if staged else 0
-    if look_ahead < 2:
-        look_ahead = 0
-    u.set_staged(staged, look_ahead=look_ahead)
+    level = int(os.environ.get("BENCH_LEVEL", "0")) if staged else 0
+    if level:
+        u.set_staged(True, look_ahead=level if level >= 2 else False)
     g = bbb.CLTGRNG(u)
     buf = torch.empty(NSAMP, dtype=torch.int8, device=f"cuda:{local_rank}")
 
@@ -237,49 +250,75 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def first_step(step):
-        # every rank reads its own contiguous stretch of the one stream, 2^48 steps apart (jump-ahead makes any start
-        # position as cheap as any other); within a rank the steps follow each other
-        return WARM_STATE + (rank << 48) + step * NSAMP
-
-    # parity spot check before timing (rank 0): a prefix of step 0 against the oracle
-    verified = None
-    g.generate(NSAMP, first_step=first_step(0), out=buf)
-    if rank == 0:
-        import numpy as np
-        import oracle as O
-        m = O.Lutopt(path=O.data_path(256))
-        verified = bool(np.array_equal(buf[:1_000_000].cpu().numpy(), m.awgn(1, WARM_STATE, 1_000_000, fast=True)))
-        tail0 = NSAMP - 4096
-        verified = verified and bool(np.array_equal(buf[tail0:].cpu().numpy(),
-                                                    m.awgn(u.state_at(WARM_STATE + tail0), 0, 4096, fast=True)))
+    # every rank reads its own contiguous stretch of the one stream, 2^48 steps apart (jump-ahead makes any start
+    # position as cheap as any other); within a rank the steps follow each other
+    first0 = WARM_STATE + (rank << 48)
+    first_step = lambda step: first0 + step * NSAMP
     prefetch = not os.environ.get("BENCH_NO_PREFETCH")
-    for s in range(1, args.warmup + 1):
-        g.generate(NSAMP, first_step=first_step(s), out=buf)
-        if prefetch:
-            g.prefetch(NSAMP, first_step=first_step(s + 1))
-    if look_ahead:
-        # the timed region must not inherit arithmetic from the warm-up: drop a waiting second half, so that the first
-        # timed step launches a sample kernel (with an odd --steps the last kernel's second half is produced and unused)
-        u.set_staged(staged, look_ahead=look_ahead)
-        if prefetch:
-            g.prefetch(NSAMP, first_step=first_step(args.warmup + 1))
+    st = g.stream(NSAMP, first_step=first0) if staged else None
+    pos = [0]
+
+    def one_step():
+        if st is not None:
+            st.next(out=buf)
+        else:
+            g.generate(NSAMP, first_step=first_step(pos[0]), out=buf)
+            if prefetch:
+                g.prefetch(NSAMP, first_step=first_step(pos[0] + 1))
+        pos[0] += 1
+
+    def drop_ahead():
+        # the timed region must not inherit arithmetic from the untimed one: a waiting second half of a sample kernel's
+        # output is dropped, so that the first timed step launches a kernel (with an odd --steps the last kernel's second
+        # half is produced inside the timed region and unused)
+        if st is not None:
+            st.seek(st.tell())
+
+    # step 0: kept for the parity check (rank 0) -- a prefix and the tail are copied aside on the device now and compared
+    # with the oracle AFTER the timed region, so that the GPU does not idle in front of it
+    one_step()
+    head_d, tail_d = buf[:1_000_000].clone(), buf[NSAMP - 4096:].clone()
+    torch.cuda.synchronize()
+    # cold start: the K steps as a process finds them when it comes out of an idle GPU (for the record: `extra.cold_start`)
+    drop_ahead()
+    barrier()
+    tc = time.perf_counter()
+    for s in range(args.steps):
+        one_step()
+    barrier()
+    cold_ms = (time.perf_counter() - tc) / args.steps * 1e3
+    # clock ramp: untimed steps until the governor has left its idle state, then the W warm-up steps
+    ramp_steps = int(os.environ.get("BENCH_RAMP_STEPS", "64"))
+    for s in range(ramp_steps + args.warmup):
+        one_step()
+    drop_ahead()
     u.profile(True)
-    u.profile_read(reset=True)
+    u.profile_read(reset=True); u.profile_read_mover(reset=True)
     barrier()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        g.generate(NSAMP, first_step=first_step(args.warmup + 1 + s), out=buf)
-        if prefetch:      # seeding of the following step, issued now so that it runs beside this step's kernel
-            g.prefetch(NSAMP, first_step=first_step(args.warmup + 2 + s))
+        one_step()
     barrier()
     dt = time.perf_counter() - t0
     seed_ms, kern_ms, calls = u.profile_read(reset=True)
+    mover_ms, movers = u.profile_read_mover(reset=True)
     u.profile(False)
+    if st is not None:
+        st.close()
+    look_ahead = level if level >= 2 else (2 if (staged and not level) else 0)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    verified = None
+    if rank == 0:
+        import numpy as np
+        import oracle as O
+        m = O.Lutopt(path=O.data_path(256))
+        verified = bool(np.array_equal(head_d.cpu().numpy(), m.awgn(1, WARM_STATE, 1_000_000, fast=True)))
+        verified = verified and bool(np.array_equal(tail_d.cpu().numpy(),
+                                                    m.awgn(u.state_at(WARM_STATE + NSAMP - 4096), 0, 4096, fast=True)))
+    del head_d, tail_d
 
     value = world * args.steps * NSAMP / dt / 1e9
     kern_avg_ms = kern_ms / max(calls, 1)                 # per LAUNCH of the sample kernel
@@ -301,19 +340,22 @@ def main():
         fill_gbs = 5 * NSAMP / f0.elapsed_time(f1) / 1e6
         del fb
 
-    # HBM bytes per launch from the PMC counters: they need their own rocprofv3 passes (--pmc WRITE_SIZE /
-    # --pmc FETCH_SIZE, profiles/README.md), so the line carries the committed summary of this round's pass and
-    # says which file it came from (stale if the kernel changed since)
-    traffic = traffic_src = None
-    for name in ("r02_awgn256_la_pmc.json", "r02_awgn256_pmc.json", "r01_awgn256_pmc.json"):
+    # HBM bytes and issued instructions from the PMC counters: they need their own rocprofv3 passes (profiles/README.md:
+    # --pmc WRITE_SIZE, --pmc FETCH_SIZE, an SQ pass; counter collection serialises the kernels), so the line carries the
+    # committed summary of this round's passes and says which file it came from (stale if the kernels changed since)
+    traffic = traffic_src = traffic_step = None
+    pmc_rec = {}
+    for name in ("r03_awgn_pmc.json",):
         pmc = ROOT / "profiles" / name
-        if pmc.exists():
+        if pmc.exists() and staged:
             try:
                 rec = json.load(open(pmc))
-                if int(rec.get("samples_per_launch", NSAMP)) != per_launch:
-                    continue                      # measured on launches of another size (with / without look-ahead)
-                traffic = rec.get("awgn256_kernel_hbm_bytes_per_launch")
-                traffic_src = f"profiles/{name} (separate --pmc WRITE_SIZE / FETCH_SIZE passes over this command; stale if the kernel changed since)"
+                if int(rec.get("samples_per_launch", 0)) != per_launch:
+                    continue                      # measured on launches of another size (another level)
+                pmc_rec = rec
+                traffic = rec["sample_kernel"]["hbm_bytes_per_launch"]["total"]
+                traffic_step = rec.get("traffic_per_read")
+                traffic_src = f"profiles/{name} (separate --pmc passes over bench.py; kernels run alone under counter collection; stale if they changed since)"
                 break
             except Exception:
                 traffic = None
@@ -341,21 +383,23 @@ def main():
                     "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": int(nbytes), "kernel_ms_avg": round(ms, 4),
                     "what": what}
 
-        # the other form of the same stream, a few steps outside the timed region
-        u2 = bbb.LUTOPT.shipped(256, init=1, device=local_rank)
-        u2.set_staged(not staged)
-        g2 = bbb.CLTGRNG(u2)
-        for s_ in range(2):
-            g2.generate(NSAMP, first_step=first_step(s_), out=buf); g2.prefetch(NSAMP, first_step=first_step(s_ + 1))
-        u2.profile(True); u2.profile_read(reset=True)
-        torch.cuda.synchronize(); t_o = time.perf_counter()
-        for s_ in range(2, 8):
-            g2.generate(NSAMP, first_step=first_step(s_), out=buf); g2.prefetch(NSAMP, first_step=first_step(s_ + 1))
-        torch.cuda.synchronize(); t_o = (time.perf_counter() - t_o) / 6
-        _, k_o, c_o = u2.profile_read(reset=True)
-        extra["awgn_other_form"] = {"form": "one kernel" if staged else "two kernels (staged)", "ms_per_step": round(t_o * 1e3, 4),
-                                    "gsample_s": round(NSAMP / t_o / 1e9, 1), "sample_kernel_ms_avg": round(k_o / max(c_o, 1), 4)}
-        del u2, g2
+        # the other forms of the same stream, outside the timed region (hot GPU, 20 steps each): plain bbb_awgn_fill_i8 +
+        # bbb_awgn_prefetch calls in the one-kernel form and in the two-kernel form at level 1 (one read per sample kernel)
+        def other_form(level_):
+            u2 = bbb.LUTOPT.shipped(256, init=1, device=local_rank)
+            u2.set_staged(level_ > 0)
+            g2 = bbb.CLTGRNG(u2)
+            for s_ in range(8):
+                g2.generate(NSAMP, first_step=first_step(s_), out=buf); g2.prefetch(NSAMP, first_step=first_step(s_ + 1))
+            u2.profile(True); u2.profile_read(reset=True)
+            torch.cuda.synchronize(); t_o = time.perf_counter()
+            for s_ in range(8, 28):
+                g2.generate(NSAMP, first_step=first_step(s_), out=buf); g2.prefetch(NSAMP, first_step=first_step(s_ + 1))
+            torch.cuda.synchronize(); t_o = (time.perf_counter() - t_o) / 20
+            _, k_o, c_o = u2.profile_read(reset=True)
+            return {"ms_per_step": round(t_o * 1e3, 4), "gsample_s": round(NSAMP / t_o / 1e9, 1), "sample_kernel_ms_avg": round(k_o / max(c_o, 1), 4)}
+        extra["awgn_other_forms"] = {"one_kernel (bbb_awgn_fill_i8 + bbb_awgn_prefetch, staged off)": other_form(0),
+                                     "two_kernels_level_1 (bbb_lutopt_set_staged(h, 1): one read per sample kernel)": other_form(1)}
         # PRBS-31 loopback (BASELINE configs[2]): 1e10 bits written, then read back and checked.  Per pass, device
         # time between hipEvents on the launch stream: the fill, the check right after the fill (the loopback order:
         # it also pays for the write-backs of the fill's last 256 MiB, which are still dirty in the memory-side cache),
@@ -442,12 +486,11 @@ def main():
         tx_ms = tx_rate(ntx, True)
         tx_ms_1k = tx_rate(1 << 29, False)
         extra["tx_waveform"] = {"samples": ntx, "gsample_s": round(ntx / tx_ms / 1e6, 1), "ms_per_call": round(tx_ms, 4),
-                                "form": "staged (bbb_lutopt_set_staged on the TX's generator handle): noise kernel + shaping mover",
+                                "form": "staged (bbb_lutopt_set_staged on the TX's generator handle): noise kernel (count planes) + shaping mover",
                                 "one_kernel_form_2p29_per_call": {"gsample_s": round((1 << 29) / tx_ms_1k / 1e6, 1), "ms_per_call": round(tx_ms_1k, 4)},
-                                "note": "bbb_tx_fill_i16: PRBS fill + the sample kernel with the shaper fused into its round end "
-                                        "(int16 out, the int8 noise never goes through HBM)"}
-        r = hbm("awgn256_kernel<false, true> + tx_unstage_kernel (whole bbb_tx_fill_i16 call)", 2.0 * ntx, tx_ms, "2 B per sample delivered (4 B of HBM traffic: int8 staging write and read, int16 output write)")
-        r["true_bound"] = "integer VALU of the noise generator at one wave per SIMD, slowed by its guests (shaping mover, seeding, data bits) on the same CUs"
+                                "note": "bbb_tx_fill_i16; the one-kernel form has the shaper fused into the sample kernel's round end"}
+        r = hbm("awgn256_planes_kernel + unplane_kernel<true> (whole bbb_tx_fill_i16 call)", 2.0 * ntx, tx_ms, "2 B per sample delivered (4 B of HBM traffic: count planes written and read, int16 output written)")
+        r["true_bound"] = "the shaping mover: a guest of the noise kernel (one wave per SIMD, about one issue slot in ten cycles), ~950 instructions per 32 KiB unit"
         other.append(r)
         # PRBSShaper.x alone (noise off): PRBS fill + table rows, 2 B per sample written
         txs = bbb.TX(31, 1, 0, 16, 0, 8, device=local_rank)
@@ -483,7 +526,9 @@ def main():
         # pass per rank), ONE all-reduce (RCCL) sums the uint64 counters: N times the bits per point in the same time.
         nv = 8
         trials = [channel.Trial(nbits=1_000_000_000, amp=channel.amp_for_ebn0(db, nv), noise_var=nv) for db in range(11)]
-        us = u if world == 1 else bbb.LUTOPT.shipped(256, init=1 + rank, device=local_rank)
+        # one seed per rank = the reset state jumped 2^48 r clocks ahead: disjoint stretches of the one cycle (reset states that
+        # differ by small integers are XOR-dependent and nothing keeps their streams apart)
+        us = u if world == 1 else bbb.LUTOPT.shipped(256, init=u.state_at(rank << 48), device=local_rank)
         # untimed: builds the jump plans (tables per segment length).  At another stream position, so that the timed sweep
         # derives its own start states: the library keeps the last start states of a handle and would hand them back
         warm = [channel.Trial(nbits=t.nbits, amp=t.amp, noise_var=nv, first_bit=1 << 20) for t in trials]
@@ -517,6 +562,24 @@ def main():
                                               "reduce": "ncclAllReduce(ncclUint64, ncclSum) of uint64[22] inside bbb_ber_sweep_multi"}
 
     if rank == 0:
+        # issued VALU instructions per step and wave: from the SQ pass of this round (SQ_INSTS_VALU), else the ISA count
+        sk = pmc_rec.get("sample_kernel", {})
+        issued_per_step = sk.get("valu_insts_per_step_and_wave")
+        issued_src = "SQ_INSTS_VALU of the committed counter pass" if issued_per_step else "ISA count (hipcc -S): 918 network + 142 accvgpr moves"
+        if not issued_per_step:
+            issued_per_step = 1060.5 if staged else 1249.0
+        samples_per_s = achieved * 1e9                                   # of the sample kernel while it runs
+        net_t = ops_per_step / 32.0 * samples_per_s / 1e12               # network lane-ops only
+        issued_t = issued_per_step / 32.0 * samples_per_s / 1e12         # every issued VALU instruction (moves, address arithmetic)
+        mover_avg_ms = mover_ms / max(movers, 1)
+        if staged and mover_avg_ms > 0:
+            mbytes = (pmc_rec.get("mover", {}).get("hbm_bytes_per_launch") or {}).get("total")
+            other.insert(0, {"kernel": "unplane_kernel<false> (the mover of the two-kernel form, beside the next sample kernel)", "bound": "hbm",
+                             "achieved": round(2.0 * NSAMP / mover_avg_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(2.0 * NSAMP / mover_avg_ms / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": 2 * NSAMP,
+                             "kernel_ms_avg": round(mover_avg_ms, 4), "launches_timed": int(movers), "traffic": mbytes,
+                             "what": "1 B per sample read (count planes) + 1 B written (the stream); a guest of the sample kernel: one 58-register "
+                                     "wave per SIMD, LDS-DMA loads, bound by latency and by the issue slots the host wave leaves (about one in ten cycles)"})
         out = {
             "metric": "awgn_clt_gsamples_per_s", "value": round(value, 3), "unit": "Gsample/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -526,33 +589,45 @@ def main():
                                    "warm-up 16, sequential reference stream (BASELINE configs[1]; reference-faithful "
                                    "generator, no xorshift/CLT-12 exists in the reference)",
                        "samples_per_step_per_gpu": NSAMP, "seeding_in_timed_region": True,
-                       "form": "two kernels: sample kernel -> staging buffer (full lines), piece mover -> output, the mover of step s "
-                               "beside the arithmetic of step s+1; all of it inside the timed region"
-                               + (f"; look-ahead: one sample-kernel launch (and one seeding) per {look_ahead} consecutive steps, the timed region "
-                                   "starts on a launch" if look_ahead else "") if staged else "one kernel",
-                       "seeding_overlapped_by_prefetch_hint": bool(prefetch),
+                       "form": (f"bbb_awgn_stream_next on the rank's sample stream: two kernels -- sample kernel -> count planes in a staging slot, "
+                                f"mover -> bytes, the movers beside the NEXT sample kernel; one sample-kernel launch (and one seeding) per "
+                                f"{max(look_ahead, 1)} consecutive steps, the timed region starts on a launch; all of it inside the timed region")
+                               if staged else "bbb_awgn_fill_i8 + bbb_awgn_prefetch, one kernel",
+                       "clock_ramp_steps": ramp_steps,
+                       "clock_ramp_note": "untimed steps of the same workload in front of the W warm-up steps: the clock governor needs ~50 ms of load "
+                                          "to leave its idle state (profiles/r03_ramp_clock_per_launch.log); extra.cold_start is the same K steps straight from idle",
                        "verified_vs_oracle": verified},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "awgn256_kernel<false, staged>" if staged else "awgn256_kernel<false, false>", "kernel_ms_avg": round(kern_avg_ms, 4),
+                         "achieved_is": "sample kernel only: algorithmic bytes per launch / its mean duration (hipEvents on its stream)",
+                         # the whole step: sample kernel + mover + seeding, per 1e9 samples delivered
+                         "traffic_step": traffic_step,
+                         "kernel": "awgn256_planes_kernel" if staged else "awgn256_kernel<false>", "kernel_ms_avg": round(kern_avg_ms, 4),
                          "seed_ms_avg": round(seed_ms / max(calls, 1), 4), "launches_timed": int(calls),
                          "algorithmic_bytes_per_launch": per_launch,
                          "steps_per_launch": per_launch // NSAMP,
                          "streaming_fill_gb_s": round(fill_gbs, 1) if fill_gbs else None,
                          "frac_of_streaming_fill": round(achieved / fill_gbs, 4) if fill_gbs else None,
-                         "true_bound": "integer VALU (bit-sliced XOR/majority network), not HBM",
+                         "true_bound": "integer VALU issue (bit-sliced XOR / majority network) and, with the guests beside it, the chip's power "
+                                       "limit (the shader clock sits at 2.1-2.2 GHz under this load, 2.37 for the kernel alone: profiles/README.md), not HBM",
                          "valu_lane_ops_per_sample": round(ops_per_step / 32.0, 2),
-                         "valu_net_tlaneops_s": round(ops_per_step / 32.0 * achieved / 1e3, 2),
-                         # the chip's VALU issue peak: 256 CUs x 4 SIMD-32 x 32 lanes x 2.4 GHz (one wave-instruction
-                         # per 2 cycles per SIMD, reachable with >= 2 waves per SIMD) -- the honest denominator
+                         "valu_issued_per_step_and_wave": round(issued_per_step, 1), "valu_issued_source": issued_src,
+                         "valu_net_tlaneops_s": round(net_t, 2),
+                         "valu_issued_tlaneops_s": round(issued_t, 2),
+                         # three denominators, named: the chip's nominal VALU issue peak (256 CUs x 4 SIMD-32 x 32 lanes x 2.4 GHz: one
+                         # wave-instruction per 2 cycles per SIMD); the one-wave-per-SIMD ceiling the 256-plane state forces on this kernel
+                         # (a single wave issues one VALU instruction per 4 cycles); and the V_BITOP3 rate MEASURED with two and more waves
+                         # per SIMD on this part (profiles/r01_design_ubench.log: 2.85 cycles per instruction = 55-57 T lane-op/s)
                          "valu_peak_tlaneops_s": 78.64,
-                         "valu_frac": round(ops_per_step / 32.0 * achieved / 1e3 / 78.64, 3),
-                         # this kernel holds the whole register file (256 state planes), i.e. ONE wave per SIMD, and a
-                         # single wave issues one VALU instruction per 4 cycles (SQ_ACTIVE_INST_VALU = SQ_INSTS_VALU
-                         # quad-cycles, profiles/r01_d_pmc_sq.json): half the peak above is its structural ceiling
                          "valu_peak_1wave_tlaneops_s": 39.32,
-                         "valu_frac_of_1wave_ceiling": round(ops_per_step / 32.0 * achieved / 1e3 / 39.32, 3)},
+                         "valu_attainable_measured_tlaneops_s": 56.0,
+                         "valu_frac": round(net_t / 78.64, 3),
+                         "valu_frac_issued": round(issued_t / 78.64, 3),
+                         "valu_frac_issued_of_1wave_ceiling": round(issued_t / 39.32, 3),
+                         "valu_frac_issued_of_measured_attainable": round(issued_t / 56.0, 3)},
         }
+        extra["cold_start"] = {"ms_per_step": round(cold_ms, 4), "gsample_s": round(NSAMP / cold_ms / 1e6, 1),
+                               "what": f"the same {args.steps} steps timed straight after the parity copy, GPU coming out of idle, no clock ramp"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             if extra:

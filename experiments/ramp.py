@@ -7,12 +7,13 @@ from basebandboard_amd import _lib as _l
 if os.environ.get('BBB_EXP'): _l.select_build('experiments')
 import basebandboard_amd as bbb
 N = 1_000_000_000
-u = bbb.LUTOPT.shipped(256); u.set_staged(True); g = bbb.CLTGRNG(u)
+LA = int(os.environ.get('RAMP_LA', '0'))
+u = bbb.LUTOPT.shipped(256); u.set_staged(True, look_ahead=LA if LA >= 2 else False); g = bbb.CLTGRNG(u)
 buf = torch.empty(N, dtype=torch.int8, device="cuda")
 for s in range(3):
     g.generate(N, first_step=16 + s * N, out=buf)
 torch.cuda.synchronize()
-for idle in (2.0, 0.2, 0.0):
+for idle in ((2.0, 0.2, 0.0) if not os.environ.get('RAMP_QUICK') else (0.0,)):
     time.sleep(idle)
     K = int(os.environ.get("RAMP_K", "600"))
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]

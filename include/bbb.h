@@ -82,6 +82,9 @@ int bbb_lutopt_is_specialised(const bbb_lutopt *h);
  * milliseconds (seeding / sample kernel) and the number of calls; reset != 0 clears the sums. */
 int bbb_lutopt_profile(bbb_lutopt *h, int enable);
 int bbb_lutopt_profile_read(bbb_lutopt *h, double *seed_ms, double *kernel_ms, uint64_t *calls, int reset);
+/* The same for the second kernel of the two-kernel form (the mover, on its internal stream): accumulated milliseconds
+ * and number of movers since the last reset. */
+int bbb_lutopt_profile_read_mover(bbb_lutopt *h, double *mover_ms, uint64_t *calls, int reset);
 
 /* LUTOPT.x after `nsteps` clocks from reset (rng.py:38-40), by GF(2) jump-ahead
  * (the x' = A x algebra of software/rnghunt/src/binary_matrix.rs:53-76). Host result. */
@@ -133,15 +136,17 @@ int bbb_awgn_fill_i16(bbb_lutopt *h, int16_t *dst_dev, uint64_t nsamples, uint64
 /* The sample stream as an OBJECT that is drained sequentially -- what a CLTGRNG is: one value per clock, in order
  * (gateware/bbb/rng.py:70-108; tx.py:70-71 is its only consumer).  The stream owns everything a fast sequential reader
  * would otherwise have to choreograph with bbb_lutopt_set_staged / bbb_awgn_prefetch: it turns the two-kernel form on
- * for the handle, announces every next read itself (so the start states of read i+1 are derived beside read i) and
- * restores the handle's mode when it is closed.  A host simply calls bbb_awgn_stream_next in a loop.
+ * for the handle (with two reads per sample kernel, level 2 of bbb_lutopt_set_staged, unless the caller had chosen a
+ * level: staging then takes 4 bytes per sample of a read), announces every next read itself (so the start states are
+ * derived beside the running kernel) and restores the handle's mode when it is closed.  A host simply calls
+ * bbb_awgn_stream_next in a loop.
  *   open   nsamples_per_call = the length bbb_awgn_stream_next delivers (and the length the stream prepares for);
  *          first_step = LUTOPT clocks before the first sample, as in bbb_awgn_fill_i8; elem_bytes 1 (int8, k <= 256)
  *          or 2 (int16).  One stream per handle at a time (BBB_EINVAL otherwise); the handle must outlive it.
  *   next   the next nsamples_per_call samples to dst_dev (16-byte aligned, elem_bytes * nsamples_per_call bytes),
  *          asynchronous on the handle's stream like bbb_awgn_fill_i8.
  *   read   the next `nsamples` samples, any length (a ragged tail, a short probe): the stream continues behind them.
- *   seek   continue at another position (the announced read is re-announced there).
+ *   seek   continue at another position (what was produced ahead at the old one is dropped, the next read announced there).
  *   tell   *next_step = clocks before the sample the next read starts with.
  * Other calls on the handle between two reads are allowed (they cost the pending announcement at most).  Every byte is
  * the one bbb_awgn_fill_i8 / _i16 would deliver for the same position. */

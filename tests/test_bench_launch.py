@@ -62,4 +62,6 @@ def test_single_gpu_line_has_the_contract_fields():
         assert k in out
     rf = out["roofline"]
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
-    assert 0 < rf["valu_frac"] < rf["valu_frac_of_1wave_ceiling"] < 1 and rf["kernel_ms_avg"] / rf["steps_per_launch"] <= out["ms_per_step"] * 1.05
+    assert 0 < rf["valu_frac"] < rf["valu_frac_issued"] < rf["valu_frac_issued_of_measured_attainable"] < rf["valu_frac_issued_of_1wave_ceiling"] < 1
+    assert rf["kernel_ms_avg"] / rf["steps_per_launch"] <= out["ms_per_step"] * 1.05
+    assert out["config"]["clock_ramp_steps"] >= 0 and out["extra"]["cold_start"]["ms_per_step"] > 0
