@@ -1499,13 +1499,25 @@ int bbb_multi_release(void) {
 int bbb_ber_sweep_multi(bbb_lutopt *const *handles, int ndev, const bbb_trial_cfg *cfgs, int ncfg, int mode, bbb_ber *out) {
     if (!handles || ndev < 1 || ncfg < 0 || (ncfg && (!cfgs || !out))) return fail(BBB_EINVAL, "null argument");
     if (ncfg == 0) return BBB_OK;
+    // the calling thread's current device is restored on every way out (the loops below select each handle's device in turn)
+    struct DeviceGuard {
+        int dev = -1;
+        DeviceGuard() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+        ~DeviceGuard() { if (dev >= 0) (void)hipSetDevice(dev); }
+    } device_guard;
+    // REHEARSAL (experiments build only, BBB_MULTI_REHEARSAL=1): handles may share a device and the all-reduce is replaced by
+    // a host-side sum -- what a one-GPU box can exercise of this function: ndev host threads inside ber_run at once (plan
+    // caches, per-device statics, the per-thread error text), the sharding, the bookkeeping around the collective
+    const bool rehearsal = env_knob("BBB_MULTI_REHEARSAL", 0) != 0;
     std::vector<int> devs((size_t)ndev);
     for (int r = 0; r < ndev; r++) {
         if (!handles[r]) return fail(BBB_EINVAL, "null handle");
         if (handles[r]->device < 0) return fail(BBB_ENODEV, "host-only handle (device -1) cannot run trials");
         devs[(size_t)r] = handles[r]->device;
-        for (int q = 0; q < r; q++)
-            if (devs[(size_t)q] == devs[(size_t)r]) return fail(BBB_EINVAL, "every handle must live on its own device");
+        for (int q = 0; q < r; q++) {
+            if (handles[q] == handles[r]) return fail(BBB_EINVAL, "the same handle twice");
+            if (devs[(size_t)q] == devs[(size_t)r] && !rehearsal) return fail(BBB_EINVAL, "every handle must live on its own device");
+        }
     }
     {   // argument errors are found before any device is touched (and before a rank could miss the collective)
         std::vector<bbb_trial_cfg> probe((size_t)ncfg);
@@ -1513,9 +1525,8 @@ int bbb_ber_sweep_multi(bbb_lutopt *const *handles, int ndev, const bbb_trial_cf
         if (e) return e;
     }
     std::vector<ncclComm_t> comms;
-    int rc = get_comms(devs, &comms);
+    int rc = rehearsal ? BBB_OK : get_comms(devs, &comms);
     if (rc) return rc;
-    const Rccl &nccl = rccl();
     const size_t nwords = 2 * (size_t)ncfg;
     std::vector<int> rcs((size_t)ndev, BBB_OK);
     std::vector<std::string> errs((size_t)ndev);
@@ -1552,13 +1563,16 @@ int bbb_ber_sweep_multi(bbb_lutopt *const *handles, int ndev, const bbb_trial_cf
     // The ONE collective of the path: all-reduce (sum) of the uint64 {bits, errors} counters over xGMI, queued on
     // each device's stream behind its trials.  Every rank must enter it, so it is issued only after all shares
     // were launched without error; one group call from this thread (the single-process multi-device form).
-    ncclResult_t e = nccl.GroupStart();
-    for (int r = 0; r < ndev && e == ncclSuccess; r++)
-        e = nccl.AllReduce(handles[r]->d_counters, handles[r]->d_counters, nwords, ncclUint64, ncclSum, comms[(size_t)r],
-                           handles[r]->stream);
-    const ncclResult_t e2 = nccl.GroupEnd();
-    if (e == ncclSuccess) e = e2;
-    if (e != ncclSuccess) return fail(BBB_EHIP, std::string("ncclAllReduce: ") + nccl.GetErrorString(e));
+    if (!rehearsal) {
+        const Rccl &nccl = rccl();
+        ncclResult_t e = nccl.GroupStart();
+        for (int r = 0; r < ndev && e == ncclSuccess; r++)
+            e = nccl.AllReduce(handles[r]->d_counters, handles[r]->d_counters, nwords, ncclUint64, ncclSum, comms[(size_t)r],
+                               handles[r]->stream);
+        const ncclResult_t e2 = nccl.GroupEnd();
+        if (e == ncclSuccess) e = e2;
+        if (e != ncclSuccess) return fail(BBB_EHIP, std::string("ncclAllReduce: ") + nccl.GetErrorString(e));
+    }
     for (int r = 0; r < ndev; r++) {
         BBB_HIP(hipSetDevice(handles[r]->device));
         BBB_HIP(hipMemcpyAsync(host[(size_t)r].data(), handles[r]->d_counters, nwords * sizeof(unsigned long long),
@@ -1568,8 +1582,13 @@ int bbb_ber_sweep_multi(bbb_lutopt *const *handles, int ndev, const bbb_trial_cf
         BBB_HIP(hipSetDevice(handles[r]->device));
         BBB_HIP(hipStreamSynchronize(handles[r]->stream));
     }
-    for (int r = 1; r < ndev; r++)
-        if (host[(size_t)r] != host[0]) return fail(BBB_EHIP, "ranks disagree after the all-reduce");
+    if (rehearsal) {                  // the sum the collective would have left on every device
+        for (int r = 1; r < ndev; r++)
+            for (size_t i = 0; i < nwords; i++) host[0][i] += host[(size_t)r][i];
+    } else {
+        for (int r = 1; r < ndev; r++)
+            if (host[(size_t)r] != host[0]) return fail(BBB_EHIP, "ranks disagree after the all-reduce");
+    }
     for (int i = 0; i < ncfg; i++) {
         out[i].bits = host[0][2 * (size_t)i];
         out[i].errors = host[0][2 * (size_t)i + 1];

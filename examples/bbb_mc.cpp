@@ -4,9 +4,14 @@
 //
 //   bbb_mc [--matrix FILE] [--init HEX] [--gpus N] [--json 1]
 //          BER sweep:   [--prbs 31] [--bits 1e9] [--nv 8] [--ebn0 A:B:STEP] [--seeds N] [--shard bits|seeds|trials]
-//          AWGN fill:   --nsamples 1e9 [--steps 5] [--staged 0|1|m]   (bbb_lutopt_set_staged: 1 = the two-kernel form, the
-//                       default; m = 2..8 = one sample kernel per m consecutive steps)
+//          AWGN fill:   --nsamples 1e9 [--steps 5] [--staged 0|1|m]   the sample stream drained through bbb_awgn_stream_next;
+//                       --staged picks the level of bbb_lutopt_set_staged for it (default: the stream's own choice, two reads
+//                       per sample kernel; 0 = plain bbb_awgn_fill_i8 calls in the one-kernel form)
 //          loopback:    --loopback BITS
+//          search:      --search K [--seed S] [--count N] --out FILE    the reference's rnghunt (software/rnghunt/src/bin/
+//                       rnghunt.rs:13-66) on the GPU: candidates of `seed` are examined in windows of N (default 65536)
+//                       until one has period 2^K - 1; it is written to FILE in the reference's `out` format (K lines of K
+//                       characters 0/1), read back and re-checked (bbb_lutopt_is_full_period)
 //
 // --matrix   the reference's 0/1 text format (software/rnghunt/matrices/256); default: the shipped n256 matrix
 //            (gateware/bbb/rng_recurrences.py:172-259, used by tx.py:70).
@@ -15,11 +20,13 @@
 // --gpus N   BER sweep: bbb_ber_sweep_multi over devices 0..N-1 -- one host thread per device and ONE RCCL
 //            all-reduce of the uint64 counters.  --shard bits (default): every device runs every point over its
 //            slice of the bit range, the counters equal the 1-GPU counters exactly; seeds: device d runs every
-//            point on reset state init+d, counters summed (points x seeds, BASELINE configs[4]); trials: point i
-//            on device i % N.  AWGN fill: device d generates stream positions [16 + (s N + d) n, +n) of step s,
-//            no collective (independent shards of one sequential stream).
+//            point on its own seed (below), counters summed (points x seeds, BASELINE configs[4]); trials: point i
+//            on device i % N.  AWGN fill: device d reads stream positions [16 + 2^48 d + s n, +n) in step s -- its own
+//            contiguous stretch of the one sequential stream, no collective.
 // --multi 1  take the bbb_ber_sweep_multi route (RCCL) even with --gpus 1.
-// --seeds N  (1 GPU) repeat the sweep with reset states init, init+1, ... and sum the counters.
+// --seeds N  (1 GPU) repeat the sweep on N seeds and sum the counters.  Seed d = the reset state `init` advanced 2^48 d
+//            clocks (GF(2) jump-ahead, bbb_lutopt_state_at): disjoint stretches of the generator's one cycle.  (Reset
+//            states that differ by small integers are XOR-dependent streams, and nothing would keep them from overlapping.)
 // --json 1   one JSON object per line (points, then a summary with rates and the roofline fraction) instead of
 //            the table.
 #include "../include/bbb.h"
@@ -80,7 +87,7 @@ struct Matrix {
 };
 
 // AWGN fill on one device: `steps` consecutive fills of n samples; device d reads its own stretch of the stream, 2^48 d steps in
-struct FillResult { int rc = 0; std::string err; double kernel_ms = 0, seed_ms = 0, wall_s = 0; std::vector<int8_t> head; };
+struct FillResult { int rc = 0; std::string err; double kernel_ms = 0, seed_ms = 0, wall_s = 0; uint64_t launches = 0; std::vector<int8_t> head; };
 static void fill_worker(const Matrix &m, unsigned long long init0, int dev, int ndev, uint64_t n, int steps, int staged, FillResult *res) {
     auto body = [&]() -> int {
         if (hipSetDevice(dev) != hipSuccess) { res->err = "hipSetDevice failed"; return 1; }
@@ -88,27 +95,39 @@ static void fill_worker(const Matrix &m, unsigned long long init0, int dev, int 
         bbb_lutopt *h = nullptr;
         int rc = bbb_lutopt_create(&h, m.n, m.taps.data(), m.off.data(), init, dev);
         if (rc) { res->err = bbb_last_error_detail(); return rc; }
-        (void)bbb_lutopt_set_staged(h, staged);               // two-kernel form: the piece mover of step s beside step s+1
         int8_t *buf = nullptr;
         if (hipMalloc((void **)&buf, (n + 15) / 16 * 16) != hipSuccess) { res->err = "hipMalloc failed"; return 1; }
         (void)ndev;
-        auto first = [&](int s) { return (uint64_t)16 + ((uint64_t)dev << 48) + (uint64_t)s * n; };
-        if ((rc = bbb_awgn_fill_i8(h, buf, n, first(0)))) { res->err = bbb_last_error_detail(); return rc; }   // builds the jump plan
+        const uint64_t first0 = (uint64_t)16 + ((uint64_t)dev << 48);
+        auto first = [&](int s) { return first0 + (uint64_t)s * n; };
+        // the sample stream as an object: the library owns staging, the two-kernel form and the announcement of every next read
+        bbb_awgn_stream *st = nullptr;
+        if (staged > 0) (void)bbb_lutopt_set_staged(h, staged);             // an explicit level; otherwise the stream picks its own
+        if (staged != 0) {
+            if ((rc = bbb_awgn_stream_open(h, n, first0, 1, &st))) { res->err = bbb_last_error_detail(); return rc; }
+            if ((rc = bbb_awgn_stream_next(st, buf))) { res->err = bbb_last_error_detail(); return rc; }       // builds the jump plan
+        } else if ((rc = bbb_awgn_fill_i8(h, buf, n, first(0)))) { res->err = bbb_last_error_detail(); return rc; }
         res->head.resize(n < 64 ? n : 64);
         (void)hipMemcpy(res->head.data(), buf, res->head.size(), hipMemcpyDeviceToHost);
-        (void)bbb_lutopt_set_staged(h, staged);               // (drops a look-ahead half: the timed steps start on a launch)
+        if (st) (void)bbb_awgn_stream_seek(st, first(1));      // (drops what a sample kernel produced ahead: the timed steps start on a launch)
         (void)bbb_lutopt_profile(h, 1);
         (void)hipDeviceSynchronize();
         const double t0 = now_s();
         for (int s = 1; s <= steps; s++) {
-            if ((rc = bbb_awgn_fill_i8(h, buf, n, first(s)))) { res->err = bbb_last_error_detail(); return rc; }
-            (void)bbb_awgn_prefetch(h, n, first(s + 1));       // the next step's seeding runs beside this step's kernel
+            if (st) rc = bbb_awgn_stream_next(st, buf);
+            else {
+                rc = bbb_awgn_fill_i8(h, buf, n, first(s));
+                if (!rc) (void)bbb_awgn_prefetch(h, n, first(s + 1));       // the next step's seeding runs beside this step's kernel
+            }
+            if (rc) { res->err = bbb_last_error_detail(); return rc; }
         }
         (void)hipDeviceSynchronize();
         res->wall_s = now_s() - t0;
         uint64_t calls = 0;
         (void)bbb_lutopt_profile_read(h, &res->seed_ms, &res->kernel_ms, &calls, 1);
         if (calls) { res->kernel_ms /= (double)calls; res->seed_ms /= (double)calls; }
+        res->launches = calls;
+        if (st) (void)bbb_awgn_stream_close(st);
         (void)hipFree(buf);
         (void)bbb_lutopt_destroy(h);
         return 0;
@@ -118,7 +137,9 @@ static void fill_worker(const Matrix &m, unsigned long long init0, int dev, int 
 
 int main(int argc, char **argv) {
     std::string matrix, shard = "bits";
-    int k = 31, nv = 8, seeds = 1, gpus = 1, json = 0, steps = 5, multi = 0, staged = 1;
+    int k = 31, nv = 8, seeds = 1, gpus = 1, json = 0, steps = 5, multi = 0, staged = -1, search_k = 0;
+    unsigned long long search_seed = 1, search_count = 65536;
+    std::string outfile;
     unsigned long long init0 = 1;
     double bits = 1e9, from = 0, to = 10, step = 1, loopback = 0, nsamples = 0;
     for (int i = 1; i + 1 < argc; i += 2) {
@@ -144,6 +165,10 @@ int main(int argc, char **argv) {
         else if (a == "--json") json = std::atoi(v);
         else if (a == "--multi") multi = std::atoi(v);
         else if (a == "--staged") staged = std::atoi(v);
+        else if (a == "--search") search_k = std::atoi(v);
+        else if (a == "--seed") search_seed = std::strtoull(v, nullptr, 0);
+        else if (a == "--count") search_count = std::strtoull(v, nullptr, 0);
+        else if (a == "--out") outfile = v;
         else if (a == "--gen") { if (std::string(v) != "lutopt") { std::fprintf(stderr, "--gen lutopt is the only generator the reference has\n"); return 2; } }
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
@@ -157,6 +182,36 @@ int main(int argc, char **argv) {
     int ndev_seen = 0;
     CHECK(bbb_device_count(&ndev_seen));
     if (gpus > ndev_seen) { std::fprintf(stderr, "--gpus %d but %d device(s) visible\n", gpus, ndev_seen); return 1; }
+
+    // ---- matrix search (software/rnghunt/src/bin/rnghunt.rs:13-66) -------------------------------------------------------
+    if (search_k > 0) {
+        if (outfile.empty()) { std::fprintf(stderr, "--search K needs --out FILE\n"); return 2; }
+        std::vector<uint16_t> taps((size_t)search_k * 4);
+        std::vector<uint32_t> off((size_t)search_k + 1);
+        uint64_t found = ~0ull, first = 0, tested = 0, full = 0;
+        double kernel_ms = 0;
+        const double t0 = now_s();
+        while (found == ~0ull) {                       // the reference's workers loop until one reports a hit (rnghunt.rs:23-57)
+            bbb_search_stats st{};
+            CHECK(bbb_lutopt_search(search_k, search_seed, first, search_count, &found, taps.data(), off.data(), &st, 0, nullptr));
+            tested += st.tested; full += st.full_degree; kernel_ms += (double)st.kernel_ns * 1e-6;
+            first += search_count;
+            if (first > (1ull << 40)) { std::fprintf(stderr, "no matrix among 2^40 candidates\n"); return 1; }
+        }
+        CHECK(bbb_lutopt_save_matrix_file(outfile.c_str(), search_k, taps.data(), off.data()));      // rnghunt.rs:51-53
+        int k2 = 0, ok = 0;
+        uint16_t *t2 = nullptr;
+        uint32_t *o2 = nullptr;
+        CHECK(bbb_lutopt_load_matrix_file(outfile.c_str(), &k2, &t2, &o2));                              // what --matrix reads
+        CHECK(bbb_lutopt_is_full_period(k2, t2, o2, &ok));
+        bbb_free(t2);
+        bbb_free(o2);
+        std::printf("{\"mode\": \"search\", \"k\": %d, \"seed\": %llu, \"candidate\": %llu, \"tested\": %llu, \"full_degree\": %llu, "
+                    "\"kernel_ms\": %.3f, \"seconds\": %.3f, \"out\": \"%s\", \"reloaded_k\": %d, \"full_period\": %s}\n",
+                    search_k, search_seed, (unsigned long long)found, (unsigned long long)tested, (unsigned long long)full, kernel_ms, now_s() - t0,
+                    outfile.c_str(), k2, ok ? "true" : "false");
+        return ok && k2 == search_k ? 0 : 1;
+    }
 
     Matrix m;
     if (matrix.empty()) {
@@ -172,6 +227,19 @@ int main(int argc, char **argv) {
         bbb_free(t);
         bbb_free(o);
     }
+
+    // seed d of the run = the reset state advanced 2^48 d clocks (host-side GF(2) jump-ahead on a device -1 handle)
+    auto seed_words = [&](int d, uint64_t (&w)[8]) -> int {
+        const uint64_t base[8] = {init0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 8; i++) w[i] = base[i];
+        if (d == 0) return BBB_OK;
+        bbb_lutopt *hh = nullptr;
+        int rc = bbb_lutopt_create(&hh, m.n, m.taps.data(), m.off.data(), base, -1);
+        if (rc) return rc;
+        rc = bbb_lutopt_state_at(hh, (uint64_t)d << 48, w);
+        (void)bbb_lutopt_destroy(hh);
+        return rc;
+    };
 
     // ---- AWGN fill mode (BASELINE configs[1]) -----------------------------------------------------------------------
     if (nsamples > 0) {
@@ -190,7 +258,7 @@ int main(int argc, char **argv) {
         const double gs = (double)gpus * steps * (double)n / wall / 1e9;
         // what one launch of the sample kernel produces (bbb.h, bbb_lutopt_set_staged: look-ahead applies to fills of at
         // least 2^24 samples, a multiple of 16)
-        const uint64_t per_launch = (staged >= 2 && n >= (1ull << 24) && n % 16 == 0) ? (uint64_t)staged * n : n;
+        const uint64_t per_launch = res[0].launches ? (uint64_t)steps * n / res[0].launches : n;
         const double kernel_gbs = kms > 0 ? (double)per_launch / (kms * 1e-3) / 1e9 : 0;        // 1 B per sample
         if (json) {
             std::printf("{\"mode\": \"awgn_fill\", \"n_gpus\": %d, \"samples_per_step_per_gpu\": %llu, \"steps\": %d, \"gsample_s\": %.3f, "
@@ -227,10 +295,11 @@ int main(int argc, char **argv) {
     double ms = 0;
     const char *reduce = "single device";
     if (gpus > 1 || multi) {
-        // one handle per device; seeds mode gives device d the reset state init + d
+        // one handle per device; seeds mode gives device d seed d
         std::vector<bbb_lutopt *> hs((size_t)gpus, nullptr);
         for (int d = 0; d < gpus; d++) {
-            const uint64_t init[8] = {init0 + (mode == BBB_SHARD_SEEDS ? (uint64_t)d : 0), 0, 0, 0, 0, 0, 0, 0};
+            uint64_t init[8];
+            CHECK(seed_words(mode == BBB_SHARD_SEEDS ? d : 0, init));
             CHECK(bbb_lutopt_create(&hs[(size_t)d], m.n, m.taps.data(), m.off.data(), init, d));
         }
         CHECK(bbb_ber_sweep_multi(hs.data(), gpus, cfg.data(), (int)cfg.size(), mode, out.data()));   // plans + communicators
@@ -244,7 +313,8 @@ int main(int argc, char **argv) {
     } else {
         bbb_lutopt *h = nullptr;
         for (int sd = 0; sd < seeds; sd++) {
-            const uint64_t init[8] = {init0 + (uint64_t)sd, 0, 0, 0, 0, 0, 0, 0};     // reset value (gateware/bbb/rng.py:21)
+            uint64_t init[8];                                                      // reset value (gateware/bbb/rng.py:21), jumped
+            CHECK(seed_words(sd, init));
             if (h) CHECK(bbb_lutopt_destroy(h));
             CHECK(bbb_lutopt_create(&h, m.n, m.taps.data(), m.off.data(), init, 0));
             CHECK(bbb_ber_trials(h, cfg.data(), (int)cfg.size(), part.data()));  // first call builds the jump plans

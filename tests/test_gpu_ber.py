@@ -160,7 +160,9 @@ def test_cpp_caller_of_the_c_abi(gpu, oracle):
     assert r.returncode == 0, r.stderr
     row = [l.split() for l in r.stdout.splitlines() if l and not l.startswith("#")][0]
     amp = int(row[1])
-    e = [m.ber_trial(s, 15, 1, amp, 7, 16, 0, 100_000) for s in (0xa5, 0xa6)]
+    # seed d = the reset state advanced 2^48 d clocks (disjoint stretches of the one cycle), not init + d
+    seed1 = gpu.LUTOPT.shipped(256, init=0xa5).state_at(1 << 48)
+    e = [m.ber_trial(s, 15, 1, amp, 7, 16, 0, 100_000) for s in (0xa5, seed1)]
     assert (int(row[2]), int(row[3])) == (e[0][0] + e[1][0], e[0][1] + e[1][1])
 
 
@@ -234,13 +236,59 @@ def test_cli_json_multi_and_awgn_modes(gpu, oracle):
     a = json.loads(r.stdout.strip().splitlines()[-1])
     assert a["mode"] == "awgn_fill" and a["gsample_s"] > 0 and 0 < a["hbm_roofline_frac"] < 1
     assert a["head"] == m.awgn(1, 16, 64, fast=True).tolist() and a["samples_per_launch"] == 3_000_000
-    # a size at which the staged form (the default) and its look-ahead (--staged 2) apply; 0 = the one-kernel form
+    # a size at which the two-kernel form applies: the stream's own level (two reads per sample kernel), explicit levels, and
+    # 0 = plain bbb_awgn_fill_i8 calls in the one-kernel form
     nbig = (1 << 24) + 16
-    for staged, per in ((2, 2 * nbig), (1, nbig), (0, nbig)):
-        r = subprocess.run([str(exe), "--nsamples", str(nbig), "--steps", "4", "--staged", str(staged), "--json", "1"], cwd=str(ROOT),
+    for staged, per in ((None, 2 * nbig), (2, 2 * nbig), (1, nbig), (0, nbig)):
+        r = subprocess.run([str(exe), "--nsamples", str(nbig), "--steps", "4", "--json", "1"] + ([] if staged is None else ["--staged", str(staged)]), cwd=str(ROOT),
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr
         a = json.loads(r.stdout.strip().splitlines()[-1])
         assert a["samples_per_launch"] == per and a["gsample_s"] > 0 and a["head"] == m.awgn(1, 16, 64, fast=True).tolist()
     r = subprocess.run([str(exe), "--gpus", "64"], cwd=str(ROOT), capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "visible" in r.stderr
+
+
+def test_thread_per_device_body_rehearsed_on_one_gpu():
+    """bbb_ber_sweep_multi runs one host thread per device; a one-GPU box has never run more than `work(0)` on the calling
+    thread.  The experiments build (libbbb_hip_exp.so) with BBB_MULTI_REHEARSAL=1 accepts handles that share a device and
+    replaces the RCCL all-reduce by a host-side sum: 2 and 8 host threads inside ber_run at once (plan caches, per-device
+    statics, per-thread error text), in all three sharding modes -- the totals must equal the same trials run undivided.
+    A child process: the product build refuses (and must keep refusing) two handles on one device."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = (
+        "import json, torch, basebandboard_amd as g\n"
+        "g._lib.select_build('experiments')\n"
+        "from basebandboard_amd.channel import sweep_multi\n"
+        "from basebandboard_amd import _lib\n"
+        "base = g.LUTOPT.shipped(256)\n"
+        "ts = [g.Trial(nbits=2_000_003, amp=g.channel.amp_for_ebn0(db, 8), noise_var=8) for db in (0, 2, 4, 6, 8)] + [g.Trial(nbits=77_777, amp=40, noise_var=5, prbs_k=9, first_bit=123)]\n"
+        "want = g.run_trials(base, ts)\n"
+        "res = {'want': want}\n"
+        "for nd in (2, 8):\n"
+        "    same = [g.LUTOPT.shipped(256) for _ in range(nd)]\n"
+        "    res[f'bits{nd}'] = sweep_multi(same, ts, _lib.SHARD_BITS)\n"
+        "    res[f'trials{nd}'] = sweep_multi(same, ts, _lib.SHARD_TRIALS)\n"
+        "    seeds = [g.LUTOPT.shipped(256, init=base.state_at(d << 48)) for d in range(nd)]\n"
+        "    got = sweep_multi(seeds, ts, _lib.SHARD_SEEDS)\n"
+        "    tot = [[0, 0] for _ in ts]\n"
+        "    for u in seeds:\n"
+        "        for i, (b, e) in enumerate(g.run_trials(u, ts)):\n"
+        "            tot[i][0] += b; tot[i][1] += e\n"
+        "    res[f'seeds{nd}'] = [got, tot]\n"
+        "    res[f'device{nd}'] = torch.cuda.current_device()\n"
+        "print(json.dumps(res))\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=str(ROOT), env={**os.environ, "BBB_MULTI_REHEARSAL": "1"}, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    for nd in (2, 8):
+        assert res[f"bits{nd}"] == res["want"], nd
+        assert res[f"trials{nd}"] == res["want"], nd
+        got, tot = res[f"seeds{nd}"]
+        assert got == tot and got != res["want"]
+        assert res[f"device{nd}"] == 0

@@ -131,3 +131,33 @@ def test_found_k256_matrix_runs_ber_trials_and_tx(gpu, oracle, tmp_path):
     got = bbb.run_trials(u, t)
     assert got == [m.ber_trial(0xABCDEF, x.prbs_k, 1, x.amp, x.noise_var, 16, 0, x.nbits) for x in t]
     assert np.array_equal(bbb.CLTGRNG(u).generate(100_000, first_step=16).cpu().numpy(), m.awgn(0xABCDEF, 16, 100_000))
+
+
+def test_cli_search_writes_the_reference_format_and_the_file_loads(gpu, oracle, tmp_path):
+    """examples/bbb_mc --search K --seed S --out FILE: the reference's rnghunt loop (software/rnghunt/src/bin/rnghunt.rs:13-66)
+    around bbb_lutopt_search -- windows of candidates until one is accepted, the matrix written in the `out` format
+    (rnghunt.rs:51-53), read back and re-checked; the file then drives --matrix, and its first samples equal the oracle's on
+    that matrix."""
+    import json
+    import subprocess
+    from conftest import ROOT
+    exe = ROOT / "examples" / "bbb_mc"
+    subprocess.check_call(["make", "-C", str(ROOT / "examples")], stdout=subprocess.DEVNULL)
+    out = tmp_path / "out"
+    r = subprocess.run([str(exe), "--search", "32", "--seed", "5", "--count", "4096", "--out", str(out)], cwd=str(ROOT),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec["mode"] == "search" and rec["k"] == 32 and rec["full_period"] is True and rec["reloaded_k"] == 32 and rec["tested"] > 0
+    rows = out.read_text().split()
+    assert len(rows) == 32 and all(len(x) == 32 and set(x) <= {"0", "1"} and 3 <= x.count("1") <= 4 for x in rows)
+    # the same candidate through the library call, and the file as a generator
+    idx, packed, _ = gpu.gf2.search(32, seed=5, first=0, count=rec["candidate"] + 1)
+    assert idx == rec["candidate"]
+    assert [[c for c, ch in enumerate(x) if ch == "1"] for x in rows] == [sorted(p) for p in packed]
+    r = subprocess.run([str(exe), "--matrix", str(out), "--nsamples", "100000", "--steps", "1", "--json", "1"], cwd=str(ROOT),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    a = json.loads(r.stdout.strip().splitlines()[-1])
+    m = oracle.Lutopt(path=str(out))
+    assert a["head"] == m.awgn(1, 16, 64).tolist()
