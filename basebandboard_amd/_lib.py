@@ -17,7 +17,7 @@ SYMBOLS = [
     "bbb_abi_version", "bbb_strerror", "bbb_last_error_detail", "bbb_device_count", "bbb_free",
     "bbb_lutopt_load_matrix_file", "bbb_lutopt_create", "bbb_lutopt_destroy", "bbb_lutopt_set_stream",
     "bbb_lutopt_is_specialised", "bbb_lutopt_set_staged", "bbb_lutopt_set_custom_fill", "bbb_lutopt_set_custom_ber", "bbb_lutopt_attach_custom_library", "bbb_lutopt_profile", "bbb_lutopt_profile_read", "bbb_lutopt_profile_read_mover", "bbb_lutopt_state_at", "bbb_lutopt_fill_words", "bbb_awgn_fill_i8", "bbb_awgn_fill_i16", "bbb_awgn_prefetch", "bbb_awgn_stream_open", "bbb_awgn_stream_next", "bbb_awgn_stream_read", "bbb_awgn_stream_seek", "bbb_awgn_stream_tell", "bbb_awgn_stream_close",
-    "bbb_clt_tree_i16", "bbb_prbs_fill", "bbb_prbs_check", "bbb_prbs_check_dev", "bbb_prbs_state_at",
+    "bbb_clt_tree_i16", "bbb_prbs_fill", "bbb_prbs_fill_hint", "bbb_prbs_check", "bbb_prbs_check_dev", "bbb_prbs_state_at",
     "bbb_prbs_detector_run", "bbb_prbs_detector_stream", "bbb_ber_trials", "bbb_ber_trials_dev", "bbb_ber_sweep_multi", "bbb_sweep_shard", "bbb_multi_release", "bbb_shaper_fill_i16", "bbb_tx_fill_i16", "bbb_rx_slice", "bbb_rx_phase_search", "bbb_gf2_berlekamp_massey", "bbb_gf2_recur",
     "bbb_gf2_dot", "bbb_gf2_poly_is_primitive", "bbb_gf2_poly_modexp", "bbb_lutopt_charpoly", "bbb_lutopt_is_full_period",
     "bbb_lutopt_save_matrix_file", "bbb_lutopt_search_candidate", "bbb_lutopt_search",
@@ -116,6 +116,7 @@ def lib():
     l.bbb_awgn_stream_close.argtypes = [vp]
     l.bbb_clt_tree_i16.argtypes = [i32, vp, u64, vp, i32, vp]
     l.bbb_prbs_fill.argtypes = [i32, u64, u64, u64, vp, i32, vp]
+    l.bbb_prbs_fill_hint.argtypes = [i32, u64, u64, u64, vp, C.c_uint, i32, vp]
     l.bbb_prbs_check.argtypes = [i32, u64, u64, u64, vp, u64p, i32, vp]
     l.bbb_prbs_check_dev.argtypes = [i32, u64, u64, u64, vp, vp, i32, vp]
     l.bbb_prbs_state_at.argtypes = [i32, u64, u64, u64p]

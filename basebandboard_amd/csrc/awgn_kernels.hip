@@ -716,11 +716,10 @@ unplane_kernel(const u32x4 *__restrict stage, char *__restrict dst, unsigned lon
             // positions are relative to the window: sample p of this call = stream offset win_lo + p; dst holds int16
             int16_t *const dst16 = reinterpret_cast<int16_t *>(dst);
             const u16x2 nv16 = {(uint16_t)(tx.noise_var * 16), (uint16_t)(tx.noise_var * 16)};
-#pragma unroll
-            for (unsigned k = 0; k < 8; k++) {
-                const unsigned long long o = off + k * goff;
-                if (g0 + 256ull * k >= G || o >= nbytes) break;
-                if (o < win_lo) continue;
+            const uint32_t use_mask = tx.use_bits ? 0x3ffu : 0u;
+            // one 16-byte piece of noise -> 16 int16 samples; FULL: the piece lies wholly inside the window (no tail)
+            auto piece = [&](auto full_c, unsigned k, unsigned long long o) {
+                constexpr bool FULL = decltype(full_c)::value;
                 const unsigned long long p0 = o - win_lo;                                        // first sample of the piece, in this call
                 const uint32_t rel = ((uint32_t)p0 >> 3) + tx.rel_base;
                 // the generator's two window words (dma_unit), and where the unit's first sample sits in them
@@ -729,10 +728,10 @@ unplane_kernel(const u32x4 *__restrict stage, char *__restrict dst, unsigned lon
                 const u32x2 ww = *reinterpret_cast<const u32x2 *>(&winb[buf * 512 + row * 2]);
                 const uint32_t rel_u = rel - 2u * c2;                                            // window position of the unit's first sample
                 const unsigned long long w64 = ((unsigned long long)ww[1] << 32) | ww[0];
-                const uint32_t wk = tx.use_bits ? (uint32_t)(w64 >> ((rel_u & 31u) + 2u * c2)) : 0u;
+                const uint32_t wk = (uint32_t)(w64 >> ((rel_u & 31u) + 2u * c2));
                 const u32x4 v = *reinterpret_cast<const u32x4 *>(&tile[rd0 + k * 1024]);
-                // the piece's 10-bit data window (bit j = data bit M0 - 7 + j), as in the fused kernel
-                const uint32_t Q4 = (wk & 0x3ffu) << 4;
+                // the piece's 10-bit data window (bit j = data bit M0 - 7 + j), as in the fused kernel (use_mask: no data bits = all 0)
+                const uint32_t Q4 = (wk & use_mask) << 4;
                 const char *tt = reinterpret_cast<const char *>(TT);
                 const u32x4 A = *reinterpret_cast<const u32x4 *>(tt + (Q4 & 0xff0u));
                 const u32x4 B = *reinterpret_cast<const u32x4 *>(tt + ((Q4 >> 1) & 0xff0u));
@@ -752,13 +751,26 @@ unplane_kernel(const u32x4 *__restrict stage, char *__restrict dst, unsigned lon
                     x[2 * w4 + 1] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(i16x2, m23) >> 4);
                 }
                 int16_t *out = dst16 + p0;
-                if (o + 16 <= nbytes) {
+                if (FULL || o + 16 <= nbytes) {
                     const u32x4 lo = {x[0], x[1], x[2], x[3]}, hi = {x[4], x[5], x[6], x[7]};
                     reinterpret_cast<u32x4 *>(out)[0] = lo;
                     reinterpret_cast<u32x4 *>(out)[1] = hi;
                 } else {
                     const unsigned n = (unsigned)(nbytes - o);
                     for (unsigned e = 0; e < n; e++) out[e] = (int16_t)((x[e >> 1] >> (16 * (e & 1))) & 0xffff);
+                }
+            };
+            if (g0 + 7 * 256 < G && off >= win_lo && off + 7 * goff + 16 <= nbytes) {
+                // every piece of this thread exists and lies inside the window: straight-line code, so that the LDS reads of
+                // one piece are in flight while the previous one is shaped (a guest wave waits ~100 cycles per dependent read)
+#pragma unroll
+                for (unsigned k = 0; k < 8; k++) piece(std::true_type{}, k, off + k * goff);
+            } else {
+                for (unsigned k = 0; k < 8; k++) {
+                    const unsigned long long o = off + k * goff;
+                    if (g0 + 256ull * k >= G || o >= nbytes) break;
+                    if (o < win_lo) continue;
+                    piece(std::false_type{}, k, o);
                 }
             }
         }

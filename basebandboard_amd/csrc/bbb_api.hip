@@ -850,15 +850,21 @@ int bbb_lutopt_attach_custom_library(bbb_lutopt *h, const char *path) {
     if (!h || !path) return fail(BBB_EINVAL, "null argument");
     void *lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
     if (!lib) return fail(BBB_EIO, std::string("cannot load ") + path + ": " + dlerror());
+    auto bail = [&](int code, const std::string &what) { dlclose(lib); return fail(code, what); };
     auto order = reinterpret_cast<int (*)(void)>(dlsym(lib, "bbb_custom_order"));
+    auto abi = reinterpret_cast<int (*)(void)>(dlsym(lib, "bbb_custom_abi"));
     auto fill = reinterpret_cast<bbb_custom_fill_fn>(dlsym(lib, "bbb_custom_fill"));
-    if (!order || !fill) return fail(BBB_EIO, std::string(path) + " does not export bbb_custom_order / bbb_custom_fill");
-    if (order() != h->k) return fail(BBB_EINVAL, std::string(path) + " was built for another order");
+    if (!order || !fill) return bail(BBB_EIO, std::string(path) + " does not export bbb_custom_order / bbb_custom_fill");
+    // a library built by another checkout shares plane layout and trial records with THAT library, not with this one
+    if (!abi || abi() != BBB_CUSTOM_ABI)
+        return bail(BBB_EINVAL, std::string(path) + " was built for another version of this library (custom ABI " +
+                                    (abi ? std::to_string(abi()) : std::string("none")) + ", expected " + std::to_string(BBB_CUSTOM_ABI) + "): rebuild it");
+    if (order() != h->k) return bail(BBB_EINVAL, std::string(path) + " was built for another order");
     int rc = bbb_lutopt_set_custom_fill(h, fill);
-    if (rc) return rc;
+    if (rc) { dlclose(lib); return rc; }
     auto ber = reinterpret_cast<bbb_custom_ber_fn>(dlsym(lib, "bbb_custom_ber"));
     if (ber && h->k == 256) rc = bbb_lutopt_set_custom_ber(h, ber);
-    return rc;
+    return rc;            // (on success the library stays loaded for the life of the process: the handle calls into it)
 }
 
 int bbb_lutopt_set_staged(bbb_lutopt *h, int enable) {
@@ -972,7 +978,11 @@ int bbb_awgn_prefetch(bbb_lutopt *h, uint64_t nsamples, uint64_t first_step) {
         h->pf_waited_slot = h->stage_slot ^ 1;
         h->pf_waited_gen = h->stage_gen[h->stage_slot ^ 1];
     }
-    if (!pf.seeded) BBB_HIP(hipEventCreateWithFlags(&pf.seeded, hipEventDisableTiming));
+    // An announcement that was never taken leaves its seeding behind -- queued on the arithmetic stream of the fill it expected,
+    // which need not be the one this seeding goes to: without this wait the two would write the same buffers side by side
+    // (the soak test's case: a hint whose fill came with another partition, then the next hint).
+    if (pf.seeded) BBB_HIP(hipStreamWaitEvent(side, pf.seeded, 0));
+    else BBB_HIP(hipEventCreateWithFlags(&pf.seeded, hipEventDisableTiming));
     // the buffers may still be read by the sample kernel that used them last (main stream)
     if (pf.read_pending) BBB_HIP(hipStreamWaitEvent(side, pf.last_read, 0));
     if (pf.states_cap < (size_t)G * h->W32 || pf.planes_cap < (size_t)2 * h->k * nlanes) {
@@ -1130,6 +1140,16 @@ int bbb_prbs_fill(int k, uint64_t init_state, uint64_t first_bit, uint64_t nbits
     int rc = use_device(device);
     if (rc) return rc;
     return prbs_fill_launch(k, init_state, first_bit, nbits, dst_packed_dev, (hipStream_t)hip_stream);
+}
+
+int bbb_prbs_fill_hint(int k, uint64_t init_state, uint64_t first_bit, uint64_t nbits, uint64_t *dst_packed_dev,
+                       unsigned flags, int device, void *hip_stream) {
+    if (flags & ~(unsigned)BBB_PRBS_WILL_READ_BACK) return fail(BBB_EINVAL, "unknown flag");
+    if (nbits && !dst_packed_dev) return fail(BBB_EINVAL, "null device pointer");
+    if (!prbs_tap(k)) return fail(BBB_EINVAL, "k=" + std::to_string(k) + " invalid for PRBS");
+    int rc = use_device(device);
+    if (rc) return rc;
+    return prbs_fill_launch(k, init_state, first_bit, nbits, dst_packed_dev, (hipStream_t)hip_stream, (flags & BBB_PRBS_WILL_READ_BACK) ? 1 : 0);
 }
 
 int bbb_prbs_check_dev(int k, uint64_t init_state, uint64_t first_bit, uint64_t nbits,

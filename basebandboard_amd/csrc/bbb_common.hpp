@@ -45,7 +45,7 @@ constexpr int env_knob(const char *, int dflt) { return dflt; }
 
 // ---- PRBS entry points implemented in prbs_kernels.hip -------------------------------------
 int prbs_fill_launch(int k, uint64_t init_state, uint64_t first_bit, uint64_t nbits,
-                     uint64_t *dst, hipStream_t st);
+                     uint64_t *dst, hipStream_t st, int nt_stores = 0);
 int prbs_check_launch(int k, uint64_t init_state, uint64_t first_bit, uint64_t nbits,
                       const uint64_t *src, uint64_t *nerr_dev, hipStream_t st);
 int prbs_detector_launch(int k, const uint8_t *bits, uint64_t nstreams, uint64_t n, uint8_t *err,

@@ -104,6 +104,8 @@ extern "C" int bbb_custom_fill(const uint32_t *planes_dev, int8_t *dst_dev, uint
     return (int)hipGetLastError();
 }
 extern "C" int bbb_custom_order(void) { return BBB_N; }
+// the layout contract between this library and libbbb_hip.so (plane layout, TrialDev, launch geometry): awgn_launch.hpp
+extern "C" int bbb_custom_abi(void) { return BBB_CUSTOM_ABI; }
 
 #if BBB_N == 256
 // the fused BER trial kernels over this matrix's network (the signature of bbb_custom_ber_fn, include/bbb.h)

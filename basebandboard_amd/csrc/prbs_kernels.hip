@@ -145,7 +145,7 @@ __device__ __forceinline__ void fill_store(T *p, const T &v) {
 template <int K, bool CHECK, int WPL, bool LW>
 __global__ void __launch_bounds__(64, 2)   // >= 2 waves per SIMD: at most 256 registers
 prbs_stream_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwords, u64 rows_per_wave,
-                   u64 *__restrict buf, u64 *__restrict nerr) {
+                   u64 *__restrict buf, u64 *__restrict nerr, int nt_stores) {
     typedef typename LaneWords<WPL>::type lw_t;
     constexpr int TAP = tap_of(K);
     constexpr int RW = 64 * WPL;                 // words per row
@@ -294,13 +294,26 @@ prbs_stream_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwords,
                 for (int i = 0; i < K; i++) W[i] ^= W[(i - TAP + K) % K];
 #pragma unroll
                 for (int i = 0; i < K; i++) Xv[i * 64 + lane] = W[i];
+                if (nt_stores) {
 #pragma unroll
-                for (int i = 0; i < K; i++) fill_store(reinterpret_cast<lw_t *>(rowp + (u64)i * RW) + lane, W[i]);
+                    for (int i = 0; i < K; i++) __builtin_nontemporal_store(W[i], reinterpret_cast<lw_t *>(rowp + (u64)i * RW) + lane);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < K; i++) fill_store(reinterpret_cast<lw_t *>(rowp + (u64)i * RW) + lane, W[i]);
+                }
             } else {
 #pragma unroll
                 for (int i = 0; i < K; i++) xor_inplace(V[i], V[(i - TAP + K) % K]);
+                // nt_stores (bbb_prbs_fill_hint, BBB_PRBS_WILL_READ_BACK): non-temporal stores leave the memory-side cache
+                // clean, so that a check right behind this fill does not pay for the write-backs of its last 256 MiB (the
+                // fill itself is ~15 % slower that way, which is why it is the caller's choice: DESIGN.md, PRBS)
+                if (nt_stores) {
 #pragma unroll
-                for (int i = 0; i < K; i++) fill_store(reinterpret_cast<lw_t *>(rowp + (u64)i * RW) + lane, V[i]);
+                    for (int i = 0; i < K; i++) __builtin_nontemporal_store(V[i], reinterpret_cast<lw_t *>(rowp + (u64)i * RW) + lane);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < K; i++) fill_store(reinterpret_cast<lw_t *>(rowp + (u64)i * RW) + lane, V[i]);
+                }
             }
             continue;
         }
@@ -536,7 +549,7 @@ static int prbs_wpl(bool check) {
 }
 
 template <bool CHECK, int WPL, bool LW>
-static int launch_stream_w(int k, int ki, u64 init_state, u64 first_bit, u64 nbits, u64 *buf, u64 *nerr, hipStream_t st) {
+static int launch_stream_w(int k, int ki, u64 init_state, u64 first_bit, u64 nbits, u64 *buf, u64 *nerr, hipStream_t st, int nt_stores) {
     const u64 nwords = (nbits + 63) / 64;
     const u64 RW = 64 * WPL;
     const u64 rows = (nwords + RW - 1) / RW;
@@ -575,7 +588,7 @@ static int launch_stream_w(int k, int ki, u64 init_state, u64 first_bit, u64 nbi
 #define BBB_PRBS_CASE(KK)                                                                                       \
     case KK:                                                                                                    \
         hipLaunchKernelGGL((prbs_stream_kernel<KK, CHECK, WPL, LW>), grid, block, 0, st, ki, init_state, first_bit, \
-                           nbits, nwords, rpw, buf, nerr);                                                      \
+                           nbits, nwords, rpw, buf, nerr, nt_stores);                                           \
         break;
     switch (k) {
         BBB_PRBS_CASE(7) BBB_PRBS_CASE(9) BBB_PRBS_CASE(11) BBB_PRBS_CASE(15)
@@ -587,7 +600,7 @@ static int launch_stream_w(int k, int ki, u64 init_state, u64 first_bit, u64 nbi
 }
 
 template <bool CHECK>
-static int launch_stream(int k, u64 init_state, u64 first_bit, u64 nbits, u64 *buf, u64 *nerr, hipStream_t st) {
+static int launch_stream(int k, u64 init_state, u64 first_bit, u64 nbits, u64 *buf, u64 *nerr, hipStream_t st, int nt_stores = 0) {
     const int ki = k_index(k);
     if (ki < 0) return fail(BBB_EINVAL, "k=" + std::to_string(k) + " invalid for PRBS");
     if (init_state == 0 || init_state >> k) return fail(BBB_EINVAL, "PRBS state must be in [1, 2^k)");
@@ -606,14 +619,14 @@ static int launch_stream(int k, u64 init_state, u64 first_bit, u64 nbits, u64 *b
     static const int rev = env_knob("BBB_PRBS_CHECK_REV", 1);
     if (CHECK && rev && !lw && prbs_wpl(true) == 1) return launch_check_rev(k, ki, init_state, first_bit, nbits, buf, nerr, st);
     if (prbs_wpl(CHECK) == 1)
-        return lw ? launch_stream_w<CHECK, 1, true>(k, ki, init_state, first_bit, nbits, buf, nerr, st)
-                  : launch_stream_w<CHECK, 1, false>(k, ki, init_state, first_bit, nbits, buf, nerr, st);
-    return lw ? launch_stream_w<CHECK, 2, true>(k, ki, init_state, first_bit, nbits, buf, nerr, st)
-              : launch_stream_w<CHECK, 2, false>(k, ki, init_state, first_bit, nbits, buf, nerr, st);
+        return lw ? launch_stream_w<CHECK, 1, true>(k, ki, init_state, first_bit, nbits, buf, nerr, st, nt_stores)
+                  : launch_stream_w<CHECK, 1, false>(k, ki, init_state, first_bit, nbits, buf, nerr, st, nt_stores);
+    return lw ? launch_stream_w<CHECK, 2, true>(k, ki, init_state, first_bit, nbits, buf, nerr, st, nt_stores)
+              : launch_stream_w<CHECK, 2, false>(k, ki, init_state, first_bit, nbits, buf, nerr, st, nt_stores);
 }
 
-int prbs_fill_launch(int k, uint64_t init_state, uint64_t first_bit, uint64_t nbits, uint64_t *dst, hipStream_t st) {
-    return launch_stream<false>(k, init_state, first_bit, nbits, (u64 *)dst, nullptr, st);
+int prbs_fill_launch(int k, uint64_t init_state, uint64_t first_bit, uint64_t nbits, uint64_t *dst, hipStream_t st, int nt_stores) {
+    return launch_stream<false>(k, init_state, first_bit, nbits, (u64 *)dst, nullptr, st, nt_stores);
 }
 int prbs_check_launch(int k, uint64_t init_state, uint64_t first_bit, uint64_t nbits, const uint64_t *src,
                       uint64_t *nerr_dev, hipStream_t st) {

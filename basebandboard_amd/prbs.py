@@ -38,15 +38,17 @@ class PRBS:
         _lib.check(_lib.lib().bbb_prbs_state_at(self.k, self.init, int(nbits), C.byref(s)), "bbb_prbs_state_at")
         return s.value
 
-    def generate(self, nbits, first_bit=0, out=None):
+    def generate(self, nbits, first_bit=0, out=None, will_read_back=False):
+        """will_read_back: hint that a checker follows right behind (bbb_prbs_fill_hint): same bits, the fill leaves no
+        dirty lines in the memory-side cache for the reader to write back."""
         nwords = (int(nbits) + 63) // 64
         dev = torch.device("cuda", self.device)
         if out is None:
             out = torch.empty(nwords, dtype=torch.int64, device=dev)
         if out.dtype != torch.int64 or out.numel() < nwords or not out.is_contiguous() or out.device != dev:
             raise ValueError("out must be a contiguous int64 CUDA tensor with >= ceil(nbits/64) words")
-        _lib.check(_lib.lib().bbb_prbs_fill(self.k, self.init, int(first_bit), int(nbits), C.c_void_p(out.data_ptr()),
-                                            self.device, _stream_ptr(self.device)), "bbb_prbs_fill")
+        _lib.check(_lib.lib().bbb_prbs_fill_hint(self.k, self.init, int(first_bit), int(nbits), C.c_void_p(out.data_ptr()),
+                                                 1 if will_read_back else 0, self.device, _stream_ptr(self.device)), "bbb_prbs_fill")
         return out[:nwords]
 
 

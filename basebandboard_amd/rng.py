@@ -107,7 +107,13 @@ class LUTOPT:
         if self.k > 256 or self.k & (self.k - 1):
             raise ValueError("custom kernels exist for power-of-two k <= 256")
         root = pathlib.Path(__file__).resolve().parent
-        key = hashlib.sha1(repr([list(r) for r in self.packed]).encode()).hexdigest()[:16]
+        # the cache key covers the taps AND everything the built library shares with libbbb_hip.so (template, BER kernels,
+        # launch header with BBB_CUSTOM_ABI, generator): a library cached by another checkout is never picked up
+        hsh = hashlib.sha1(repr([list(r) for r in self.packed]).encode())
+        for dep in ("csrc/custom_fill_template.hip", "csrc/ber_kernels_impl.hpp", "csrc/awgn_launch.hpp", "csrc/bitslice_util.hpp",
+                    "csrc/bbb_common.hpp", "gen_lutopt_kernel.py"):
+            hsh.update((root / dep).read_bytes())
+        key = hsh.hexdigest()[:16]
         bdir = pathlib.Path(build_dir) if build_dir else pathlib.Path.home() / ".cache" / "basebandboard_amd"
         work = bdir / f"k{self.k}_{key}"
         so = work / f"libbbb_custom_{key}.so"

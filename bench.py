@@ -411,10 +411,18 @@ def main():
         fill = lambda first, n: _lib.check(L.bbb_prbs_fill(31, 1, first, n, C.c_void_p(pbuf.data_ptr() + first // 8), local_rank, sp), "bbb_prbs_fill")
         check = lambda first, n: _lib.check(L.bbb_prbs_check_dev(31, 1, first, n, C.c_void_p(pbuf.data_ptr() + first // 8),
                                                                 C.c_void_p(cnt.data_ptr()), local_rank, sp), "bbb_prbs_check_dev")
+        fill_rb = lambda first, n: _lib.check(L.bbb_prbs_fill_hint(31, 1, first, n, C.c_void_p(pbuf.data_ptr() + first // 8), 1, local_rank, sp), "bbb_prbs_fill_hint")
         for _ in range(2):
             fill(0, nbits); check(0, nbits)
         torch.cuda.synchronize()
         reps = 5
+        # the loopback as a loopback caller runs it: the fill told that a check follows (BBB_PRBS_WILL_READ_BACK)
+        fh_ms = ch_ms = 0.0
+        for _ in range(reps):
+            e = [ev() for _ in range(3)]
+            e[0].record(); fill_rb(0, nbits); e[1].record(); check(0, nbits); e[2].record()
+            torch.cuda.synchronize()
+            fh_ms += e[0].elapsed_time(e[1]) / reps; ch_ms += e[1].elapsed_time(e[2]) / reps
         f_ms = c_ms = c2_ms = p_ms = 0.0
         piece = 1 << 31                                  # 256 MiB
         for _ in range(reps):
@@ -434,8 +442,11 @@ def main():
             "bits": nbits, "errors": nerr,
             "fill_ms": round(f_ms, 4), "check_after_fill_ms": round(c_ms, 4), "check_clean_ms": round(c2_ms, 4),
             "fill_tb_s": tb(f_ms), "check_after_fill_tb_s": tb(c_ms), "check_clean_tb_s": tb(c2_ms),
-            "loopback_ms": round(f_ms + c_ms, 4), "loopback_tb_s": round(2 * nbytes / (f_ms + c_ms) / 1e9, 3),
-            "loopback_hbm_frac": round(2 * nbytes / (f_ms + c_ms) / 1e6 / HBM_PEAK_GBS, 4),
+            "loopback_ms": round(fh_ms + ch_ms, 4), "loopback_tb_s": round(2 * nbytes / (fh_ms + ch_ms) / 1e9, 3),
+            "loopback_hbm_frac": round(2 * nbytes / (fh_ms + ch_ms) / 1e6 / HBM_PEAK_GBS, 4),
+            "loopback_form": "bbb_prbs_fill_hint(BBB_PRBS_WILL_READ_BACK) + bbb_prbs_check_dev: the fill writes with non-temporal stores",
+            "hinted_fill_ms": round(fh_ms, 4), "check_after_hinted_fill_ms": round(ch_ms, 4),
+            "plain_fill_then_check_ms": round(f_ms + c_ms, 4), "plain_fill_then_check_hbm_frac": round(2 * nbytes / (f_ms + c_ms) / 1e6 / HBM_PEAK_GBS, 4),
             "pieced_256MiB_loopback_ms": round(p_ms, 4), "pieced_256MiB_loopback_tb_s": round(2 * nbytes / p_ms / 1e9, 3),
             "gen_gbit_s": round(nbits / f_ms / 1e6, 1), "check_gbit_s": round(nbits / c_ms / 1e6, 1),
             "note": "whole-buffer passes; the checker reads every region from its end on the generator's partition (what the "

@@ -172,6 +172,13 @@ int bbb_clt_tree_i16(int k, const uint64_t *states_dev, uint64_t nstates, int16_
  * word are zero.  dst_dev must be 16-byte aligned. */
 int bbb_prbs_fill(int k, uint64_t init_state, uint64_t first_bit, uint64_t nbits,
                   uint64_t *dst_packed_dev, int device, void *hip_stream);
+/* The same fill with a hint about what the caller does next.  BBB_PRBS_WILL_READ_BACK: the buffer is about to be read
+ * back (a loopback: bbb_prbs_check / bbb_prbs_detector_stream right behind the fill).  The generator then writes with
+ * non-temporal stores: the fill itself takes ~15 % longer, but it leaves no dirty lines in the memory-side cache for the
+ * reader to write back, and fill + check together finish sooner.  Same bits either way. */
+#define BBB_PRBS_WILL_READ_BACK 1u
+int bbb_prbs_fill_hint(int k, uint64_t init_state, uint64_t first_bit, uint64_t nbits,
+                       uint64_t *dst_packed_dev, unsigned flags, int device, void *hip_stream);
 /* Phase-known checker: number of positions where src differs from the same PRBS.  This is
  * the steady-state (`reload == 0`) behaviour of PRBSErrorDetector.err (prbs.py:79) summed
  * over the stream.  *nerr is a host result (the call synchronises the stream). */

@@ -172,3 +172,19 @@ def test_concurrent_checks_do_not_share_a_counter(gpu, oracle):
     for x in th:
         x.join()
     assert got == [[w] * 6 for w in want]
+
+
+@pytest.mark.parametrize("k", [7, 20, 31])
+def test_read_back_hint_changes_no_bit(gpu, k):
+    """bbb_prbs_fill_hint(BBB_PRBS_WILL_READ_BACK): non-temporal stores in the generator -- the same words as bbb_prbs_fill at
+    ragged sizes and offsets, and a clean check behind it; an unknown flag is refused."""
+    import ctypes as C
+    p = gpu.PRBS(k)
+    for nbits, first in ((1, 0), (4097, 3), (3_000_001, 64 * 1000 + 5), (50_000_000, 1 << 40)):
+        a = p.generate(nbits, first_bit=first)
+        b = p.generate(nbits, first_bit=first, will_read_back=True)
+        assert torch.equal(a, b)
+        assert gpu.PRBSErrorDetector(k).count_errors(b, nbits, first_bit=first) == 0
+    buf = torch.zeros(4, dtype=torch.int64, device="cuda")
+    l = gpu._lib.lib()
+    assert l.bbb_prbs_fill_hint(k, 1, 0, 100, C.c_void_p(buf.data_ptr()), 2, 0, None) == gpu._lib.BBB_EINVAL

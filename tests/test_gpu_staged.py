@@ -366,3 +366,29 @@ def test_prefetch_survives_unrelated_fills_on_its_slot(gpu, oracle):
         got = buf.cpu().numpy()
         for off in (0, big // 2 - 77, big - 300_000):
             assert np.array_equal(got[off:off + 300_000], m.awgn(u.state_at(first + off), 0, 300_000, fast=True)), (first, off)
+
+
+def test_an_untaken_hint_does_not_race_the_next_one(gpu, oracle):
+    """A hint whose fill comes with another partition is never taken: its seeding stays queued on the arithmetic stream of the
+    fill it expected.  The next hint seeds the same buffers from the OTHER arithmetic stream and must queue behind it (round
+    3: seeding moved from one side stream to the two arithmetic streams; the soak's seed 3 found the two writing side by
+    side).  Several rounds of: hinted fill with a size of another partition, hint, fill that takes it."""
+    m = oracle.Lutopt(path=oracle.data_path(256))
+    u = gpu.LUTOPT.shipped(256, init=0xBEEF)
+    u.set_staged(True)
+    g = gpu.CLTGRNG(u)
+    pos, outs = 16, []
+    for r in range(6):
+        n1 = BIG + 16 * (100 + r)
+        n2 = BIG + 16 * (400 + 7 * r)            # another number of generators: the hint for (n1, pos) does not match it
+        g.prefetch(n1, first_step=pos)
+        outs.append((pos, g.generate(n2, first_step=pos)))
+        pos += n2
+        g.prefetch(n2, first_step=pos)             # seeds the same buffers as the untaken hint, from the other stream
+        outs.append((pos, g.generate(n2, first_step=pos)))
+        pos += n2
+    torch.cuda.synchronize()
+    for p, x in outs:
+        assert np.array_equal(x[:200_000].cpu().numpy(), m.awgn(u.state_at(p), 0, 200_000, fast=True)), p
+        tail = m.awgn(u.state_at(p + x.numel() - 4096), 0, 4096, fast=True)
+        assert np.array_equal(x[-4096:].cpu().numpy(), tail), p
