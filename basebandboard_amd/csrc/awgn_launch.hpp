@@ -2,11 +2,6 @@
 #pragma once
 #include "bbb_common.hpp"
 
-// Version of what a custom library (csrc/custom_fill_template.hip, built per matrix) shares with this one: the bit-plane
-// layout it is handed, TrialDev, the generator numbering.  Bumped whenever any of them changes;
-// bbb_lutopt_attach_custom_library refuses a library that reports another value (or none).
-#define BBB_CUSTOM_ABI 3
-
 namespace bbb {
 
 // start states S[g] = B^g s0 (per radix-16 level e and digit j = 1..15 a nibble-combination table of

@@ -9,6 +9,8 @@
 
 #include "../../include/bbb.h"
 
+#include "custom_abi.hpp"
+
 namespace bbb {
 
 // per-thread text of the last failure (returned by bbb_last_error_detail)

@@ -8,6 +8,7 @@
 #include <cstdint>
 
 #include "bitslice_util.hpp"
+#include "custom_abi.hpp"
 #include "custom_gen.inc"
 
 #define BBB_CAT2(a, b, c) a##b##c
@@ -104,7 +105,7 @@ extern "C" int bbb_custom_fill(const uint32_t *planes_dev, int8_t *dst_dev, uint
     return (int)hipGetLastError();
 }
 extern "C" int bbb_custom_order(void) { return BBB_N; }
-// the layout contract between this library and libbbb_hip.so (plane layout, TrialDev, launch geometry): awgn_launch.hpp
+// the layout contract between this library and libbbb_hip.so (plane layout, TrialDev, launch geometry): custom_abi.hpp
 extern "C" int bbb_custom_abi(void) { return BBB_CUSTOM_ABI; }
 
 #if BBB_N == 256

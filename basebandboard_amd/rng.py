@@ -111,7 +111,7 @@ class LUTOPT:
         # launch header with BBB_CUSTOM_ABI, generator): a library cached by another checkout is never picked up
         hsh = hashlib.sha1(repr([list(r) for r in self.packed]).encode())
         for dep in ("csrc/custom_fill_template.hip", "csrc/ber_kernels_impl.hpp", "csrc/awgn_launch.hpp", "csrc/bitslice_util.hpp",
-                    "csrc/bbb_common.hpp", "gen_lutopt_kernel.py"):
+                    "csrc/bbb_common.hpp", "csrc/custom_abi.hpp", "gen_lutopt_kernel.py"):
             hsh.update((root / dep).read_bytes())
         key = hsh.hexdigest()[:16]
         bdir = pathlib.Path(build_dir) if build_dir else pathlib.Path.home() / ".cache" / "basebandboard_amd"

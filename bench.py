@@ -482,17 +482,17 @@ def main():
             tx = bbb.TX(31, 1, 0, 16, 1, 8, device=local_rank)
             tx.urng.set_staged(staged_tx)
             txbuf = torch.empty(ntx, dtype=torch.int16, device=dev)
-            for i in range(3):                                   # (the first calls build the jump plans)
+            for i in range(24):                                  # (jump plans; and the clock governor's ramp: see the docstring)
                 tx.generate(ntx, first_sample=i * ntx, out=txbuf)
             torch.cuda.synchronize()
             t0e, t1e = ev(), ev()
             t0e.record()
-            for i in range(3, 11):
+            for i in range(24, 44):
                 tx.generate(ntx, first_sample=i * ntx, out=txbuf)
             t1e.record()
             torch.cuda.synchronize()
             del txbuf
-            return t0e.elapsed_time(t1e) / 8
+            return t0e.elapsed_time(t1e) / 20
         ntx = 1_000_000_000
         tx_ms = tx_rate(ntx, True)
         tx_ms_1k = tx_rate(1 << 29, False)
