@@ -480,16 +480,22 @@ awgn256_kernel(const uint32_t *__restrict planes, void *__restrict dst_, unsigne
 // with two waves per CU that runs in the issue slots the sample kernel cannot use.
 // Staging layout: u32x4 stage[wave][step][half][lane], half 0 = planes 0..3, half 1 = planes 4..7 (plane 7 already
 // complemented: the int8 two's complement form).  Every wave runs all L steps (generators beyond G are padding).
+// (Tried: [wave][lane >> 3][step][half][lane & 7], which makes a mover unit's 32 KiB ONE contiguous block instead of 256 lines
+// out of 256 different 1 KiB rows.  Slower: noise 1.085 -> 1.19 ms per 1e9 at one read per kernel, the shaping mover's
+// calls 1.44 -> 1.77 ms -- a CU's burst then falls on few memory channels; scattered lines spread over all of them.)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 awgn256_planes_kernel(const uint32_t *__restrict planes, u32x4 *__restrict stage, unsigned L, unsigned nlanes
 #ifdef BBB_EXPERIMENTS
-                      , unsigned long long *dbg
+                      , unsigned long long *dbg, unsigned exp_flags      // 1: compute, but store nothing; 2: plain stores; 4: wave priority 0
 #endif
 ) {
     const unsigned lane = threadIdx.x;
     const unsigned long long wave = blockIdx.x;
     const unsigned long long LG = wave * 64 + lane;
+#ifdef BBB_EXPERIMENTS
+    if (exp_flags & 4) __builtin_amdgcn_s_setprio(0); else
+#endif
     __builtin_amdgcn_s_setprio(3);
 #ifdef BBB_EXPERIMENTS
     unsigned long long dbg_t0 = 0, dbg_r0 = 0;
@@ -503,6 +509,25 @@ awgn256_planes_kernel(const uint32_t *__restrict planes, u32x4 *__restrict stage
     LUTOPT256_FOR_PARKED_HI(BBB_PARK)
 #undef BBB_PARK
     u32x4 *out = stage + (wave * L) * 128 + lane;
+#ifdef BBB_EXPERIMENTS
+    if (exp_flags & 3) {      // (experiments/mover_beside.py: what slows the mover beside this kernel -- its stores or its instructions)
+        const bool nostore = exp_flags & 1;
+#pragma unroll 1
+        for (unsigned t = 0; t < L; t += 2) {
+            lutopt256_step_parked_hi(a, pa, b, pb, cnt);
+            if (!nostore || (cnt[0] == 0x9e3779b9u && cnt[5] == 0x7f4a7c15u && cnt[7] == 0x12345u)) {
+                out[0] = (u32x4){cnt[0], cnt[1], cnt[2], cnt[3]};
+                out[64] = (u32x4){cnt[4], cnt[5], cnt[6], cnt[7]};
+            }
+            lutopt256_step_parked_hi(b, pb, a, pa, cnt);
+            if (!nostore || (cnt[0] == 0x9e3779b9u && cnt[5] == 0x7f4a7c15u && cnt[7] == 0x12345u)) {
+                out[128] = (u32x4){cnt[0], cnt[1], cnt[2], cnt[3]};
+                out[192] = (u32x4){cnt[4], cnt[5], cnt[6], cnt[7]};
+            }
+            out += 256;
+        }
+    } else
+#endif
 #pragma unroll 1
     for (unsigned t = 0; t < L; t += 2) {
         lutopt256_step_parked_hi(a, pa, b, pb, cnt);
@@ -530,7 +555,7 @@ int awgn256_planes_launch(const uint32_t *d_planes, void *stage, unsigned L, uns
     if (L & 1) return fail(BBB_EINVAL, "segment length must be even");
 #ifdef BBB_EXPERIMENTS
     hipLaunchKernelGGL(awgn256_planes_kernel, dim3(nlanes / 64), dim3(64), 0, st, d_planes, (u32x4 *)stage, L, nlanes,
-                       (unsigned long long *)g_exp_awgn_debug);
+                       (unsigned long long *)g_exp_awgn_debug, (unsigned)env_knob("BBB_EXP_PLANES_FLAGS", 0));
 #else
     hipLaunchKernelGGL(awgn256_planes_kernel, dim3(nlanes / 64), dim3(64), 0, st, d_planes, (u32x4 *)stage, L, nlanes);
 #endif
@@ -552,40 +577,55 @@ int awgn256_planes_launch(const uint32_t *d_planes, void *stage, unsigned L, uns
 //            row sits at chunk position c ^ 2 * ((lane8 >> 1) & 3): a wave's store hits all 64 banks once);
 //   phase 2  thread (row, chunk): ds_read_b128 + one 16-byte store; the 8 lanes of a generator write 128 consecutive
 //            bytes of its segment, a wave 8 consecutive segments.
-// LDS (dynamic, ONE array: 2 x 32 KiB raw + 32 KiB tile): the DMA of unit u+1 is in flight while unit u is processed;
-// raw barriers and counted vmcnt (a __syncthreads() would drain the DMA: cdna_hip_programming.md, "Pipelining across barriers").
-// One block of four waves per CU, persistent over its share of the units.
-constexpr unsigned kUnplaneRaw = 32 * 1024, kUnplaneLds = 3 * 32 * 1024, kUnplaneLdsTx = kUnplaneLds + 256 * 8 * 2 + 2 * 2048;
+// LDS (dynamic, ONE array: 2 x 32 KiB raw + 32 KiB tile; the shaping mover adds its 32 KiB table and 4 KiB of window words):
+// the DMA of unit u+1 is in flight while unit u is processed; raw barriers and counted vmcnt (a __syncthreads() would drain the
+// DMA: cdna_hip_programming.md, "Pipelining across barriers").  One block of four waves per CU, persistent over its share of
+// the units.
+// What bounds it (experiments/mover_phases.py, shader-clock stamps per phase and wave): of ~9500 cycles per unit 1900 go to
+// phase 1 (its 340 instructions), 5100 to phase 2 -- eight LDS reads and eight stores -- and 1700 to ISSUING the eight DMA
+// instructions: the wave waits for the memory pipeline to accept its loads and stores.  64 KiB per unit and CU in 9500 cycles
+// is 3.9 TB/s over the chip: the memory system's rate for this pattern (128-byte pieces, read and written 1:1), not the
+// mover's instructions -- taking the divisions out of the loop, the DMA addresses down to one add each and the shaping
+// mover's per-sample selects out (1290 -> 830 instructions per unit; 810 -> 440 for the plain mover) changed its time by
+// nothing, and so did a third raw buffer (two units in flight).  What did help is the ORDER of the units: see Pos below.
+constexpr unsigned kUnplaneRaw = 32 * 1024, kUnplaneLds = 3 * 32 * 1024, kUnplaneLdsTx = kUnplaneLds + 32 * 1024 + 2 * 2048;
+
+struct UnplaneGeom {                 // host computed (unplane_launch_with)
+    unsigned w_lo, ngroups, nunits;  // first source wave of the window; ceil(L / 128); units = waves x 8 x ngroups
+    unsigned per_block;              // a block takes the units [per_block * blockIdx.x, + per_block) of the order (w, q8, rg)
+};
 
 template <bool TXM>
 __global__ void __launch_bounds__(256, 7)      // <= 72 registers: a wave of this kernel must fit beside the sample kernel's (<= 440 of 512)
 unplane_kernel(const u32x4 *__restrict stage, char *__restrict dst, unsigned long long win_lo, unsigned long long nbytes_, unsigned L,
-               unsigned long long G, unsigned w_lo, unsigned w_n, TxFuse tx) {
+               unsigned long long G, UnplaneGeom ge, TxFuse tx) {
     // DYNAMIC shared memory: with a static array of this size hipcc derives "at most one wave per SIMD" from the LDS size
     // and enforces it by declaring 257 registers for this kernel -- which then cannot share a SIMD with the sample
     // kernel's wave (measured: half of the sample waves waited for the mover to leave)
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     typedef __attribute__((address_space(3))) void *lds_void_ptr;
-    const unsigned tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const unsigned ngroups = (L + 127) / 128;
-    const unsigned long long nunits = (unsigned long long)w_n * ngroups * 8;
+    const unsigned tid = threadIdx.x, lane = tid & 63;
+    const unsigned wv = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    if (blockIdx.x * ge.per_block >= ge.nunits) return;
     // the stream window [win_lo, win_lo + nbytes_) of the staged segments goes to dst[0 ..): dst is indexed by stream offset
     char *const dstw = dst - win_lo;
     const unsigned long long nbytes = win_lo + nbytes_;
     // phase 1: quad-step and lane of eight
     const unsigned l8 = tid & 7, qs = tid >> 3;
     const unsigned wr0 = l8 * 32 + ((((qs >> 2) ^ (2 * ((l8 >> 1) & 3))) << 2) | (qs & 3));      // word of (row j*8 + l8, steps 4qs..)
-    // phase 2: rows (4 k + (tid >> 6)) * 8 + lq, k = 0..7; chunk c2
+    // phase 2: rows (4 k + wv) * 8 + lq, k = 0..7; chunk c2
     const unsigned lq = (tid >> 3) & 7, c2 = tid & 7;
-    const unsigned rd0 = ((tid >> 6) * 8 + lq) * 32 + ((c2 ^ (2 * ((lq >> 1) & 3))) << 2);
+    const unsigned rd0 = (wv * 8 + lq) * 32 + ((c2 ^ (2 * ((lq >> 1) & 3))) << 2);
     uint32_t *const tile = lds + 2 * (kUnplaneRaw / 4);
     // TXM (the SHAPING mover of bbb_tx_fill_i16 on a staged handle): every 16-byte piece of noise leaves as the 16 int16
-    // samples x = wrap12(bit_en shaped + g noise_var) (tx.py:75-81), the arithmetic of the fused kernel's round end (TxFuse, the
-    // table TT and the window / select / multiply-add scheme described above awgn256_kernel) done here, by the guest
-    uint16_t *const TT = reinterpret_cast<uint16_t *>(lds + kUnplaneLds / 4);
-    uint32_t *const winb = lds + kUnplaneLds / 4 + 1024;      // [2][256 generators][2 words]: the units' data-bit windows, by DMA
-    uint32_t selmask[4] = {0, 0, 0, 0};
+    // samples x = wrap12(bit_en shaped + g noise_var) (tx.py:75-81), the arithmetic of the fused kernel's round end (TxFuse and
+    // the multiply-add scheme described above awgn256_kernel) done here, by the guest.  The fused kernel's table TT[q][j] (8
+    // phases of one 8-bit window) is widened to T10[q10][e]: the 16 shaped samples of a piece for each value of its 10-bit
+    // data window -- two ds_read_b128 and no per-sample select.
+    uint32_t *const T10 = lds + kUnplaneLds / 4;              // [1024 windows][8 words = 16 samples]
+    uint32_t *const winb = lds + kUnplaneLds / 4 + 8192;      // [2][256 generators][2 words]: the units' data-bit windows, by DMA
     if (TXM) {
+        uint16_t *const TT = reinterpret_cast<uint16_t *>(tile);      // (the tile is idle until the first unit's phase 1)
         for (int e = (int)tid; e < 256 * 8; e += 256) {
             const int q = e >> 3, j = e & 7, ph = (int)((tx.c0 + (unsigned)j) & 7u);
             int sum = 0;
@@ -597,10 +637,15 @@ unplane_kernel(const u32x4 *__restrict stage, char *__restrict dst, unsigned lon
             const int shaped = tx.bit_en ? ((int)((unsigned)sum << 20) >> 20) : 0;
             TT[e] = (uint16_t)((unsigned)((shaped - 128 * tx.noise_var) * 16) & 0xffffu);
         }
-#pragma unroll
-        for (int d = 0; d < 4; d++)
-            selmask[d] = (tx.c0 + 2u * (unsigned)d < 8u ? 0x0000ffffu : 0u) | (tx.c0 + 2u * (unsigned)d + 1u < 8u ? 0xffff0000u : 0u);
-        // (made visible to the other waves by the first barrier of the unit loop; no DMA touches this part of the LDS)
+        __syncthreads();
+        // sample e of a piece has phase (c0 + e) & 7 and sees the window shifted by (c0 + e) >> 3 in {0, 1, 2} data bits
+        for (unsigned p = tid; p < 1024 * 8; p += 256) {
+            const unsigned q10 = p >> 3, e = 2 * (p & 7);
+            const uint32_t lo = TT[(((q10 >> ((tx.c0 + e) >> 3)) & 0xffu) << 3) + (e & 7)];
+            const uint32_t hi = TT[(((q10 >> ((tx.c0 + e + 1) >> 3)) & 0xffu) << 3) + ((e + 1) & 7)];
+            T10[p] = lo | (hi << 16);
+        }
+        __syncthreads();      // (TT is overwritten by the first unit's phase 1; nothing is in flight yet, so the full barrier costs nothing)
     }
 #ifdef BBB_EXPERIMENTS
     if (!TXM && tx.bits && lane == 0) {      // which SIMD this mover wave sits on, and when it ran
@@ -612,55 +657,102 @@ unplane_kernel(const u32x4 *__restrict stage, char *__restrict dst, unsigned lon
         d[1] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
-    // the 8 DMA instructions of this wave for unit u into raw buffer `buf`: 1 KiB block b = wv * 8 + k holds
-    // c = b >> 2 (step-in-quad s = c >> 1, half = c & 1) of quad-steps (b & 3) * 8 .. + 8
-    auto dma_unit = [&](unsigned long long u, unsigned buf) {
-        const unsigned q8 = (unsigned)(u & 7);
-        const unsigned step0 = (unsigned)((u >> 3) % ngroups) * 128;
-        const unsigned long long w = w_lo + (u >> 3) / ngroups;
-        const u32x4 *src = stage + (w * L) * 128 + q8 * 8 + (lane & 7);
+    // a unit's place: 8 lanes q8 of source wave w (relative to ge.w_lo), steps 128 rg ..; unit index = (w * 8 + q8) * ngroups + rg.
+    // A block takes CONSECUTIVE units: the step groups of the same 8 lanes one after the other.  A generator's 128 bytes of a
+    // unit are not aligned to the 128-byte lines of the stream unless L is a multiple of 128 (1e9 samples: L = 480); the rest
+    // of its first and last line belongs to the neighbouring step groups, and those now pass through the same L2 within
+    // microseconds instead of through eight different ones (with a block stride over the units the eight lanes-of-eight of
+    // one (wave, step group) ran at the same time on eight XCDs, and every line left its L2 partly written).
+    struct Pos { unsigned q8, rg, w; };
+    auto advance = [&](Pos &p) {
+        if (++p.rg == ge.ngroups) {
+            p.rg = 0;
+            if (++p.q8 == 8) { p.q8 = 0; p.w++; }
+        }
+    };
+    const unsigned voff_lane = (lane & 7) * 16 + (lane >> 3) * 8192;      // a lane's 16 bytes of its row; rows 4 steps (8 KiB) apart
+    // the 8 DMA instructions of this wave for a unit into raw buffer `buf`: 1 KiB block b = wv * 8 + k holds
+    // c = b >> 2 = 2 wv + (k >> 2) (step-in-quad s = wv, half = k >> 2) of quad-steps (k & 3) * 8 .. + 8
+    auto dma_unit = [&](const Pos &p, unsigned buf) {
+        const unsigned step0 = p.rg * 128;
+        const unsigned long long wabs = (unsigned long long)ge.w_lo + p.w;
+        const char *const sb = reinterpret_cast<const char *>(stage) + ((wabs * L + step0) * 128 + p.q8 * 8) * 16;
+        uint32_t *const rawb = lds + buf * (kUnplaneRaw / 4) + wv * 8 * 256;
+        if (step0 + 128 <= L) {
+            const char *const pl = sb + wv * 2048 + voff_lane;
 #pragma unroll
-        for (unsigned k = 0; k < 8; k++) {
-            const unsigned b = wv * 8 + k, c = b >> 2;
-            unsigned st = step0 + 4 * ((b & 3) * 8 + (lane >> 3)) + (c >> 1);
-            st = st < L ? st : L - 1;                       // (a segment's last unit may be short: phase 2 never writes those steps)
-            const u32x4 *g = src + ((size_t)st * 2 + (c & 1)) * 64;
-            __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)(uintptr_t)(lds + buf * (kUnplaneRaw / 4) + b * 256), 16, 0, 0);
+            for (unsigned k = 0; k < 8; k++)
+                __builtin_amdgcn_global_load_lds((const void *)(pl + ((k & 3) * 32 * 2048 + (k >> 2) * 1024)),
+                                                 (lds_void_ptr)(uintptr_t)(rawb + k * 256), 16, 0, 0);
+        } else {
+            // a segment's last unit may be short: phase 2 never writes the missing steps, the DMA re-reads the last one
+            const unsigned last = L - 1 - step0;
+#pragma unroll
+            for (unsigned k = 0; k < 8; k++) {
+                unsigned st = 4 * ((k & 3) * 8 + (lane >> 3)) + wv;
+                st = st < last ? st : last;
+                __builtin_amdgcn_global_load_lds((const void *)(sb + (size_t)st * 2048 + (k >> 2) * 1024 + (lane & 7) * 16),
+                                                 (lds_void_ptr)(uintptr_t)(rawb + k * 256), 16, 0, 0);
+            }
         }
         if (TXM) {
             // the data bits the unit's pieces will need: per generator the two 32-bit words that hold the windows of its 128
-            // samples (16 data bits + 10 of window), fetched like the planes: no registers, landed before phase 2 asks
+            // samples (16 data bits + 10 of window), fetched like the planes: no registers, landed before phase 2 asks.
+            // pu = position in this call of the generator's first sample of the unit (negative when the window starts inside
+            // the unit; the buffer leads with 128 zero bits, so the word index stays >= 0)
+            const long long so = (long long)((wabs * 2048 + p.q8 * 8) * (unsigned long long)L + step0) - (long long)win_lo;
 #pragma unroll
             for (unsigned i = 0; i < 2; i++) {
                 const unsigned e = (wv * 2 + i) * 64 + lane, row = e >> 1;
-                const unsigned long long gq = (w * 32 + (row >> 3)) * 64 + q8 * 8 + (row & 7);
-                const unsigned long long o = gq * (unsigned long long)L + step0;
-                // (the window may start inside the unit: the unit's first sample then has a negative position in this call;
-                // the buffer leads with 128 zero bits, so the word index stays >= 0)
+                const long long pu = so + (long long)((unsigned long long)((row >> 3) * 64 + (row & 7)) * L);
                 uint32_t word = 0;
-                if (o + 128 > win_lo && o < nbytes) {
-                    const long long pu = (long long)o - (long long)win_lo;
-                    word = ((uint32_t)((pu >> 3) + (long long)tx.rel_base) >> 5) + (e & 1);
-                }
+                if (pu > -128 && pu < (long long)nbytes_) word = (((uint32_t)(pu >> 3) + tx.rel_base) >> 5) + (e & 1);
                 word = word < tx.last_word ? word : tx.last_word;
                 __builtin_amdgcn_global_load_lds((const void *)(tx.bits + word), (lds_void_ptr)(uintptr_t)(winb + buf * 512 + (wv * 2 + i) * 64), 4, 0, 0);
             }
         }
     };
+    // counted wait: all but the wave's n youngest vector-memory operations done (n wave-uniform)
+    auto wait_vm = [](unsigned n) {
+        switch (n) {
+#define BBB_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+            BBB_W(8) BBB_W(10) BBB_W(16) BBB_W(26)
+#undef BBB_W
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+    };
+    constexpr unsigned NDMA = TXM ? 10 : 8, NST = TXM ? 16 : 8;      // DMA instructions per unit and wave; stores of a straight-line unit
+    const unsigned u0 = blockIdx.x * ge.per_block;
+    const unsigned n_it = ge.nunits - u0 < ge.per_block ? ge.nunits - u0 : ge.per_block;
+    Pos cur;
+    cur.rg = u0 % ge.ngroups;
+    cur.q8 = (u0 / ge.ngroups) & 7;
+    cur.w = (u0 / ge.ngroups) >> 3;
+    Pos nxt = cur;
+    advance(nxt);
     unsigned buf = 0;
-    if (blockIdx.x < nunits) dma_unit(blockIdx.x, 0);
-    for (unsigned long long u = blockIdx.x; u < nunits; u += gridDim.x, buf ^= 1) {
-        const unsigned q8 = (unsigned)(u & 7);
-        const unsigned rg = (unsigned)((u >> 3) % ngroups);
-        const unsigned long long w = w_lo + (u >> 3) / ngroups;
-        const unsigned step0 = rg * 128;
-        const bool more = u + gridDim.x < nunits;
-        if (more) dma_unit(u + gridDim.x, buf ^ 1);
-        // this unit's DMA (and the previous unit's stores, which are older) done: all but the 8 instructions just issued
-        if (more && TXM) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        else if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bool fast1 = false;      // wave-uniform: the whole wave took the straight-line store path in the previous unit
+#ifdef BBB_EXPERIMENTS
+    // where a unit's time goes (experiments/mover_phases.py): shader-clock ticks summed per wave over its units
+    unsigned long long ph_t[6] = {0, 0, 0, 0, 0, 0}, ph_last = __builtin_amdgcn_s_memtime();
+#define BBB_PH(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph_t[i] += now_ - ph_last; ph_last = now_; }
+#else
+#define BBB_PH(i)
+#endif
+    dma_unit(cur, 0);
+    for (unsigned it = 0; it < n_it; it++, buf ^= 1) {
+        const unsigned q8 = cur.q8, step0 = cur.rg * 128;
+        const unsigned long long w = (unsigned long long)ge.w_lo + cur.w;
+        const bool more1 = it + 1 < n_it;
+        if (more1) dma_unit(nxt, buf ^ 1);
+        BBB_PH(0)
+        // This unit's DMA must have landed.  vmcnt counts loads, DMA and stores together, in issue order.  Younger than this
+        // unit's DMA are the previous unit's stores and the DMA just issued: with a KNOWN count (a straight-line unit issues
+        // exactly NST store instructions per wave) they stay in flight; otherwise the wait covers the stores too.
+        wait_vm((more1 ? NDMA : 0u) + (fast1 ? NST : 0u));
+        BBB_PH(1)
         __builtin_amdgcn_s_barrier();
+        BBB_PH(2)
         // ---- phase 1
         {
             const uint32_t *raw = lds + buf * (kUnplaneRaw / 4) + (qs * 8 + l8) * 4;
@@ -670,7 +762,7 @@ unplane_kernel(const u32x4 *__restrict stage, char *__restrict dst, unsigned lon
                 const u32x4 lo = *reinterpret_cast<const u32x4 *>(raw + (2 * s) * 1024);
                 const u32x4 hi = *reinterpret_cast<const u32x4 *>(raw + (2 * s + 1) * 1024);
                 Z[s][0] = lo[0]; Z[s][1] = lo[1]; Z[s][2] = lo[2]; Z[s][3] = lo[3];
-                Z[s][4] = hi[0]; Z[s][5] = hi[1]; Z[s][6] = hi[2]; Z[s][7] = hi[3];
+                Z[s][4] = hi[0]; Z[s][5] = hi[1]; Z[s][6] = hi[2]; Z[s][7] = TXM ? ~hi[3] : hi[3];      // (TXM: u = g + 128, the unsigned count)
             }
 #pragma unroll
             for (unsigned s = 0; s < 4; s++) planes8_to_bytes(Z[s]);
@@ -683,14 +775,21 @@ unplane_kernel(const u32x4 *__restrict stage, char *__restrict dst, unsigned lon
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        BBB_PH(3)
         __builtin_amdgcn_s_barrier();
+        BBB_PH(4)
         // ---- phase 2: row (4 k + wv) * 8 + lq = generator (w * 32 + 4 k + wv) * 64 + q8 * 8 + lq, its bytes step0 + 16 c2 ..
         const unsigned inseg = step0 + c2 * 16;
         const unsigned long long g0 = (w * 32 + wv) * 64 + q8 * 8 + lq;
         unsigned long long off = g0 * (unsigned long long)L + inseg;
         const unsigned long long goff = 256ull * L;
+        // the straight-line path is taken by the WHOLE wave or not at all (the count of store instructions a wave issues then
+        // is exact: see the wait above)
+        const bool lane_fast = inseg < L && g0 + 7 * 256 < G && off >= win_lo && off + 7 * goff + 16 <= nbytes;
+        const bool wave_fast = __all(lane_fast);
+        fast1 = wave_fast;
         if (!TXM && inseg < L) {
-            if (g0 + 7 * 256 < G && off >= win_lo && off + 7 * goff + 16 <= nbytes) {
+            if (wave_fast) {
                 // every generator of this thread exists and its chunk lies inside the window
 #pragma unroll
                 for (unsigned k = 0; k < 8; k++) {
@@ -716,41 +815,34 @@ unplane_kernel(const u32x4 *__restrict stage, char *__restrict dst, unsigned lon
             // positions are relative to the window: sample p of this call = stream offset win_lo + p; dst holds int16
             int16_t *const dst16 = reinterpret_cast<int16_t *>(dst);
             const u16x2 nv16 = {(uint16_t)(tx.noise_var * 16), (uint16_t)(tx.noise_var * 16)};
-            const uint32_t use_mask = tx.use_bits ? 0x3ffu : 0u;
+            const uint32_t idx_mask = tx.use_bits ? 0x7fe0u : 0u;            // (no data bits: every window reads as 0)
+            // where the thread's pieces sit in their generators' two window words (dma_unit): the same for all eight, their
+            // positions differ by multiples of 256 L samples = 32 L data bits
+            const uint32_t sh = ((((uint32_t)((long long)(off - win_lo) >> 3)) + tx.rel_base - 2u * c2) & 31u) + 2u * c2;
+            const uint32_t *const wb0 = winb + buf * 512 + (wv * 8 + lq) * 2;
             // one 16-byte piece of noise -> 16 int16 samples; FULL: the piece lies wholly inside the window (no tail)
             auto piece = [&](auto full_c, unsigned k, unsigned long long o) {
                 constexpr bool FULL = decltype(full_c)::value;
-                const unsigned long long p0 = o - win_lo;                                        // first sample of the piece, in this call
-                const uint32_t rel = ((uint32_t)p0 >> 3) + tx.rel_base;
-                // the generator's two window words (dma_unit), and where the unit's first sample sits in them
-                const unsigned row = (4 * k + wv) * 8 + lq;
                 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-                const u32x2 ww = *reinterpret_cast<const u32x2 *>(&winb[buf * 512 + row * 2]);
-                const uint32_t rel_u = rel - 2u * c2;                                            // window position of the unit's first sample
-                const unsigned long long w64 = ((unsigned long long)ww[1] << 32) | ww[0];
-                const uint32_t wk = (uint32_t)(w64 >> ((rel_u & 31u) + 2u * c2));
+                const u32x2 ww = *reinterpret_cast<const u32x2 *>(wb0 + k * 64);
                 const u32x4 v = *reinterpret_cast<const u32x4 *>(&tile[rd0 + k * 1024]);
-                // the piece's 10-bit data window (bit j = data bit M0 - 7 + j), as in the fused kernel (use_mask: no data bits = all 0)
-                const uint32_t Q4 = (wk & use_mask) << 4;
-                const char *tt = reinterpret_cast<const char *>(TT);
-                const u32x4 A = *reinterpret_cast<const u32x4 *>(tt + (Q4 & 0xff0u));
-                const u32x4 B = *reinterpret_cast<const u32x4 *>(tt + ((Q4 >> 1) & 0xff0u));
-                const u32x4 C = *reinterpret_cast<const u32x4 *>(tt + ((Q4 >> 2) & 0xff0u));
+                // the piece's 10-bit data window (bit j = data bit M0 - 7 + j) selects its row of shaped samples
+                const uint32_t wk = (uint32_t)((((unsigned long long)ww[1] << 32) | ww[0]) >> sh);
+                const char *const row = reinterpret_cast<const char *>(T10) + ((wk << 5) & idx_mask);
+                const u32x4 A = *reinterpret_cast<const u32x4 *>(row);
+                const u32x4 B = *reinterpret_cast<const u32x4 *>(row + 16);
                 uint32_t x[8];
 #pragma unroll
                 for (int w4 = 0; w4 < 4; w4++) {
-                    const uint32_t ub = v[w4] ^ 0x80808080u;                          // bytes g + 128 of samples 4w .. 4w+3
-                    const uint32_t u01 = __builtin_amdgcn_perm(0u, ub, 0x0c010c00u);  // [u0, 0, u1, 0]
-                    const uint32_t u23 = __builtin_amdgcn_perm(0u, ub, 0x0c030c02u);
-                    const int d0 = (2 * w4) & 3, d1 = (2 * w4 + 1) & 3;
-                    const uint32_t s01 = w4 < 2 ? bfi_uniform(selmask[d0], A[d0], B[d0]) : bfi_uniform(selmask[d0], B[d0], C[d0]);
-                    const uint32_t s23 = w4 < 2 ? bfi_uniform(selmask[d1], A[d1], B[d1]) : bfi_uniform(selmask[d1], B[d1], C[d1]);
+                    const uint32_t u01 = __builtin_amdgcn_perm(0u, v[w4], 0x0c010c00u);  // [u0, 0, u1, 0]: bytes g + 128 of samples 4w, 4w+1
+                    const uint32_t u23 = __builtin_amdgcn_perm(0u, v[w4], 0x0c030c02u);
+                    const uint32_t s01 = w4 < 2 ? A[2 * w4] : B[2 * w4 - 4], s23 = w4 < 2 ? A[2 * w4 + 1] : B[2 * w4 - 3];
                     const u16x2 m01 = __builtin_bit_cast(u16x2, u01) * nv16 + __builtin_bit_cast(u16x2, s01);
                     const u16x2 m23 = __builtin_bit_cast(u16x2, u23) * nv16 + __builtin_bit_cast(u16x2, s23);
                     x[2 * w4] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(i16x2, m01) >> 4);
                     x[2 * w4 + 1] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(i16x2, m23) >> 4);
                 }
-                int16_t *out = dst16 + p0;
+                int16_t *out = dst16 + (o - win_lo);
                 if (FULL || o + 16 <= nbytes) {
                     const u32x4 lo = {x[0], x[1], x[2], x[3]}, hi = {x[4], x[5], x[6], x[7]};
                     reinterpret_cast<u32x4 *>(out)[0] = lo;
@@ -760,12 +852,18 @@ unplane_kernel(const u32x4 *__restrict stage, char *__restrict dst, unsigned lon
                     for (unsigned e = 0; e < n; e++) out[e] = (int16_t)((x[e >> 1] >> (16 * (e & 1))) & 0xffff);
                 }
             };
-            if (g0 + 7 * 256 < G && off >= win_lo && off + 7 * goff + 16 <= nbytes) {
-                // every piece of this thread exists and lies inside the window: straight-line code, so that the LDS reads of
+            if (wave_fast) {
+                // every piece of this wave exists and lies inside the window: straight-line code, so that the LDS reads of
                 // one piece are in flight while the previous one is shaped (a guest wave waits ~100 cycles per dependent read)
+                // (four at a time: eight in flight need more than the 72 registers a guest wave gets, and a spill to scratch
+                // would count in vmcnt, which this kernel counts by hand)
+#pragma unroll 1
+                for (unsigned k4 = 0; k4 < 8; k4 += 4) {
 #pragma unroll
-                for (unsigned k = 0; k < 8; k++) piece(std::true_type{}, k, off + k * goff);
+                    for (unsigned k = 0; k < 4; k++) piece(std::true_type{}, k4 + k, off + (k4 + k) * goff);
+                }
             } else {
+#pragma unroll 1
                 for (unsigned k = 0; k < 8; k++) {
                     const unsigned long long o = off + k * goff;
                     if (g0 + 256ull * k >= G || o >= nbytes) break;
@@ -775,8 +873,22 @@ unplane_kernel(const u32x4 *__restrict stage, char *__restrict dst, unsigned lon
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        BBB_PH(5)
         __builtin_amdgcn_s_barrier();           // the tile and raw[buf] are free for the next unit
+        BBB_PH(4)
+        cur = nxt;
+        advance(nxt);
     }
+#ifdef BBB_EXPERIMENTS
+    if (!TXM && tx.bits && lane == 0 && blockIdx.x * 4 + wv < 1024) {
+        // [7 * 1024 + ...] is beyond the 8 x 1024 buffer's stamps in use: [6*1024 .. 8*1024) holds the SIMD ids (2 per wave);
+        // the phase sums go to a second buffer handed over through tx.coeffs' place: see mover_phases.py
+        unsigned long long *d = (unsigned long long *)tx.bits + 8 * 1024 + 8 * (blockIdx.x * 4 + wv);
+        for (int i = 0; i < 6; i++) d[i] = ph_t[i];
+        d[6] = n_it;
+    }
+#endif
+#undef BBB_PH
 }
 
 static int unplane_launch_with(const void *stage, void *dst, uint64_t win_lo, uint64_t nbytes, unsigned L, uint64_t G, unsigned nlanes,
@@ -792,9 +904,15 @@ static int unplane_launch_with(const void *stage, void *dst, uint64_t win_lo, ui
     uint64_t w_hi = (win_lo + nbytes + seg - 1) / seg;
     if (w_hi > nlanes / 64) w_hi = nlanes / 64;
     const unsigned w_n = (unsigned)(w_hi - w_lo);
-    const uint64_t nunits = (uint64_t)w_n * ((L + 127) / 128) * 8;
+    const unsigned ngroups = (L + 127) / 128;
+    const uint64_t nunits = (uint64_t)w_n * ngroups * 8;
+    if (nunits >> 32) return fail(BBB_EINVAL, "staged window too large for one mover launch (2^32 units of 32 KiB)");
     uint64_t blocks = (uint64_t)ncu * (uint64_t)env_knob("BBB_UNPLANE_BLOCKS_PER_CU", 1);
     if (blocks > nunits) blocks = nunits;
+    UnplaneGeom ge;
+    ge.w_lo = w_lo; ge.ngroups = ngroups; ge.nunits = (unsigned)nunits;
+    ge.per_block = (unsigned)((nunits + blocks - 1) / blocks);
+    blocks = (nunits + ge.per_block - 1) / ge.per_block;
     {
         static std::mutex mu;
         static bool attr_set[64] = {false};
@@ -807,14 +925,14 @@ static int unplane_launch_with(const void *stage, void *dst, uint64_t win_lo, ui
     }
     if (tx) {
         hipLaunchKernelGGL(unplane_kernel<true>, dim3((unsigned)blocks), dim3(256), kUnplaneLdsTx, st, (const u32x4 *)stage, (char *)dst,
-                           (unsigned long long)win_lo, (unsigned long long)nbytes, L, (unsigned long long)G, w_lo, w_n, *tx);
+                           (unsigned long long)win_lo, (unsigned long long)nbytes, L, (unsigned long long)G, ge, *tx);
     } else {
         TxFuse none{};
 #ifdef BBB_EXPERIMENTS
         none.bits = (const uint32_t *)g_exp_awgn_debug;
 #endif
         hipLaunchKernelGGL(unplane_kernel<false>, dim3((unsigned)blocks), dim3(256), kUnplaneLds, st, (const u32x4 *)stage, (char *)dst,
-                           (unsigned long long)win_lo, (unsigned long long)nbytes, L, (unsigned long long)G, w_lo, w_n, none);
+                           (unsigned long long)win_lo, (unsigned long long)nbytes, L, (unsigned long long)G, ge, none);
     }
     BBB_HIP(hipGetLastError());
     return BBB_OK;

@@ -5,6 +5,7 @@
 #include "gf2.hpp"
 #include "rccl_loader.hpp"
 #include "sweep_shard.hpp"
+#include "sweep_threads.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -88,7 +89,8 @@ struct bbb_lutopt {
     // kernel of call s still reads its own -- two buffers, each with the event of its last reader
     uint32_t *d_fbits[2] = {nullptr, nullptr}; size_t fbits_cap[2] = {0, 0};
     hipEvent_t fbits_read[2] = {nullptr, nullptr}, fbits_ready = nullptr;
-    uint32_t *d_mbits = nullptr; size_t mbits_cap = 0;        // staged TX: this call's data bits, written and read on the mover's stream
+    uint32_t *d_mbits[2] = {nullptr, nullptr}; size_t mbits_cap[2] = {0, 0};   // staged TX: a call's data bits, one buffer per staging slot (written on the
+                                                                               // slot's arithmetic stream in front of the sample kernel, read by the slot's mover)
     hipEvent_t ber_fork = nullptr, ber_join = nullptr;       // ber_run: PRBS seeding on the side stream beside the generator's
     bool fbits_pending[2] = {false, false};
     int fbits_slot = 0;
@@ -138,6 +140,7 @@ struct bbb_lutopt {
     struct Ahead {
         bool valid = false; int kind = 0; uint64_t first = 0, step = 0, n = 0, win_lo = 0, L = 0, G = 0;
         unsigned nlanes = 0, left = 0; int slot = 0; bbb_tx_cfg cfg{};
+        int64_t bits_m0 = 0; uint64_t bits_words64 = 0;      // transmitter: the slot's data-bit buffer starts at bit bits_m0
     } ahead;
     bool last_fill_tx = false;            // the last sample-kernel launch was the transmitter variant (more LDS: see bbb_awgn_prefetch)
     int staged_level = 0;                 // 0 off, 1 staged, m >= 2 staged with m fills per sample kernel
@@ -812,7 +815,7 @@ int bbb_lutopt_destroy(bbb_lutopt *h) {
     for (auto &p : h->prbs_plans) (void)hipFree(p.second.d_cols);
     for (void *p : {(void *)h->d_states, (void *)h->d_planes, (void *)h->d_pstates, (void *)h->d_pplanes,
                     (void *)h->d_taps, (void *)h->d_row_off, (void *)h->d_counters, (void *)h->d_txnoise,
-                    (void *)h->d_txbits, (void *)h->d_fbits[0], (void *)h->d_fbits[1], (void *)h->d_mbits, (void *)h->pf.d_states, (void *)h->pf.d_planes})
+                    (void *)h->d_txbits, (void *)h->d_fbits[0], (void *)h->d_fbits[1], (void *)h->d_mbits[0], (void *)h->d_mbits[1], (void *)h->pf.d_states, (void *)h->pf.d_planes})
         (void)hipFree(p);
     for (hipEvent_t e : {h->pf.seeded, h->pf.last_read, h->cur_last_read, h->handover, h->stage_free[0], h->stage_free[1],
                          h->stage_arith[0], h->stage_arith[1], h->ev_user, h->fbits_read[0], h->fbits_read[1], h->fbits_ready, h->ber_fork, h->ber_join})
@@ -1285,25 +1288,37 @@ int bbb_tx_fill_i16(bbb_lutopt *h, const bbb_tx_cfg *cfg, int16_t *out_dev, uint
             // this call's window of them into the transmitter's int16 samples (unplane_kernel<true>): the call is bounded by
             // the noise kernel, and the int8 noise crosses HBM once each way instead of the int16 output doing so twice.
             if ((rc = ensure_internal_streams(h))) return rc;
-            // the data bits go to the MOVER's stream: in order behind the previous mover (the buffer's last reader) and ahead
-            // of this call's; two zero 64-bit words lead (data bits before the first read as 0: the shaper's reset register)
-            const uint64_t words64 = 2 + (nbits + 63) / 64 + 3;
-            if (h->mbits_cap < (size_t)words64 * 2) {
-                BBB_HIP(hipStreamSynchronize(h->ys));                          // growing frees the old buffer
-                if ((rc = grow(&h->d_mbits, &h->mbits_cap, (size_t)words64 * 2))) return rc;
-            }
-            uint32_t *const d_bits = h->d_mbits;
-            if (use_bits) {
-                BBB_HIP(hipMemsetAsync(d_bits, 0, 16, h->ys));
+            // The data bits: two zero 64-bit words lead (data bits before the first read as 0: the shaper's reset register).
+            // One buffer per staging slot, holding the bits of ALL the windows the slot's sample kernel produces; they are
+            // generated on the slot's ARITHMETIC stream, straight in front of the sample kernel -- in the gap between two sample
+            // kernels.  (On the mover's stream the generator, a 100-register kernel, could not be placed beside the running
+            // sample kernel and held the mover back until that kernel had ended: the transmitter's mover then ran AFTER the
+            // noise kernel instead of beside it.)
+            uint64_t words64 = 0;
+            uint32_t *d_bits = nullptr;
+            uint32_t rel = rel_base;
+            bool bits_on = use_bits;
+            auto make_bits = [&](int slot, uint64_t nbits_all) -> int {
+                words64 = 2 + (nbits_all + 63) / 64 + 3;
+                // the buffer's last reader is the slot's last mover
+                if (h->mbits_cap[slot] < (size_t)words64 * 2) {
+                    if (h->stage_busy[slot]) BBB_HIP(hipEventSynchronize(h->stage_free[slot]));      // growing frees the old buffer
+                    int rcg = grow(&h->d_mbits[slot], &h->mbits_cap[slot], (size_t)words64 * 2);
+                    if (rcg) return rcg;
+                } else if (h->stage_busy[slot]) {
+                    BBB_HIP(hipStreamWaitEvent(h->cs, h->stage_free[slot], 0));
+                }
+                d_bits = h->d_mbits[slot];
+                if (!cfg->bit_en || !nbits_all) return BBB_OK;
+                BBB_HIP(hipMemsetAsync(d_bits, 0, 16, h->cs));
                 uint64_t *bits64 = (uint64_t *)d_bits + 2;
-                if (cfg->source == 0) rc = prbs_fill_launch(cfg->prbs_k, cfg->prbs_state, (uint64_t)m0, nbits, bits64, h->ys);
-                else rc = pulse_bits_launch(bits64, m0, (nbits + 63) / 64, h->ys);
-                if (rc) return rc;
-            }
+                return cfg->source == 0 ? prbs_fill_launch(cfg->prbs_k, cfg->prbs_state, (uint64_t)m0, nbits_all, bits64, h->cs)
+                                        : pulse_bits_launch(bits64, m0, (nbits_all + 63) / 64, h->cs);
+            };
             auto deliver_tx = [&](int slot, uint64_t win_lo, uint64_t Lk, uint64_t Gk, unsigned nl) {
                 return queue_mover_with(h, slot, [&](const void *stage, hipStream_t ys) {
                     return unplane_tx_launch(stage, out_dev, win_lo, nsamples, (unsigned)Lk, Gk, nl, cfg->coeffs, d_bits, (uint32_t)(words64 * 2),
-                                             rel_base, (uint32_t)(F & 7), cfg->noise_var, cfg->bit_en, use_bits ? 1 : 0, ys);
+                                             rel, (uint32_t)(F & 7), cfg->noise_var, cfg->bit_en, bits_on ? 1 : 0, ys);
                 });
             };
             // look-ahead (bbb_lutopt_set_staged(h, m >= 2)): the noise of these very samples was produced by an earlier call's
@@ -1313,13 +1328,18 @@ int bbb_tx_fill_i16(bbb_lutopt *h, const bbb_tx_cfg *cfg, int16_t *out_dev, uint
                 tx_cfg_equal(h->ahead.cfg, *cfg)) {
                 if ((rc = begin_op(h, true))) return rc;
                 const bbb_lutopt::Ahead a = h->ahead;
+                // its data bits sit in the slot's buffer, behind those of the windows before it
+                d_bits = h->d_mbits[a.slot]; words64 = a.bits_words64;
+                rel = (uint32_t)(FM - 7 - (a.bits_m0 - 128));
+                bits_on = cfg->bit_en != 0;
                 h->ahead.first += nsamples; h->ahead.step += nsamples;
                 h->ahead.win_lo += nsamples;
                 h->ahead.valid = --h->ahead.left > 0;
                 return deliver_tx(a.slot, a.win_lo, a.L, a.G, a.nlanes);
             }
             const uint64_t mla = (uint64_t)h->staged_level;
-            const bool ahead = mla >= 2 && (nsamples % 16) == 0 && mla * nsamples < (1ull << 40) &&
+            // (< 2^34 samples per kernel: the windows' bit offsets into the slot's data-bit buffer are 32-bit)
+            const bool ahead = mla >= 2 && (nsamples % 16) == 0 && mla * nsamples < (1ull << 34) &&
                                first_sample + mla * nsamples < (1ull << 62) && cfg->warmup + first_sample + mla * nsamples >= mla * nsamples;
             const uint64_t ntotal = ahead ? mla * nsamples : nsamples;        // what the sample kernel produces
             partition(h, ntotal, 16, &L, &G, &nlanes);
@@ -1330,6 +1350,11 @@ int bbb_tx_fill_i16(bbb_lutopt *h, const bbb_tx_cfg *cfg, int16_t *out_dev, uint
             h->last_fill_tx = false;            // (what runs on the SIMDs is the plain kernel)
             bool from_pf = false;
             if ((rc = acquire_planes(h, step0, L, G, nlanes, true, &from_pf))) return rc;
+            int64_t m0_all;
+            uint64_t nbits_all;
+            tx_bit_range(first_sample, ntotal, &m0_all, &nbits_all);           // (m0_all == m0: the same first sample)
+            bits_on = cfg->bit_en && nbits_all;
+            if ((rc = make_bits(h->stage_slot ^ 1, nbits_all))) return rc;     // (the slot produce_planes takes next)
             int slot = 0;
             if ((rc = produce_planes(h, L, nlanes, nullptr, from_pf, &slot))) return rc;
             if ((rc = deliver_tx(slot, 0, L, G, nlanes))) return rc;
@@ -1339,6 +1364,7 @@ int bbb_tx_fill_i16(bbb_lutopt *h, const bbb_tx_cfg *cfg, int16_t *out_dev, uint
                 a.first = first_sample + nsamples; a.step = step0 + nsamples;
                 a.n = nsamples; a.win_lo = nsamples; a.left = (unsigned)mla - 1;
                 a.L = L; a.G = G; a.nlanes = nlanes; a.slot = slot;
+                a.bits_m0 = m0; a.bits_words64 = words64;
             }
             return BBB_OK;
         }
@@ -1548,38 +1574,32 @@ int bbb_ber_sweep_multi(bbb_lutopt *const *handles, int ndev, const bbb_trial_cf
     int rc = rehearsal ? BBB_OK : get_comms(devs, &comms);
     if (rc) return rc;
     const size_t nwords = 2 * (size_t)ncfg;
-    std::vector<int> rcs((size_t)ndev, BBB_OK);
-    std::vector<std::string> errs((size_t)ndev);
     std::vector<std::vector<unsigned long long>> host((size_t)ndev, std::vector<unsigned long long>(nwords));
-    // one host thread per device launches that device's share of the trials
-    auto work = [&](int r) {
-        bbb_lutopt *h = handles[r];
-        auto body = [&]() -> int {
-            BBB_HIP(hipSetDevice(h->device));
-            std::vector<bbb_trial_cfg> mine((size_t)ncfg);
-            int e = bbb_sweep_shard(cfgs, ncfg, ndev, r, mode, mine.data());
-            if (e) return e;
-            if (h->counters_cap < nwords) {
-                if (h->d_counters) BBB_HIP(hipFree(h->d_counters));
-                h->d_counters = nullptr;
-                h->counters_cap = 0;
-                BBB_HIP(hipMalloc((void **)&h->d_counters, nwords * sizeof(unsigned long long)));
-                h->counters_cap = nwords;
-            }
-            BBB_HIP(hipMemsetAsync(h->d_counters, 0, nwords * sizeof(unsigned long long), h->stream));
-            return ber_run(h, mine.data(), ncfg, h->d_counters);
-        };
-        rcs[(size_t)r] = body();
-        if (rcs[(size_t)r]) errs[(size_t)r] = last_error();
-    };
+    // one host thread per device launches that device's share of the trials (csrc/sweep_threads.hpp: the same orchestration is
+    // built for the host under ThreadSanitizer with a stub launch, tests/san_sweep.cpp)
     {
-        std::vector<std::thread> th;
-        for (int r = 1; r < ndev; r++) th.emplace_back(work, r);
-        work(0);
-        for (auto &t : th) t.join();
+        std::string err;
+        int bad = 0;
+        rc = run_shares_on_threads(cfgs, ncfg, ndev, mode, [&](int r, const bbb_trial_cfg *mine, std::string *etext) -> int {
+            bbb_lutopt *h = handles[r];
+            auto body = [&]() -> int {
+                BBB_HIP(hipSetDevice(h->device));
+                if (h->counters_cap < nwords) {
+                    if (h->d_counters) BBB_HIP(hipFree(h->d_counters));
+                    h->d_counters = nullptr;
+                    h->counters_cap = 0;
+                    BBB_HIP(hipMalloc((void **)&h->d_counters, nwords * sizeof(unsigned long long)));
+                    h->counters_cap = nwords;
+                }
+                BBB_HIP(hipMemsetAsync(h->d_counters, 0, nwords * sizeof(unsigned long long), h->stream));
+                return ber_run(h, mine, ncfg, h->d_counters);
+            };
+            const int e = body();
+            if (e) *etext = last_error();          // (the error text is per thread)
+            return e;
+        }, &err, &bad);
+        if (rc) return fail(rc, "device " + std::to_string(devs[(size_t)bad]) + ": " + err);
     }
-    for (int r = 0; r < ndev; r++)
-        if (rcs[(size_t)r]) return fail(rcs[(size_t)r], "device " + std::to_string(devs[(size_t)r]) + ": " + errs[(size_t)r]);
     // The ONE collective of the path: all-reduce (sum) of the uint64 {bits, errors} counters over xGMI, queued on
     // each device's stream behind its trials.  Every rank must enter it, so it is issued only after all shares
     // were launched without error; one group call from this thread (the single-process multi-device form).

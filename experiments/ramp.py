@@ -27,4 +27,5 @@ for idle in ((2.0, 0.2, 0.0) if not os.environ.get('RAMP_QUICK') else (0.0,)):
     cum = [ev[0].elapsed_time(ev[i]) for i in range(K + 1)]
     print(f"after {idle} s idle: ms per step, steps 0-4: {[round(x, 3) for x in t[:5]]}")
     for lo, hi in ((0, 5), (5, 25), (25, 50), (50, 100), (100, 200), (200, 400), (400, 600)):
+        if hi > K: break
         print(f"   steps {lo:3d}-{hi:3d}: {sum(t[lo:hi]) / (hi - lo):.4f} ms/step   (t = {cum[lo]:.1f} .. {cum[hi]:.1f} ms)")

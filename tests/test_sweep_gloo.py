@@ -183,3 +183,20 @@ def test_c_abi_shard_arithmetic():
         shard_trials(trials, 2, 2)
     with pytest.raises(ValueError):
         shard_trials(trials, 0, 1, 7)
+
+
+def test_thread_per_device_orchestration_under_thread_sanitizer(tmp_path):
+    """csrc/sweep_threads.hpp (the host side of bbb_ber_sweep_multi: a thread per device, shares, error hand-back) built for
+    the host with -fsanitize=thread and a stub in place of the kernel launches (tests/san_sweep.cpp): no race, totals equal
+    the undivided trials for 1, 2, 3, 8 ranks in all three modes.  The launches themselves are rehearsed on the GPU box
+    (tests/test_gpu_ber.py::test_thread_per_device_body_rehearsed_on_one_gpu)."""
+    import subprocess
+    exe = tmp_path / "san_sweep"
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=thread", str(ROOT / "tests" / "san_sweep.cpp"), "-o", str(exe)],
+                       capture_output=True, text=True)
+    if r.returncode != 0 and "sanitize" in (r.stderr or ""):
+        pytest.skip("no ThreadSanitizer runtime for g++ here")
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith("ok tsan"), (out.stdout + out.stderr)[-3000:]
+    assert "WARNING: ThreadSanitizer" not in out.stderr
