@@ -10,7 +10,7 @@
 // A^(first_step + g*L) * init (GF(2) jump-ahead), so the concatenation is bit-identical to the
 // reference stream.  32 generators are packed per lane (bit-slicing: VGPR p = state bit p of
 // 32 generators), a wave therefore advances 2048 generators per step with ~1000 V_BITOP3/XOR
-// instructions (tools/gen_lutopt_kernel.py emits the straight-line network for the matrix).
+// instructions (basebandboard_amd/gen_lutopt_kernel.py emits the straight-line network for the matrix).
 //
 // Kernels
 //   seed_first/level_kernel  start states, radix 16: S[j*16^e + i] = (A^L)^(j*16^e) * S[i]

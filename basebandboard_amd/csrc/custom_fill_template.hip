@@ -1,6 +1,6 @@
 // custom_fill_template.hip -- a sample kernel for ONE recurrence matrix that is not among the shipped ones (for
 // instance a matrix found by bbb_lutopt_search), built at run time by basebandboard_amd.LUTOPT.specialise():
-//   tools/gen_lutopt_kernel.py <taps> custom_gen.inc
+//   basebandboard_amd/gen_lutopt_kernel.py <taps> custom_gen.inc
 //   hipcc --offload-arch=gfx950 -shared -fPIC -DBBB_N=<n> -DBBB_LOG=<log2 n> -I<dir of custom_gen.inc> -I<csrc> \
 //         custom_fill_template.hip -o libbbb_custom_<hash>.so
 // and attached to a handle with bbb_lutopt_set_custom_fill.  Same formulation as awgn_small.hip / awgn256_kernel.

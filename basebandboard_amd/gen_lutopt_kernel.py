@@ -402,7 +402,7 @@ def generate_packed512(taps):
     (low half) and among planes 256..511 (high half) of the NEW state, per generator."""
     out = []
     emit = out.append
-    emit("// GENERATED by tools/gen_lutopt_kernel.py from lutopt_512.taps -- do not edit.")
+    emit("// GENERATED by basebandboard_amd/gen_lutopt_kernel.py from lutopt_512.taps -- do not edit.")
     flat = ",".join(",".join(map(str, t)) for t in taps)
     emit(f"#define LUTOPT512_TAPS_CRC 0x{zlib.crc32(flat.encode()) & 0xffffffff:08x}u")
     e = Packed512Emitter(taps)
@@ -433,7 +433,7 @@ def generate(n, taps):
     assert 1 << logn == n and n >= 16
     out = []
     emit = out.append
-    emit(f"// GENERATED by tools/gen_lutopt_kernel.py from lutopt_{n}.taps -- do not edit.")
+    emit(f"// GENERATED by basebandboard_amd/gen_lutopt_kernel.py from lutopt_{n}.taps -- do not edit.")
     flat = ",".join(",".join(map(str, t)) for t in taps)
     emit(f"#define LUTOPT{n}_TAPS_CRC 0x{zlib.crc32(flat.encode()) & 0xffffffff:08x}u")
     order = row_order(n, taps)

@@ -60,7 +60,7 @@ extern "C" unsigned long long gidx(unsigned long long w, unsigned l, unsigned j)
 
 def build(tmp_path, n):
     inc = tmp_path / f"lutopt{n}_gen.inc"
-    subprocess.check_call([sys.executable, str(ROOT / "tools" / "gen_lutopt_kernel.py"),
+    subprocess.check_call([sys.executable, str(ROOT / "basebandboard_amd" / "gen_lutopt_kernel.py"),
                            str(ROOT / "basebandboard_amd" / "data" / f"lutopt_{n}.taps"), str(inc)])
     src = tmp_path / f"h{n}.cpp"
     src.write_text(HARNESS.replace("GEN_INC", inc.name))
@@ -123,7 +123,7 @@ def test_committed_generated_file_is_current(tmp_path):
     if not cur.exists():
         pytest.skip("not built yet")
     out = tmp_path / "x.inc"
-    subprocess.check_call([sys.executable, str(ROOT / "tools" / "gen_lutopt_kernel.py"),
+    subprocess.check_call([sys.executable, str(ROOT / "basebandboard_amd" / "gen_lutopt_kernel.py"),
                            str(ROOT / "basebandboard_amd" / "data" / "lutopt_256.taps"), str(out)])
     assert out.read_text() == cur.read_text()
 
@@ -172,7 +172,7 @@ def test_packed_n512_network_matches_oracle(oracle, tmp_path):
     """n = 512 on 256 registers: register p = plane p of 16 generators (low half) | plane 256 + (p ^ 1) (high half).
     The generated step (V_PERM pairs + XOR) and the two half counters against the oracle, 16 generators, 10 steps."""
     inc = tmp_path / "lutopt512_gen.inc"
-    subprocess.check_call([sys.executable, str(ROOT / "tools" / "gen_lutopt_kernel.py"),
+    subprocess.check_call([sys.executable, str(ROOT / "basebandboard_amd" / "gen_lutopt_kernel.py"),
                            str(ROOT / "basebandboard_amd" / "data" / "lutopt_512.taps"), str(inc)])
     src = tmp_path / "h512.cpp"
     src.write_text(HARNESS512.replace("GEN_INC", inc.name))
