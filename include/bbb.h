@@ -123,7 +123,7 @@ int bbb_awgn_prefetch(bbb_lutopt *h, uint64_t nsamples, uint64_t first_step);
  * arithmetic (integer-issue bound) share the machine.  Worth it for back-to-back fills; a single isolated fill
  * finishes later than in the one-kernel form.  Costs two staging buffers of the fill's size.
  * enable = m in 2..8 adds LOOK-AHEAD for bbb_awgn_fill_i8 (and for bbb_tx_fill_i16 with noise on this handle, while the
- * configuration stays the same and m n < 2^31): a fill of n samples at `first` lets its sample kernel produce
+ * configuration stays the same and m n < 2^34): a fill of n samples at `first` lets its sample kernel produce
  * the m n samples from `first` (one seeding, one launch for m fills; the rest waits in the staging buffer); while the
  * following fills ask for exactly (n, first + n), (n, first + 2 n) ... -- a consumer reading the one sequential stream
  * the reference's generator emits -- each only costs its piece mover.  A fill elsewhere discards what still waits (that
@@ -207,7 +207,10 @@ int bbb_prbs_detector_run(int k, const uint8_t *bits_dev, uint64_t nstreams, uin
  * speculative state obtained by running the reset detector over the warm_bits (0: 1024) before the
  * chunk; every chunk whose speculative start differs from its predecessor's true end state is run
  * again from that state until the chain is consistent, so the outputs equal the serial machine's
- * bit for bit (prbs.py:61-99).  *stats is a host result (the call synchronises the stream). */
+ * bit for bit (prbs.py:61-99).  (A re-run stops where its state meets the speculative run's: from there on the chunk
+ * is what the first pass made of it.)  *stats is a host result (the call synchronises the stream).  The call's device
+ * workspace (72 bytes per chunk: 22 MB at 1e10 bits) and a pinned read-back buffer stay allocated between calls, one
+ * set per device and concurrent call. */
 typedef struct {
     uint64_t bits;            /* clocks processed */
     uint64_t errors;          /* clocks with err == 1 and reload == 0 (what the reference test compares, prbs.py:152-163) */
