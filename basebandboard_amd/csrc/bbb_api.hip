@@ -1421,6 +1421,86 @@ int bbb_tx_fill_i16(bbb_lutopt *h, const bbb_tx_cfg *cfg, int16_t *out_dev, uint
                               cfg->noise_en, first_sample, nsamples, out_dev, h->stream);
 }
 
+
+// The transmitter as a sequential-stream object: TX.x is one sample per clock (tx.py:39-81), and a host that reads it in equal
+// calls should get the staged form without choreographing bbb_lutopt_set_staged / bbb_awgn_prefetch itself (the
+// counterpart of bbb_awgn_stream_* for the waveform).
+struct bbb_tx_stream {
+    bbb_lutopt *h = nullptr;
+    bbb_tx_cfg cfg{};
+    uint64_t n = 0, pos = 0;
+    int saved_level = 0;
+};
+
+static int tx_stream_hint(bbb_tx_stream *s) {
+    // the noise of sample p is LUTOPT clock warmup + p (tx.py:70-71): what bbb_tx_fill_i16 will ask the generator for
+    if (!s->cfg.noise_en) return BBB_OK;
+    const uint64_t step = s->cfg.warmup + s->pos;
+    if (step < s->pos || step + s->n < step) return BBB_OK;
+    return bbb_awgn_prefetch(s->h, s->n, step);
+}
+
+int bbb_tx_stream_open(bbb_lutopt *h, const bbb_tx_cfg *cfg, uint64_t nsamples_per_call, uint64_t first_sample, bbb_tx_stream **out) {
+    if (!h || !out) return fail(BBB_EINVAL, "null argument");
+    int rc = tx_check(cfg);
+    if (rc) return rc;
+    if (nsamples_per_call == 0) return fail(BBB_EINVAL, "nsamples_per_call must be positive");
+    if (h->device < 0) return fail(BBB_ENODEV, "host-only handle (device -1) cannot generate samples");
+    if (h->has_stream) return fail(BBB_EINVAL, "the handle already has an open stream");
+    if (first_sample + nsamples_per_call < first_sample) return fail(BBB_EINVAL, "first_sample + nsamples_per_call overflows");
+    std::unique_ptr<bbb_tx_stream> s(new bbb_tx_stream);
+    s->h = h; s->cfg = *cfg; s->n = nsamples_per_call; s->pos = first_sample;
+    s->saved_level = h->staged_level;
+    if (h->staged_level == 0 && cfg->noise_en) {      // (a caller who chose a level keeps it)
+        // one noise kernel per two calls: per noise kernel the guests (a shaping mover per call, then the next kernel's
+        // seeding) run one at a time and must fit into its time (1e9 samples per call: 1.44 ms at level 1, 1.28 at 2)
+        if ((rc = bbb_lutopt_set_staged(h, 2))) return rc;
+    }
+    if ((rc = tx_stream_hint(s.get()))) return rc;
+    h->has_stream = true;
+    *out = s.release();
+    return BBB_OK;
+}
+
+int bbb_tx_stream_read(bbb_tx_stream *s, int16_t *out_dev, uint64_t nsamples) {
+    if (!s || !s->h) return fail(BBB_EINVAL, "null stream");
+    if (s->pos + nsamples < s->pos) return fail(BBB_EINVAL, "the stream position overflows");
+    int rc = bbb_tx_fill_i16(s->h, &s->cfg, out_dev, nsamples, s->pos);
+    if (rc) return rc;
+    s->pos += nsamples;
+    return tx_stream_hint(s);
+}
+
+int bbb_tx_stream_next(bbb_tx_stream *s, int16_t *out_dev) {
+    if (!s) return fail(BBB_EINVAL, "null stream");
+    return bbb_tx_stream_read(s, out_dev, s->n);
+}
+
+int bbb_tx_stream_seek(bbb_tx_stream *s, uint64_t first_sample) {
+    if (!s || !s->h) return fail(BBB_EINVAL, "null stream");
+    if (first_sample + s->n < first_sample) return fail(BBB_EINVAL, "first_sample + nsamples_per_call overflows");
+    s->pos = first_sample;
+    s->h->ahead.valid = false;            // what a noise kernel produced ahead at the old position is dropped
+    return tx_stream_hint(s);
+}
+
+int bbb_tx_stream_tell(const bbb_tx_stream *s, uint64_t *next_sample) {
+    if (!s || !next_sample) return fail(BBB_EINVAL, "null argument");
+    *next_sample = s->pos;
+    return BBB_OK;
+}
+
+int bbb_tx_stream_close(bbb_tx_stream *s) {
+    if (!s) return BBB_OK;
+    int rc = BBB_OK;
+    if (s->h) {
+        s->h->has_stream = false;
+        if (s->h->staged_level != s->saved_level) rc = bbb_lutopt_set_staged(s->h, s->saved_level);
+    }
+    delete s;
+    return rc;
+}
+
 int bbb_rx_slice(const int16_t *samples_dev, uint64_t nsamples, uint64_t stride, uint64_t phase, int strict,
                  uint64_t *bits_packed_dev, uint64_t *nbits_out, int device, void *hip_stream) {
     if (stride == 0) return fail(BBB_EINVAL, "stride must be >= 1");

@@ -49,3 +49,67 @@ class TX:
             _lib.check(_lib.lib().bbb_awgn_prefetch(self.urng._h, int(nsamples), int(warmup) + int(first_sample) + int(nsamples)),
                        "bbb_awgn_prefetch")
         return out[:nsamples]
+
+    def stream(self, nsamples_per_call, first_sample=0, warmup=16):
+        """TX.x read sequentially (bbb_tx_stream_*): `with tx.stream(n) as s: s.next(out=buf)`."""
+        return WaveformStream(self, nsamples_per_call, first_sample, warmup)
+
+
+class WaveformStream:
+    """bbb_tx_stream_*: the transmitter's waveform read sequentially in equal calls; the library turns the two-kernel
+    form on and announces every next call.  The TX object's settings are copied when the stream is opened.  Context
+    manager; closing restores the generator handle's mode."""
+
+    def __init__(self, tx, nsamples_per_call, first_sample=0, warmup=16):
+        self.tx, self.n = tx, int(nsamples_per_call)
+        shaper = tx.pulse_shaper if tx.src_sel else tx.prbs_shaper            # tx.py:65
+        cfg = _cfg(shaper.coefficients[shaper.setsel], shaper.prbs, tx.bit_en, tx.noise_en, tx.noise_var, warmup)
+        s = C.c_void_p()
+        tx.urng._bind_stream()
+        _lib.check(_lib.lib().bbb_tx_stream_open(tx.urng._h, C.byref(cfg), self.n, int(first_sample), C.byref(s)), "bbb_tx_stream_open")
+        self._s = s
+
+    def _out(self, n, out):
+        dev = torch.device("cuda", self.tx.device)
+        if out is None:
+            out = torch.empty(n, dtype=torch.int16, device=dev)
+        if out.dtype != torch.int16 or out.numel() < n or not out.is_contiguous() or out.device != dev:
+            raise ValueError(f"out must be a contiguous int16 tensor on {dev} with >= {n} elements")
+        self.tx.urng._bind_stream()
+        return out
+
+    def next(self, out=None):
+        out = self._out(self.n, out)
+        _lib.check(_lib.lib().bbb_tx_stream_next(self._s, C.c_void_p(out.data_ptr())), "bbb_tx_stream_next")
+        return out[:self.n]
+
+    def read(self, nsamples, out=None):
+        n = int(nsamples)
+        out = self._out(n, out)
+        _lib.check(_lib.lib().bbb_tx_stream_read(self._s, C.c_void_p(out.data_ptr()), n), "bbb_tx_stream_read")
+        return out[:n]
+
+    def seek(self, first_sample):
+        _lib.check(_lib.lib().bbb_tx_stream_seek(self._s, int(first_sample)), "bbb_tx_stream_seek")
+
+    def tell(self):
+        v = C.c_uint64()
+        _lib.check(_lib.lib().bbb_tx_stream_tell(self._s, C.byref(v)), "bbb_tx_stream_tell")
+        return v.value
+
+    def close(self):
+        s, self._s = getattr(self, "_s", None), None
+        if s:
+            _lib.check(_lib.lib().bbb_tx_stream_close(s), "bbb_tx_stream_close")
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -480,33 +480,42 @@ def main():
         # arithmetic in the SHAPING mover that empties it beside the next call's noise kernel), and 2^29 per call in the
         # one-kernel form (shaper fused into the sample kernel) as in round 1 (the size those figures were quoted on)
         def tx_rate(ntx, level_tx):
+            # level_tx None: the stream object (bbb_tx_stream_*: it chooses level 2 itself); else bbb_lutopt_set_staged + plain calls
             tx = bbb.TX(31, 1, 0, 16, 1, 8, device=local_rank)
-            tx.urng.set_staged(level_tx > 0, look_ahead=level_tx if level_tx >= 2 else False)
             txbuf = torch.empty(ntx, dtype=torch.int16, device=dev)
+            if level_tx is None:
+                stx = tx.stream(ntx)
+                call = lambda i: stx.next(out=txbuf)                                    # noqa: E731
+            else:
+                stx = None
+                tx.urng.set_staged(level_tx > 0, look_ahead=level_tx if level_tx >= 2 else False)
+                call = lambda i: tx.generate(ntx, first_sample=i * ntx, out=txbuf)      # noqa: E731
             for i in range(24):                                  # (jump plans; and the clock governor's ramp: see the docstring)
-                tx.generate(ntx, first_sample=i * ntx, out=txbuf)
+                call(i)
             torch.cuda.synchronize()
             t0e, t1e = ev(), ev()
             t0e.record()
-            for i in range(24, 44):
-                tx.generate(ntx, first_sample=i * ntx, out=txbuf)
+            for i in range(24, 64):
+                call(i)
             t1e.record()
             torch.cuda.synchronize()
+            if stx is not None:
+                stx.close()
             del txbuf
-            return t0e.elapsed_time(t1e) / 20
+            return t0e.elapsed_time(t1e) / 40
         ntx = 1_000_000_000
         # sequential calls on a handle at bbb_lutopt_set_staged level 2: one noise kernel per two calls (what the noise stream
         # object does for its reads); level 1 = one per call, level 4 = one per four calls (2 x 4 GB of staging)
-        tx_ms = tx_rate(ntx, 2)
+        tx_ms = tx_rate(ntx, None)
         tx_ms_l1, tx_ms_l4 = tx_rate(ntx, 1), tx_rate(ntx, 4)
         tx_ms_1k = tx_rate(1 << 29, 0)
         extra["tx_waveform"] = {"samples": ntx, "gsample_s": round(ntx / tx_ms / 1e6, 1), "ms_per_call": round(tx_ms, 4),
-                                "form": "staged, level 2 (bbb_lutopt_set_staged(h, 2) on the TX's generator handle, sequential calls): noise kernel (count planes, two calls' worth) + shaping mover per call",
+                                "form": "bbb_tx_stream_next (the stream object: staged, one noise kernel -- count planes -- per two calls, a shaping mover per call)",
                                 "level_1_one_noise_kernel_per_call": {"gsample_s": round(ntx / tx_ms_l1 / 1e6, 1), "ms_per_call": round(tx_ms_l1, 4)},
                                 "level_4_one_noise_kernel_per_four_calls": {"gsample_s": round(ntx / tx_ms_l4 / 1e6, 1), "ms_per_call": round(tx_ms_l4, 4)},
                                 "one_kernel_form_2p29_per_call": {"gsample_s": round((1 << 29) / tx_ms_1k / 1e6, 1), "ms_per_call": round(tx_ms_1k, 4)},
                                 "note": "bbb_tx_fill_i16; the one-kernel form has the shaper fused into the sample kernel's round end"}
-        r = hbm("awgn256_planes_kernel + unplane_kernel<true> (whole bbb_tx_fill_i16 call, level 2)", 2.0 * ntx, tx_ms, "2 B per sample delivered (4 B of HBM traffic: count planes written and read, int16 output written)")
+        r = hbm("awgn256_planes_kernel + unplane_kernel<true> (whole bbb_tx_stream_next call)", 2.0 * ntx, tx_ms, "2 B per sample delivered (4 B of HBM traffic: count planes written and read, int16 output written)")
         r["true_bound"] = ("the guests of the noise kernel run one at a time (a SIMD has registers for its wave and ONE guest wave): per noise kernel the shaping movers "
                            "(3 GB of traffic each, 0.75 ms alone, 1.0-1.4 ms beside the kernel) and the next kernel's seeding (0.14 ms alone, 0.5 beside) must fit into its 1.0 ms per 1e9 samples")
         other.append(r)

@@ -326,6 +326,20 @@ int bbb_shaper_fill_i16(const bbb_tx_cfg *cfg, int16_t *out_dev, uint64_t nsampl
 /* TX.x on the handle's generator and stream. */
 int bbb_tx_fill_i16(bbb_lutopt *h, const bbb_tx_cfg *cfg, int16_t *out_dev, uint64_t nsamples,
                     uint64_t first_sample);
+/* TX.x as a sequential stream (tx.py:39-81: one sample per clock), the counterpart of bbb_awgn_stream_* for the waveform:
+ * open keeps a copy of *cfg, turns the two-kernel form on for the handle (level 2 of bbb_lutopt_set_staged: one noise
+ * kernel per two calls, a shaping mover per call -- unless the caller had chosen a level) and announces the first call;
+ * next delivers nsamples_per_call samples at the stream position and announces the call after it; read is next with
+ * another length (a ragged tail); seek moves the position (what waits ahead is dropped); close restores the handle's
+ * staging level.  Every call is bbb_tx_fill_i16 on the handle's stream: same samples, same errors.  One open stream per
+ * handle (noise or transmitter). */
+typedef struct bbb_tx_stream bbb_tx_stream;
+int bbb_tx_stream_open(bbb_lutopt *h, const bbb_tx_cfg *cfg, uint64_t nsamples_per_call, uint64_t first_sample, bbb_tx_stream **s);
+int bbb_tx_stream_next(bbb_tx_stream *s, int16_t *out_dev);
+int bbb_tx_stream_read(bbb_tx_stream *s, int16_t *out_dev, uint64_t nsamples);
+int bbb_tx_stream_seek(bbb_tx_stream *s, uint64_t first_sample);
+int bbb_tx_stream_tell(const bbb_tx_stream *s, uint64_t *next_sample);
+int bbb_tx_stream_close(bbb_tx_stream *s);
 
 /* Receiver front end: sign slicer (gateware/bbb/rx.py:29: bit = sample >= 0), sampling phase
  * (the BitDelayLine of rx.py:32-33, delayline.py:45-66) and clock division (rx.py:35-43); with

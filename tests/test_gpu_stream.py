@@ -114,3 +114,47 @@ def test_stream_on_other_orders(gpu, oracle, k):
             got = got[:cnt]
         assert np.array_equal(got, exp)
         pos += p.numel()
+
+
+def test_waveform_stream_equals_the_plain_calls(gpu, oracle, golden_shaper):
+    """bbb_tx_stream_*: TX.x read sequentially -- whole reads, a ragged one, other calls on the handle in between, a seek --
+    against bbb_tx_fill_i16 on a plain handle for the same positions, and a stretch against the oracle."""
+    n = BIG + 4096
+    x = gpu.TX(31, 1, 0, 16, 1, 8)
+    y = gpu.TX(31, 1, 0, 16, 1, 8)
+    with x.stream(n, first_sample=100) as st:
+        parts = [st.next() for _ in range(3)]
+        parts.append(st.read(1_000_003))
+        parts.append(st.next())
+        noise = gpu.CLTGRNG(x.urng).generate(BIG + 32, first_step=9_000_000_000)      # breaks the announced sequence
+        parts.append(st.next())
+        assert st.tell() == 100 + 5 * n + 1_000_003
+        st.seek(3_000_000_017)
+        far = st.next()
+        torch.cuda.synchronize()
+    assert x.urng is not None and gpu._lib.lib().bbb_tx_stream_close(None) == gpu._lib.BBB_OK
+    pos = 100
+    for i, p in enumerate(parts):
+        ref = y.generate(p.numel(), first_sample=pos, stream_on=False)
+        assert torch.equal(p, ref), i
+        pos += p.numel()
+    assert torch.equal(far, y.generate(n, first_sample=3_000_000_017, stream_on=False))
+    m = oracle.Lutopt(path=oracle.data_path(256))
+    exp = oracle.tx(m, 1, golden_shaper["rcf_coeffs"][16], 31, 100_000, first_sample=100 + n, noise_var=8, warmup=16)
+    assert np.array_equal(parts[1][:100_000].cpu().numpy(), exp)
+    assert np.array_equal(noise[:50_000].cpu().numpy(), m.awgn(u_state(m, 9_000_000_000, x), 0, 50_000, fast=True))
+
+
+def u_state(m, step, x):
+    return x.urng.state_at(step)
+
+
+def test_waveform_stream_refuses_a_second_stream_and_restores_the_level(gpu):
+    x = gpu.TX(31, 1, 0, 16, 1, 8)
+    st = x.stream(BIG)
+    with pytest.raises(ValueError, match="already has an open stream"):
+        gpu.CLTGRNG(x.urng).stream(BIG)
+    st.close()
+    with gpu.CLTGRNG(x.urng).stream(BIG) as s2:      # the handle is free again
+        s2.next()
+    torch.cuda.synchronize()
