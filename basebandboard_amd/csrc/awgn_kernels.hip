@@ -484,10 +484,21 @@ awgn256_kernel(const uint32_t *__restrict planes, void *__restrict dst_, unsigne
 // out of 256 different 1 KiB rows.  Slower: noise 1.085 -> 1.19 ms per 1e9 at one read per kernel, the shaping mover's
 // calls 1.44 -> 1.77 ms -- a CU's burst then falls on few memory channels; scattered lines spread over all of them.)
 // ---------------------------------------------------------------------------------------------
+// Two forms (SMALL).  false: the loaded state is advanced once in front of the loop (`planes` = the state BEFORE the first
+// sample, as for every other kernel).  Those few instructions hold the loaded and the advanced state at once -- 512 values, of
+// which hipcc parks ~180 in AGPRs -- and make the kernel a 434-register one: what is left of a SIMD's 512 holds ONE guest
+// wave.  true: `planes` = the state OF the first sample (the host seeds one clock further), no advance: 344 registers
+// (hipcc packs the loop's parked planes into 95 AGPRs), room for the mover's AND the seeding's wave at once.
+// Same loop, yet the small form is 1-2 % slower alone and 6 % slower beside the noise stream's guests, whatever its
+// register count is made to be (same box: profiles/r03_small_footprint_ab.log) -- so the noise stream, which is bound by
+// this kernel, keeps the first form, and the transmitter, which is bound by the kernel's guests (a shaping mover per call,
+// then the next kernel's seeding: one after the other beside the first form), takes the second: its guests run at the same
+// time (TX 1e9 samples per call: 1.53 -> 1.31 ms at one call per kernel, 1.34 -> 1.25 at two).
+template <bool SMALL>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 awgn256_planes_kernel(const uint32_t *__restrict planes, u32x4 *__restrict stage, unsigned L, unsigned nlanes
 #ifdef BBB_EXPERIMENTS
-                      , unsigned long long *dbg, unsigned exp_flags      // 1: compute, but store nothing; 2: plain stores; 4: wave priority 0
+                      , unsigned long long *dbg, unsigned exp_flags      // 4: wave priority 0 (1 and 2 -- no stores, plain stores -- were measured and removed: profiles/r03_mover_beside_flags.log)
 #endif
 ) {
     const unsigned lane = threadIdx.x;
@@ -502,32 +513,26 @@ awgn256_planes_kernel(const uint32_t *__restrict planes, u32x4 *__restrict stage
     if (dbg) { dbg_t0 = __builtin_amdgcn_s_memtime(); dbg_r0 = __builtin_amdgcn_s_memrealtime(); }
 #endif
     uint32_t a[256], b[256], pa[256], pb[256], cnt[8];
-#pragma unroll
-    for (int p = 0; p < 256; p++) b[p] = planes[(size_t)p * nlanes + LG];
-    lutopt256_advance(b, a);
-#define BBB_PARK(p) BBB_ACC_WRITE(pa[p], a[p]);
-    LUTOPT256_FOR_PARKED_HI(BBB_PARK)
+    if constexpr (SMALL) {
+        // (the parked planes straight into their AGPRs; scalar base per plane + ONE 32-bit lane offset)
+        const uint32_t voff = (uint32_t)LG * 4u;
+#define BBB_PLANE(p) (*reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(planes + (size_t)(p) * nlanes) + (unsigned long long)voff))
+#define BBB_PARK(p) { const uint32_t v_ = BBB_PLANE(p); BBB_ACC_WRITE(pa[p], v_); }
+        LUTOPT256_FOR_PARKED_HI(BBB_PARK)
 #undef BBB_PARK
+#pragma unroll
+        for (int p = 0; p < 256; p++)
+            if (!lutopt256_hi_is_parked(p)) a[p] = BBB_PLANE(p);
+#undef BBB_PLANE
+    } else {
+#pragma unroll
+        for (int p = 0; p < 256; p++) b[p] = planes[(size_t)p * nlanes + LG];
+        lutopt256_advance(b, a);
+#define BBB_PARK(p) BBB_ACC_WRITE(pa[p], a[p]);
+        LUTOPT256_FOR_PARKED_HI(BBB_PARK)
+#undef BBB_PARK
+    }
     u32x4 *out = stage + (wave * L) * 128 + lane;
-#ifdef BBB_EXPERIMENTS
-    if (exp_flags & 3) {      // (experiments/mover_beside.py: what slows the mover beside this kernel -- its stores or its instructions)
-        const bool nostore = exp_flags & 1;
-#pragma unroll 1
-        for (unsigned t = 0; t < L; t += 2) {
-            lutopt256_step_parked_hi(a, pa, b, pb, cnt);
-            if (!nostore || (cnt[0] == 0x9e3779b9u && cnt[5] == 0x7f4a7c15u && cnt[7] == 0x12345u)) {
-                out[0] = (u32x4){cnt[0], cnt[1], cnt[2], cnt[3]};
-                out[64] = (u32x4){cnt[4], cnt[5], cnt[6], cnt[7]};
-            }
-            lutopt256_step_parked_hi(b, pb, a, pa, cnt);
-            if (!nostore || (cnt[0] == 0x9e3779b9u && cnt[5] == 0x7f4a7c15u && cnt[7] == 0x12345u)) {
-                out[128] = (u32x4){cnt[0], cnt[1], cnt[2], cnt[3]};
-                out[192] = (u32x4){cnt[4], cnt[5], cnt[6], cnt[7]};
-            }
-            out += 256;
-        }
-    } else
-#endif
 #pragma unroll 1
     for (unsigned t = 0; t < L; t += 2) {
         lutopt256_step_parked_hi(a, pa, b, pb, cnt);
@@ -551,13 +556,20 @@ awgn256_planes_kernel(const uint32_t *__restrict planes, u32x4 *__restrict stage
 #endif
 }
 
-int awgn256_planes_launch(const uint32_t *d_planes, void *stage, unsigned L, unsigned nlanes, hipStream_t st) {
+int awgn256_planes_launch(const uint32_t *d_planes, void *stage, unsigned L, unsigned nlanes, hipStream_t st, bool small_footprint) {
     if (L & 1) return fail(BBB_EINVAL, "segment length must be even");
 #ifdef BBB_EXPERIMENTS
-    hipLaunchKernelGGL(awgn256_planes_kernel, dim3(nlanes / 64), dim3(64), 0, st, d_planes, (u32x4 *)stage, L, nlanes,
-                       (unsigned long long *)g_exp_awgn_debug, (unsigned)env_knob("BBB_EXP_PLANES_FLAGS", 0));
+    if (small_footprint)
+        hipLaunchKernelGGL(awgn256_planes_kernel<true>, dim3(nlanes / 64), dim3(64), 0, st, d_planes, (u32x4 *)stage, L, nlanes,
+                           (unsigned long long *)g_exp_awgn_debug, (unsigned)env_knob("BBB_EXP_PLANES_FLAGS", 0));
+    else
+        hipLaunchKernelGGL(awgn256_planes_kernel<false>, dim3(nlanes / 64), dim3(64), 0, st, d_planes, (u32x4 *)stage, L, nlanes,
+                           (unsigned long long *)g_exp_awgn_debug, (unsigned)env_knob("BBB_EXP_PLANES_FLAGS", 0));
 #else
-    hipLaunchKernelGGL(awgn256_planes_kernel, dim3(nlanes / 64), dim3(64), 0, st, d_planes, (u32x4 *)stage, L, nlanes);
+    if (small_footprint)
+        hipLaunchKernelGGL(awgn256_planes_kernel<true>, dim3(nlanes / 64), dim3(64), 0, st, d_planes, (u32x4 *)stage, L, nlanes);
+    else
+        hipLaunchKernelGGL(awgn256_planes_kernel<false>, dim3(nlanes / 64), dim3(64), 0, st, d_planes, (u32x4 *)stage, L, nlanes);
 #endif
     BBB_HIP(hipGetLastError());
     return BBB_OK;

@@ -23,7 +23,9 @@ int awgn256_fill_launch(const uint32_t *d_planes, int8_t *dst, uint64_t nsamples
 // PLANES form of the staged stream: the sample kernel leaves the 8 count planes of every step, u32x4 stage[wave][step][half][lane]
 // (nlanes / 64 waves x L steps x 2 KiB); the mover turns them into bytes: bytes [win_lo, win_lo + nbytes) of the staged stream
 // (generator g owns [g L, (g + 1) L)) go to dst[0 .. nbytes)
-int awgn256_planes_launch(const uint32_t *d_planes, void *stage, unsigned L, unsigned nlanes, hipStream_t st);
+// small_footprint: the form without the advance in front of its loop -- d_planes then is the state OF the first sample (seeded one
+// clock further), and the kernel leaves room for two guest waves per SIMD (slower by itself: awgn_kernels.hip)
+int awgn256_planes_launch(const uint32_t *d_planes, void *stage, unsigned L, unsigned nlanes, hipStream_t st, bool small_footprint);
 int unplane_launch(const void *stage, void *dst, uint64_t win_lo, uint64_t nbytes, unsigned L, uint64_t G, unsigned nlanes, hipStream_t st);
 // the SHAPING mover: the same window as the transmitter's int16 output x = wrap12(bit_en * shaped + g * noise_var) at dst[0 .. nsamples)
 // d_bits: packed data bits (32-bit words) of THIS window; rel_base = window bit offset of its sample 0; c0 = (first_sample - 17) & 7

@@ -143,6 +143,7 @@ struct bbb_lutopt {
         int64_t bits_m0 = 0; uint64_t bits_words64 = 0;      // transmitter: the slot's data-bit buffer starts at bit bits_m0
     } ahead;
     bool last_fill_tx = false;            // the last sample-kernel launch was the transmitter variant (more LDS: see bbb_awgn_prefetch)
+    bool last_staged_small = false;       // the last staged sample kernel was the small-footprint placement (two guest waves fit beside it)
     int staged_level = 0;                 // 0 off, 1 staged, m >= 2 staged with m fills per sample kernel
     hipEvent_t cur_last_read = nullptr;   // same, for the buffers currently in d_states / d_planes
     bool cur_read_pending = false;
@@ -420,7 +421,8 @@ int deliver_i8(bbb_lutopt *h, int slot, void *dst, uint64_t win_lo, uint64_t n, 
 // produce: the sample kernel for the stream positions the planes in h->d_planes describe, L steps per generator, into the
 // next staging slot.  planes_seeded_after_mover: the start states came from a prefetch whose seeding had itself waited for
 // the mover that last read this slot (bbb_awgn_prefetch on a staged handle), so the arithmetic need not wait for it again.
-int produce_planes(bbb_lutopt *h, uint64_t L, unsigned nlanes, bbb_lutopt::ProfEv *ev, bool planes_seeded_after_mover, int *slot_out) {
+int produce_planes(bbb_lutopt *h, uint64_t L, unsigned nlanes, bbb_lutopt::ProfEv *ev, bool planes_seeded_after_mover, int *slot_out,
+                   bool small_footprint = false) {
     const size_t need_words = (size_t)nlanes * (size_t)L * 8;              // nlanes / 64 waves x L steps x 2 KiB
     const int slot = h->stage_slot ^= 1;
     *slot_out = slot;
@@ -440,7 +442,8 @@ int produce_planes(bbb_lutopt *h, uint64_t L, unsigned nlanes, bbb_lutopt::ProfE
     if (h->stage_busy[slot] && !seeding_saw_last_mover)
         BBB_HIP(hipStreamWaitEvent(h->cs, h->stage_free[slot], 0));   // its last mover has read it
     if (ev) BBB_HIP(hipEventRecord(ev->e1, h->cs));
-    int rc = awgn256_planes_launch(h->d_planes, (void *)h->d_stage[slot], (unsigned)L, nlanes, h->cs);
+    int rc = awgn256_planes_launch(h->d_planes, (void *)h->d_stage[slot], (unsigned)L, nlanes, h->cs, small_footprint);
+    h->last_staged_small = small_footprint;
     if (rc) return rc;
     if ((rc = mark_planes_read(h))) return rc;
     if (ev) BBB_HIP(hipEventRecord(ev->e2, h->cs));
@@ -523,8 +526,9 @@ int awgn_fill(bbb_lutopt *h, void *dst, int elem_size, uint64_t nsamples, uint64
         partition(h, ntotal, 16, &L, &G, &nlanes);
         if (L > 0xffffff00ull) return fail(BBB_EINVAL, "nsamples too large for one call (segment length must fit 32 bits): split it");
     }
+    const uint64_t seed_step = first_step;
     // (a fill that will take the announced start states does not depend on the previous sample kernel: see begin_op)
-    const bool takes_prefetch = fast256 && h->pf.valid && h->pf.first == first_step && h->pf.L == L && h->pf.G == G;
+    const bool takes_prefetch = fast256 && h->pf.valid && h->pf.first == seed_step && h->pf.L == L && h->pf.G == G;
     int rc = begin_op(h, staged, staged && takes_prefetch);
     if (rc) return rc;
     bbb_lutopt::ProfEv ev{};
@@ -533,7 +537,7 @@ int awgn_fill(bbb_lutopt *h, void *dst, int elem_size, uint64_t nsamples, uint64
         BBB_HIP(hipEventRecord(ev.e0, h->cs));
     }
     bool from_pf = false;
-    rc = acquire_planes(h, first_step, L, G, nlanes, fast256, &from_pf);
+    rc = acquire_planes(h, seed_step, L, G, nlanes, fast256, &from_pf);
     if (rc) return rc;
     if (staged) {
         int slot = 0;
@@ -927,13 +931,23 @@ int bbb_lutopt_state_at(bbb_lutopt *h, uint64_t nsteps, uint64_t *state_words) {
     return BBB_OK;
 }
 
+// for_tx: the announced fill is the transmitter's on a staged handle (its noise kernel takes the state OF its first sample)
+static int awgn_prefetch(bbb_lutopt *h, uint64_t nsamples, uint64_t first_step, bool for_tx);
+
 int bbb_awgn_prefetch(bbb_lutopt *h, uint64_t nsamples, uint64_t first_step) {
+    // (which kind of fill comes next is not known here: the kind of the last staged one is assumed; a wrong guess only means
+    // that the fill seeds for itself)
+    return awgn_prefetch(h, nsamples, first_step, h && h->last_staged_small);
+}
+
+static int awgn_prefetch(bbb_lutopt *h, uint64_t nsamples, uint64_t first_step, bool for_tx) {
     if (!h) return fail(BBB_EINVAL, "null handle");
     if (h->device < 0) return fail(BBB_ENODEV, "host-only handle (device -1)");
     if ((!h->specialised && !h->fast512) || nsamples == 0) return BBB_OK;          // a hint: nothing to do for the table-driven path
     BBB_HIP(hipSetDevice(h->device));
     uint64_t L, G;
     unsigned nlanes;
+    const bool staged_size = nsamples >= (1ull << 24);            // (of the announced fill itself, before look-ahead widens it)
     if (h->staged_level >= 2 && nsamples >= (1ull << 24) && (nsamples % 16) == 0) {
         // look-ahead: a sample kernel covers m fills.  If the announced fill is one that already waits in a staging slot,
         // what needs start states is the fill after the LAST waiting one; and they are those of an m-fold request
@@ -946,6 +960,11 @@ int bbb_awgn_prefetch(bbb_lutopt *h, uint64_t nsamples, uint64_t first_step) {
             first_step += skip;
         }
         if (m * nsamples < (1ull << 40) && first_step + m * nsamples > first_step) nsamples *= m;
+    }
+    // the transmitter's noise kernel on a staged handle is given the state OF its first sample (bbb_tx_fill_i16)
+    if (for_tx && h->staged_mode && h->specialised && staged_size) {
+        if (first_step + 1 == 0) return BBB_OK;
+        first_step += 1;
     }
     if (h->fast512) {
         if (!partition512(h, nsamples, &L, &G, &nlanes)) return BBB_OK;
@@ -976,7 +995,8 @@ int bbb_awgn_prefetch(bbb_lutopt *h, uint64_t nsamples, uint64_t first_step) {
     // hold the sample kernel's wave and one guest wave.  The guests of fill s are the piece mover of fill s-1 and this seeding
     // (for fill s+1): the seeding waits for that mover.  (The mover of fill s itself starts when fill s has finished.)
     h->pf_waited_slot = -1;
-    if (h->staged_mode && h->stage_busy[h->stage_slot ^ 1]) {
+    // (Beside the small form of the sample kernel -- the transmitter's -- there is room for both guests at once.)
+    if (h->staged_mode && h->stage_busy[h->stage_slot ^ 1] && !h->last_staged_small) {
         BBB_HIP(hipStreamWaitEvent(side, h->stage_free[h->stage_slot ^ 1], 0));
         h->pf_waited_slot = h->stage_slot ^ 1;
         h->pf_waited_gen = h->stage_gen[h->stage_slot ^ 1];
@@ -1345,18 +1365,21 @@ int bbb_tx_fill_i16(bbb_lutopt *h, const bbb_tx_cfg *cfg, int16_t *out_dev, uint
             partition(h, ntotal, 16, &L, &G, &nlanes);
             if (L > 0xffffff00ull) return fail(BBB_EINVAL, "nsamples too large for one call (segment length must fit 32 bits): split it");
             const uint64_t step0 = cfg->warmup + first_sample;                // tx.py:70-71
-            const bool takes_prefetch = h->pf.valid && h->pf.first == step0 && h->pf.L == L && h->pf.G == G;
+            const uint64_t seed_step = step0 + 1;      // (the small form of the noise kernel is given the state OF its first sample)
+            const bool takes_prefetch = h->pf.valid && h->pf.first == seed_step && h->pf.L == L && h->pf.G == G;
             if ((rc = begin_op(h, true, takes_prefetch))) return rc;
             h->last_fill_tx = false;            // (what runs on the SIMDs is the plain kernel)
             bool from_pf = false;
-            if ((rc = acquire_planes(h, step0, L, G, nlanes, true, &from_pf))) return rc;
+            if ((rc = acquire_planes(h, seed_step, L, G, nlanes, true, &from_pf))) return rc;
             int64_t m0_all;
             uint64_t nbits_all;
             tx_bit_range(first_sample, ntotal, &m0_all, &nbits_all);           // (m0_all == m0: the same first sample)
             bits_on = cfg->bit_en && nbits_all;
             if ((rc = make_bits(h->stage_slot ^ 1, nbits_all))) return rc;     // (the slot produce_planes takes next)
             int slot = 0;
-            if ((rc = produce_planes(h, L, nlanes, nullptr, from_pf, &slot))) return rc;
+            // (the small-footprint placement of the noise kernel: the transmitter is bound by the kernel's guests -- a shaping
+            // mover per call and the next kernel's seeding -- and beside this placement they run at the same time)
+            if ((rc = produce_planes(h, L, nlanes, nullptr, from_pf, &slot, true))) return rc;
             if ((rc = deliver_tx(slot, 0, L, G, nlanes))) return rc;
             if (ahead) {
                 bbb_lutopt::Ahead &a = h->ahead;
@@ -1437,7 +1460,7 @@ static int tx_stream_hint(bbb_tx_stream *s) {
     if (!s->cfg.noise_en) return BBB_OK;
     const uint64_t step = s->cfg.warmup + s->pos;
     if (step < s->pos || step + s->n < step) return BBB_OK;
-    return bbb_awgn_prefetch(s->h, s->n, step);
+    return awgn_prefetch(s->h, s->n, step, true);
 }
 
 int bbb_tx_stream_open(bbb_lutopt *h, const bbb_tx_cfg *cfg, uint64_t nsamples_per_call, uint64_t first_sample, bbb_tx_stream **out) {

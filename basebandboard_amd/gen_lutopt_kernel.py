@@ -480,10 +480,9 @@ def generate(n, taps):
             emit(f"#define LUTOPT{n}_NPARKED{S} {len(parked)}")
             emit(f"static const uint16_t LUTOPT{n}_PARKED{S}[{len(parked)}] = {{{','.join(map(str, parked))}}};")
             emit(f"#define LUTOPT{n}_FOR_PARKED{S}(F) " + " ".join(f"F({p})" for p in parked))
-            if not suffix:
-                words = [sum(1 << (p & 31) for p in parked if p >> 5 == w) for w in range(n // 32)]
-                emit(f"static constexpr uint32_t LUTOPT{n}_PARKED_MASK[{n // 32}] = {{{','.join(hex(w) + 'u' for w in words)}}};")
-                emit(f"static constexpr bool lutopt{n}_is_parked(int p) {{ return (LUTOPT{n}_PARKED_MASK[p >> 5] >> (p & 31)) & 1u; }}")
+            words = [sum(1 << (p & 31) for p in parked if p >> 5 == w) for w in range(n // 32)]
+            emit(f"static constexpr uint32_t LUTOPT{n}_PARKED{S}_MASK[{n // 32}] = {{{','.join(hex(w) + 'u' for w in words)}}};")
+            emit(f"static constexpr bool lutopt{n}{suffix}_is_parked(int p) {{ return (LUTOPT{n}_PARKED{S}_MASK[p >> 5] >> (p & 31)) & 1u; }}")
             emit(f"static __device__ __forceinline__ void lutopt{n}_step_parked{suffix}(const uint32_t (&a)[{n}], const uint32_t (&pa)[{n}], uint32_t (&b)[{n}], uint32_t (&pb)[{n}], uint32_t (&cnt)[{logn}])")
             emit("{")
             out.extend(e.out)
