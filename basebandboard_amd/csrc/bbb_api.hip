@@ -526,7 +526,11 @@ int awgn_fill(bbb_lutopt *h, void *dst, int elem_size, uint64_t nsamples, uint64
         partition(h, ntotal, 16, &L, &G, &nlanes);
         if (L > 0xffffff00ull) return fail(BBB_EINVAL, "nsamples too large for one call (segment length must fit 32 bits): split it");
     }
-    const uint64_t seed_step = first_step;
+    // At one read per sample kernel the noise stream is bound by the kernel's guests (mover, then seeding: together longer than
+    // the kernel): it takes the small form of the kernel, beside which they run at the same time, and that form is given the
+    // state OF its first sample.  With two and more reads per kernel the stream is bound by the kernel: the other form.
+    const bool small_form = staged && h->staged_level == 1;
+    const uint64_t seed_step = first_step + (small_form ? 1 : 0);
     // (a fill that will take the announced start states does not depend on the previous sample kernel: see begin_op)
     const bool takes_prefetch = fast256 && h->pf.valid && h->pf.first == seed_step && h->pf.L == L && h->pf.G == G;
     int rc = begin_op(h, staged, staged && takes_prefetch);
@@ -541,7 +545,7 @@ int awgn_fill(bbb_lutopt *h, void *dst, int elem_size, uint64_t nsamples, uint64
     if (rc) return rc;
     if (staged) {
         int slot = 0;
-        rc = produce_planes(h, L, nlanes, h->profiling ? &ev : nullptr, from_pf, &slot);
+        rc = produce_planes(h, L, nlanes, h->profiling ? &ev : nullptr, from_pf, &slot, small_form);
         if (!rc) rc = deliver_i8(h, slot, dst, 0, nsamples, L, G, nlanes);
         if (h->profiling) h->prof_pending.push_back(ev);
         if (!rc && ahead) {
@@ -931,13 +935,14 @@ int bbb_lutopt_state_at(bbb_lutopt *h, uint64_t nsteps, uint64_t *state_words) {
     return BBB_OK;
 }
 
-// for_tx: the announced fill is the transmitter's on a staged handle (its noise kernel takes the state OF its first sample)
+// for_tx: the announced fill will run the SMALL form of the sample kernel (the transmitter's, and the noise stream's at one read
+// per kernel), which takes the state OF its first sample
 static int awgn_prefetch(bbb_lutopt *h, uint64_t nsamples, uint64_t first_step, bool for_tx);
 
 int bbb_awgn_prefetch(bbb_lutopt *h, uint64_t nsamples, uint64_t first_step) {
     // (which kind of fill comes next is not known here: the kind of the last staged one is assumed; a wrong guess only means
     // that the fill seeds for itself)
-    return awgn_prefetch(h, nsamples, first_step, h && h->last_staged_small);
+    return awgn_prefetch(h, nsamples, first_step, h && (h->staged_level == 1 || h->last_staged_small));
 }
 
 static int awgn_prefetch(bbb_lutopt *h, uint64_t nsamples, uint64_t first_step, bool for_tx) {
