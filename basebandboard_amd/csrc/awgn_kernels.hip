@@ -514,6 +514,9 @@ awgn256_planes_kernel(const uint32_t *__restrict planes, u32x4 *__restrict stage
 #endif
     uint32_t a[256], b[256], pa[256], pb[256], cnt[8];
     if constexpr (SMALL) {
+#ifdef BBB_SMALL_THROTTLE
+        asm volatile("" ::: BBB_SMALL_THROTTLE);      // (experiments: the small form with a chosen register footprint)
+#endif
         // (the parked planes straight into their AGPRs; scalar base per plane + ONE 32-bit lane offset)
         const uint32_t voff = (uint32_t)LG * 4u;
 #define BBB_PLANE(p) (*reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(planes + (size_t)(p) * nlanes) + (unsigned long long)voff))

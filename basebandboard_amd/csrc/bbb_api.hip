@@ -529,7 +529,7 @@ int awgn_fill(bbb_lutopt *h, void *dst, int elem_size, uint64_t nsamples, uint64
     // At one read per sample kernel the noise stream is bound by the kernel's guests (mover, then seeding: together longer than
     // the kernel): it takes the small form of the kernel, beside which they run at the same time, and that form is given the
     // state OF its first sample.  With two and more reads per kernel the stream is bound by the kernel: the other form.
-    const bool small_form = staged && h->staged_level == 1;
+    const bool small_form = staged && (h->staged_level == 1 || env_knob("BBB_EXP_NOISE_SMALL", 0));
     const uint64_t seed_step = first_step + (small_form ? 1 : 0);
     // (a fill that will take the announced start states does not depend on the previous sample kernel: see begin_op)
     const bool takes_prefetch = fast256 && h->pf.valid && h->pf.first == seed_step && h->pf.L == L && h->pf.G == G;
@@ -942,7 +942,7 @@ static int awgn_prefetch(bbb_lutopt *h, uint64_t nsamples, uint64_t first_step, 
 int bbb_awgn_prefetch(bbb_lutopt *h, uint64_t nsamples, uint64_t first_step) {
     // (which kind of fill comes next is not known here: the kind of the last staged one is assumed; a wrong guess only means
     // that the fill seeds for itself)
-    return awgn_prefetch(h, nsamples, first_step, h && (h->staged_level == 1 || h->last_staged_small));
+    return awgn_prefetch(h, nsamples, first_step, h && (h->staged_level == 1 || h->last_staged_small || env_knob("BBB_EXP_NOISE_SMALL", 0)));
 }
 
 static int awgn_prefetch(bbb_lutopt *h, uint64_t nsamples, uint64_t first_step, bool for_tx) {

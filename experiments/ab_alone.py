@@ -8,7 +8,8 @@ if os.environ.get("AB_LIB"):
 import basebandboard_amd as bbb
 N = 1_000_000_000
 buf = torch.empty(N, dtype=torch.int8, device="cuda")
-u = bbb.LUTOPT.shipped(256); u.set_staged(True); g = bbb.CLTGRNG(u)
+LEVEL = int(os.environ.get('AB_LEVEL', '2'))      # 2: the form the noise stream's default level runs (one kernel per two fills)
+u = bbb.LUTOPT.shipped(256); u.set_staged(True, look_ahead=LEVEL if LEVEL >= 2 else False); g = bbb.CLTGRNG(u)
 for s in range(60):                       # clock ramp
     g.generate(N, first_step=16 + s * N, out=buf)
 torch.cuda.synchronize()
@@ -17,4 +18,4 @@ for s in range(60, 100):
     g.generate(N, first_step=16 + s * N, out=buf)
     torch.cuda.synchronize()
 seed_ms, kern_ms, calls = u.profile_read(); mv_ms, movers = u.profile_read_mover()
-print(f"{os.environ.get('AB_LIB', 'product')}: alone: sample kernel {kern_ms / calls:.4f} ms x {calls}, seeding {seed_ms / calls:.4f}, mover {mv_ms / movers:.4f} ms x {movers}", flush=True)
+print(f"{os.environ.get('AB_LIB', 'product')}: alone (level {LEVEL}): sample kernel {kern_ms / calls / max(LEVEL, 1):.4f} ms per 1e9 x {calls}, seeding {seed_ms / calls:.4f}, mover {mv_ms / movers:.4f} ms x {movers}", flush=True)
