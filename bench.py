@@ -622,7 +622,7 @@ def main():
                                if staged else "bbb_awgn_fill_i8 + bbb_awgn_prefetch, one kernel",
                        "clock_ramp_steps": ramp_steps,
                        "clock_ramp_note": "untimed steps of the same workload in front of the W warm-up steps: the clock governor needs ~50 ms of load "
-                                          "to leave its idle state (profiles/r03_ramp_clock_per_launch.log); extra.cold_start is the same K steps straight from idle",
+                                          "to leave its idle state (profiles/r03_ramp_clock_per_launch.log); extra.cold_start is 20 of the same steps straight from idle",
                        "verified_vs_oracle": verified},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
