@@ -158,3 +158,15 @@ def test_waveform_stream_refuses_a_second_stream_and_restores_the_level(gpu):
     with gpu.CLTGRNG(x.urng).stream(BIG) as s2:      # the handle is free again
         s2.next()
     torch.cuda.synchronize()
+
+
+def test_waveform_stream_without_noise(gpu):
+    """noise_en = 0: the stream is the shaper's output (nothing is staged, no hint is made): equal to the plain calls."""
+    n = 3_000_003
+    x = gpu.TX(31, 1, 0, 16, 0, 8)
+    y = gpu.TX(31, 1, 0, 16, 0, 8)
+    with x.stream(n, first_sample=5) as st:
+        a, b = st.next(), st.read(1001)
+        assert st.tell() == 5 + n + 1001
+    torch.cuda.synchronize()
+    assert torch.equal(a, y.generate(n, first_sample=5)) and torch.equal(b, y.generate(1001, first_sample=5 + n))
