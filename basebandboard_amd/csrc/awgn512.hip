@@ -84,16 +84,21 @@ awgn512p_kernel(const uint32_t *__restrict planes, int16_t *__restrict dst, unsi
     const unsigned lane = threadIdx.x;
     const unsigned long long wave = blockIdx.x;
     const unsigned long long LG = wave * 64 + lane;
-    uint32_t a[256], b[256], c0[9], c1[9];
+    // (the state registers in LUTOPT512_PARKED travel in AGPRs between their birth and their first reader of the next step,
+    // placed by the generator: gen_lutopt_kernel.py, Packed512Emitter)
+    uint32_t a[256], b[256], pa[256], pb[256], c0[9], c1[9];
 #pragma unroll
-    for (int p = 0; p < 256; p++) a[p] = planes[(size_t)p * nlanes + LG];
+    for (int p = 0; p < 256; p++) {
+        const uint32_t v = planes[(size_t)p * nlanes + LG];
+        if (lutopt512_is_parked(p)) BBB_ACC_WRITE(pa[p], v); else a[p] = v;
+    }
     const unsigned rounds = L / 8;
 #pragma unroll 1
     for (unsigned r = 0; r < rounds; r++) {
 #pragma unroll 1
         for (unsigned u = 0; u < 4; u++) {
-            lutopt512p_step_new(a, b, c0);       // the step yields the sample of the NEW state
-            lutopt512p_step_new(b, a, c1);
+            lutopt512p_step_new_parked(a, pa, b, pb, c0);       // the step yields the sample of the NEW state
+            lutopt512p_step_new_parked(b, pb, a, pa, c1);
             uint32_t s0[9], s1[9], m[16];
             add_halves(c0, s0);
             add_halves(c1, s1);

@@ -303,12 +303,25 @@ class Packed512Emitter:
     of the result; a missing tap is the zero byte selector), then V_BITOP3 / V_XOR as before.  The counter runs on the
     NEW state: 9 planes per half (0..256), the kernel adds the halves."""
 
-    def __init__(self, taps):
+    def __init__(self, taps, parked=()):
+        """parked: packed registers whose old value arrives in pa[] (AGPR) and whose new value leaves in pb[] (as in
+        StepEmitter: BBB_ACC_READ at the first reader, BBB_ACC_WRITE at birth)"""
         assert len(taps) == 512
         self.taps = taps
         self.out, self.nops, self.tmp_id = [], 0, 0
         self.levels = [[] for _ in range(10)]
         self.nlev = 9
+        self.parked, self.loaded, self.nmoves = set(parked), {}, 0
+
+    def old(self, r):
+        if r not in self.parked:
+            return f"a[{r}]"
+        if r not in self.loaded:
+            v = self.tmp()
+            self.emit(f"  uint32_t {v}; BBB_ACC_READ({v}, pa[{r}]);")
+            self.nmoves += 1
+            self.loaded[r] = v
+        return self.loaded[r]
 
     def emit(self, s):
         self.out.append(s)
@@ -354,8 +367,8 @@ class Packed512Emitter:
                 xb = [x[1], x[1] + 1] if x else [0x0c, 0x0c]
                 yb = [4 + y[1], 5 + y[1]] if y else [0x0c, 0x0c]
                 sel = xb[0] | xb[1] << 8 | yb[0] << 16 | yb[1] << 24
-                xr = f"a[{x[0]}]" if x else "0u"
-                yr = f"a[{y[0]}]" if y else "0u"
+                xr = self.old(x[0]) if x else "0u"
+                yr = self.old(y[0]) if y else "0u"
                 if x and y and x[0] == y[0] and sel == 0x07060100:
                     terms.append(xr)                      # both halves already in place
                     continue
@@ -369,14 +382,20 @@ class Packed512Emitter:
                 self.emit(f"  const uint32_t {v} = __builtin_amdgcn_bitop3_b32({x3[0]}, {x3[1]}, {x3[2]}, 0x96);")
                 self.nops += 1
                 terms.insert(0, v)
+            dst, decl = f"b[{p}]", ""
+            if p in self.parked:
+                dst, decl = self.tmp(), "const uint32_t "
             if len(terms) == 3:
-                self.emit(f"  b[{p}] = __builtin_amdgcn_bitop3_b32({terms[0]}, {terms[1]}, {terms[2]}, 0x96);")
+                self.emit(f"  {decl}{dst} = __builtin_amdgcn_bitop3_b32({terms[0]}, {terms[1]}, {terms[2]}, 0x96);")
             elif len(terms) == 2:
-                self.emit(f"  b[{p}] = {terms[0]} ^ {terms[1]};")
+                self.emit(f"  {decl}{dst} = {terms[0]} ^ {terms[1]};")
             else:
-                self.emit(f"  b[{p}] = {terms[0]};")
+                self.emit(f"  {decl}{dst} = {terms[0]};")
             self.nops += 1
-            self.push(0, (f"b[{p}]", bin(p).count("1") & 1))
+            if p in self.parked:
+                self.emit(f"  BBB_ACC_WRITE(pb[{p}], {dst});")
+                self.nmoves += 1
+            self.push(0, (dst, bin(p).count("1") & 1))
         for lev in range(self.nlev):
             lv = self.levels[lev]
             while len(lv) > 1:
@@ -414,6 +433,27 @@ def generate_packed512(taps):
     out.extend(e.out)
     emit("}")
     emit(f"// {e.nops} VALU ops per step for 16 samples per lane")
+    # the same step with the registers of LUTOPT512_PARKED travelling in AGPRs (pa / pb), placed by the generator instead of
+    # hipcc's spilling: at most PACKED512_BUDGET of the 256 state registers are VGPR-resident at any row
+    rt = e.reg_taps()
+    parked = sorted(parking_set(256, rt, order, PACKED512_BUDGET))
+    ep = Packed512Emitter(taps, parked)
+    ep.body(order)
+    emit("#ifndef BBB_ACC_WRITE   // (a host build of this text defines them as plain assignments)")
+    emit('#define BBB_ACC_WRITE(dst, src) asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(dst) : "v"(src))')
+    emit('#define BBB_ACC_READ(dst, src) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(dst) : "a"(src))')
+    emit("#endif")
+    emit(f"#define LUTOPT512_NPARKED {len(parked)}")
+    emit(f"static const uint16_t LUTOPT512_PARKED[{len(parked)}] = {{{','.join(map(str, parked))}}};")
+    emit("#define LUTOPT512_FOR_PARKED(F) " + " ".join(f"F({q})" for q in parked))
+    words = [sum(1 << (q & 31) for q in parked if q >> 5 == w) for w in range(8)]
+    emit(f"static constexpr uint32_t LUTOPT512_PARKED_MASK[8] = {{{','.join(hex(w) + 'u' for w in words)}}};")
+    emit("static constexpr bool lutopt512_is_parked(int p) { return (LUTOPT512_PARKED_MASK[p >> 5] >> (p & 31)) & 1u; }")
+    emit("static __device__ __forceinline__ void lutopt512p_step_new_parked(const uint32_t (&a)[256], const uint32_t (&pa)[256], uint32_t (&b)[256], uint32_t (&pb)[256], uint32_t (&cnt)[9])")
+    emit("{")
+    out.extend(ep.out)
+    emit("}")
+    emit(f"// {ep.nops} VALU ops + {ep.nmoves} AGPR moves per step (at most {PACKED512_BUDGET} state registers in VGPRs)")
     emit(f"static const uint16_t LUTOPT512_NTAPS[512] = {{{','.join(str(len(t)) for t in taps)}}};")
     emit(f"static const uint16_t LUTOPT512_TAPS[{sum(len(t) for t in taps)}] = {{{flat}}};")
     return "\n".join(out) + "\n", e.nops
@@ -426,6 +466,7 @@ def generate_packed512(taps):
 # (budget -> registers / VALU per step: 180 -> 436 / 1185, 200 -> 422 / 1120, 220 -> 432 / 1080, 230 -> 434 / 1060,
 # 240 -> 460 / 1054: the guests beside the kernel need 72 of the 512)
 PARK_VARIANTS = (("", 180), ("_hi", 230))
+PACKED512_BUDGET = 230        # the packed n512 kernel: state registers resident in VGPRs (its counters and output stage need the rest)
 
 
 def generate(n, taps):

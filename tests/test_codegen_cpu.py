@@ -149,6 +149,8 @@ HARNESS512 = r"""
 #include <cstring>
 #define __device__
 #define __forceinline__ inline
+#define BBB_ACC_WRITE(dst, src) ((dst) = (src))
+#define BBB_ACC_READ(dst, src) ((dst) = (src))
 static inline uint32_t __builtin_amdgcn_bitop3_b32(uint32_t a, uint32_t b, uint32_t c, unsigned tt) {
   uint32_t r = 0;
   for (int i = 0; i < 8; i++) if ((tt >> i) & 1) { uint32_t m = ~0u; m &= (i & 4) ? a : ~a; m &= (i & 2) ? b : ~b; m &= (i & 1) ? c : ~c; r |= m; }
@@ -164,6 +166,15 @@ static inline uint32_t __builtin_amdgcn_perm(uint32_t hi, uint32_t lo, uint32_t 
 #include "GEN_INC"
 extern "C" void step_new(const uint32_t* a, uint32_t* b, uint32_t* cnt) {
   uint32_t A[256], B[256], Cn[9]; memcpy(A, a, sizeof A); lutopt512p_step_new(A, B, Cn); memcpy(b, B, sizeof B); memcpy(cnt, Cn, sizeof Cn);
+}
+// the generator-placed form: the registers in LUTOPT512_PARKED travel in pa / pb
+extern "C" void step_new_parked(const uint32_t* a, uint32_t* b, uint32_t* cnt) {
+  uint32_t A[256], PA[256], B[256], PB[256], Cn[9];
+  memcpy(A, a, sizeof A); memcpy(PA, a, sizeof PA);
+  for (int i = 0; i < LUTOPT512_NPARKED; i++) A[LUTOPT512_PARKED[i]] = 0xdeadbeefu;      // must not be read
+  lutopt512p_step_new_parked(A, PA, B, PB, Cn);
+  for (int i = 0; i < LUTOPT512_NPARKED; i++) B[LUTOPT512_PARKED[i]] = PB[LUTOPT512_PARKED[i]];
+  memcpy(b, B, sizeof B); memcpy(cnt, Cn, sizeof Cn);
 }
 """
 
@@ -199,6 +210,9 @@ def test_packed_n512_network_matches_oracle(oracle, tmp_path):
     for _ in range(10):
         b, cnt = np.zeros(256, dtype=np.uint32), np.zeros(9, dtype=np.uint32)
         lib.step_new(P(a), P(b), P(cnt))
+        bp, cntp = np.zeros(256, dtype=np.uint32), np.zeros(9, dtype=np.uint32)
+        lib.step_new_parked(P(a), P(bp), P(cntp))             # the generator-placed form: same state, same counters
+        assert np.array_equal(b, bp) and np.array_equal(cnt, cntp)
         states = [m.step_int(s) for s in states]
         assert np.array_equal(b, pack(states))
         for g in range(16):
