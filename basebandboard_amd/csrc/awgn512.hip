@@ -3,10 +3,11 @@
 // CLTGRNG rng.py:58-108 (9-bit signed output for n = 512: rng.py:78).
 //
 // A 512-plane state does not fit a lane's 512 registers next to its successor, so the state is PACKED: 16 generators
-// per lane, register p = plane p in bits 0..15 | plane 256 + (p ^ 1) in bits 16..31.  tools/gen_lutopt_kernel.py
+// per lane, register p = plane p in bits 0..15 | plane 256 + (p ^ 1) in bits 16..31.  basebandboard_amd/gen_lutopt_kernel.py
 // (Packed512Emitter) emits the step: per new register the i-th taps of its two rows are brought into one word by one
 // V_PERM_B32, then XORed; the carry-save counter runs on both halves at once (9 planes each, same sign in both halves
-// by the p ^ 1 pairing).  2018 VALU ops per 16 samples per lane (n256: 918 per 32).
+// by the p ^ 1 pairing).  2018 VALU ops per 16 samples per lane (n256: 918 per 32) + 256 AGPR moves: the generator parks
+// the state registers that have no room in the 256 VGPRs between their birth and their first reader (budget 230, as for n256).
 //
 // Per pair of steps: the halves' counts are added bit-sliced (T = number of +1 terms, sample = T - 256 as 9 bits
 // signed, sign-extended to 16), the two steps merged into one word per plane (V_PERM), a 16 x 16 bit transpose on both
