@@ -516,8 +516,9 @@ def main():
                                 "one_kernel_form_2p29_per_call": {"gsample_s": round((1 << 29) / tx_ms_1k / 1e6, 1), "ms_per_call": round(tx_ms_1k, 4)},
                                 "note": "bbb_tx_fill_i16; the one-kernel form has the shaper fused into the sample kernel's round end"}
         r = hbm("awgn256_planes_kernel + unplane_kernel<true> (whole bbb_tx_stream_next call)", 2.0 * ntx, tx_ms, "2 B per sample delivered (4 B of HBM traffic: count planes written and read, int16 output written)")
-        r["true_bound"] = ("the guests of the noise kernel run one at a time (a SIMD has registers for its wave and ONE guest wave): per noise kernel the shaping movers "
-                           "(3 GB of traffic each, 0.75 ms alone, 1.0-1.4 ms beside the kernel) and the next kernel's seeding (0.14 ms alone, 0.5 beside) must fit into its 1.0 ms per 1e9 samples")
+        r["true_bound"] = ("the noise kernel's guests: a shaping mover per call (3 GB of traffic each: 0.75 ms alone, 1.0-1.3 ms beside the kernel) and the next kernel's "
+                           "seeding (0.14 ms alone, 0.5 beside); the transmitter's noise kernel is the 344-register form, beside which both run at the same time "
+                           "(DESIGN.md 3.4, profiles/r03_small_footprint_ab.log)")
         other.append(r)
         # PRBSShaper.x alone (noise off): PRBS fill + table rows, 2 B per sample written
         txs = bbb.TX(31, 1, 0, 16, 0, 8, device=local_rank)
