@@ -209,8 +209,8 @@ int bbb_prbs_detector_run(int k, const uint8_t *bits_dev, uint64_t nstreams, uin
  * again from that state until the chain is consistent, so the outputs equal the serial machine's
  * bit for bit (prbs.py:61-99).  (A re-run stops where its state meets the speculative run's: from there on the chunk
  * is what the first pass made of it.)  *stats is a host result (the call synchronises the stream).  The call's device
- * workspace (72 bytes per chunk: 22 MB at 1e10 bits) and a pinned read-back buffer stay allocated between calls, one
- * set per device and concurrent call. */
+ * workspace (72 bytes per chunk: 22 MB at 1e10 bits; kept up to 256 MiB) and a pinned read-back buffer stay allocated
+ * between calls, one set per device and concurrent call. */
 typedef struct {
     uint64_t bits;            /* clocks processed */
     uint64_t errors;          /* clocks with err == 1 and reload == 0 (what the reference test compares, prbs.py:152-163) */
