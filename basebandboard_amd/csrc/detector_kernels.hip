@@ -455,7 +455,7 @@ static int det_ws_acquire(size_t need, int *slot) {
 static void det_ws_release(int slot) {
     std::lock_guard<std::mutex> g(g_det_ws_mu);
     DetWorkspace &w = g_det_ws[slot];
-    if (w.cap > (size_t)256 << 20) {        // (a very long stream's workspace is not kept: 256 MiB = 3.7e12 bits at the default chunking)
+    if (w.cap > (size_t)256 << 20) {        // (a very long stream's workspace is not kept: 256 MiB = 1.2e11 bits at the default chunking)
         (void)hipFree(w.d);
         w.d = nullptr; w.cap = 0;
     }
