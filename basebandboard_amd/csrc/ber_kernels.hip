@@ -24,5 +24,8 @@
 
 #include <cstdlib>
 
+#ifndef BBB_BER_PART
+#define BBB_BER_PART 0
+#endif
 #include "ber_kernels_impl.hpp"
 

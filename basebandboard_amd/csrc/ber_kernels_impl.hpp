@@ -202,6 +202,176 @@ ber256_kernel(const uint32_t *__restrict planes, const uint32_t *__restrict prbs
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The fused trial kernel, PLANES generation (round 4).  ber256_kernel above (kept for the A/B runs of the experiments build)
+// is the round-1 design: the budget-180 step (242 AGPR moves), eight steps of count planes staged through LDS, a comparator
+// loop of its own per round, the PRBS planes in a circular LDS buffer with scalar index arithmetic: 1368 issued VALU
+// instructions per step and wave (SQ_INSTS_VALU, profiles/r04_ber_old_pmc.json) where the sample kernel of the stream
+// needs 1061.  This one is the sample kernel's loop -- lutopt256_step_parked_ber, no round end, no LDS staging -- with the
+// comparators run on the count planes while they are still in registers:
+//   X[q] = (T[q] ^ bit) & valid                      8 V_BITOP3 per step (T[7] = ~cnt[7]: folded into the truth table)
+//   per setting  ge = (bit | eq) & valid             1
+//                ge = tm[q] ? X[q] & ge : X[q] | ge  8   (LSB-first scan of [X >= thr]; tm[q] = bit q of thr as a 0 / ~0 SCALAR)
+//                nerr += popcount(ge)                1   (V_BCNT_U32_B32 accumulates)
+// The scalar masks of twelve settings (9 each) do not fit the SGPR file beside the loop's own scalars, and hipcc spills
+// scalars to VGPR lanes (a V_READLANE per use).  They are therefore STREAMED: the kernel-argument segment holds the
+// table, each step re-reads it with scalar loads (s_load_dwordx8 + s_load_dword per setting, ~6 cycles each for the one
+// wave of a SIMD: experiments/ubench6.hip) behind an opaque pointer that keeps hipcc from hoisting them.
+// PRBS: b[t] = b[t-k] ^ b[t-tap] (prbs.py:32-35) on a time-indexed ring in LDS, slot t & 31, every slot written twice
+// (s and s + 32) so that the reads of one iteration -- slots u + 32 - k, u + 33 - k, u + 32 - tap, u + 33 - tap,
+// u = t & 31 even -- never wrap: two ds_read2st64_b32, two XOR, two ds_write2st64_b32 per two steps.
+// The bit counters are not counted: a trial's number of bits is known to the host (wave 0 adds it).
+// ---------------------------------------------------------------------------------------------
+struct BerMasks { uint32_t m[kMaxCfg][32]; };   // fast: [c][0..7] tm, [c][8] eq; pair: [c][0..7] thr0, [8..15] thr1, [16] inv0, [17] inv1;
+                                                // general (one setting): [bv * 4 + i][0..7] tm, [..][8] enable, m[8][bv] inv
+struct TrialF {
+    int32_t k, tap, ncfg;
+    uint32_t L, last_len;
+    unsigned long long G, nbits;
+};
+
+template <int MODE, int NC>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+ber256_fused_kernel(BerMasks mk, const uint32_t *__restrict planes, const uint32_t *__restrict prbs_planes, TrialF tk, unsigned nlanes,
+                    unsigned long long *__restrict counters) {
+    __shared__ uint32_t ring[64 * 64];
+    const unsigned lane = threadIdx.x;
+    const unsigned long long wave = blockIdx.x;
+    const unsigned long long LG = wave * 64 + lane;
+    __builtin_amdgcn_s_setprio(3);
+
+    uint32_t a[256], b[256], pa[256], pb[256], cnt[8];
+#pragma unroll
+    for (int p = 0; p < 256; p++) b[p] = planes[(size_t)p * nlanes + LG];
+    lutopt256_advance(b, a);
+#define BBB_PARK(p) BBB_ACC_WRITE(pa[p], a[p]);
+    LUTOPT256_FOR_PARKED_BER(BBB_PARK)
+#undef BBB_PARK
+    // ring slot 31 - i (and its copy 63 - i) = b[-1 - i] = LFSR state bit i (prbs.py:34-35: the new bit enters at position 0)
+    for (int i = 0; i < tk.k; i++) {
+        const uint32_t v = prbs_planes[(size_t)i * nlanes + LG];
+        ring[(31 - i) * 64 + lane] = v;
+        ring[(63 - i) * 64 + lane] = v;
+    }
+    // which of this lane's 32 generators exist, and which one is the (possibly short) last one
+    uint32_t vm_all = 0, vm_last = 0;
+    for (unsigned j = 0; j < 32; j++) {
+        const unsigned long long g = gen_index(wave, lane, j);
+        if (g < tk.G) vm_all |= 1u << j;
+        if (g + 1 == tk.G) vm_last |= 1u << j;
+    }
+    uint32_t nerr[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) nerr[c] = 0;
+    const unsigned ka = (unsigned)(32 - tk.k) * 64, ta = (unsigned)(32 - tk.tap) * 64;
+
+    auto compare = [&](const uint32_t pbit, const uint32_t valid) {
+        // the table is the FIRST kernel argument: offset 0 of the kernel-argument segment (constant address space: scalar loads)
+        typedef const uint32_t __attribute__((address_space(4))) *kptr_t;
+        kptr_t mp = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(mp));            // (opaque: the scalar loads below stay inside the step)
+        if constexpr (MODE == kBerFast) {
+            uint32_t X[8];
+#pragma unroll
+            for (int q = 0; q < 7; q++) X[q] = __builtin_amdgcn_bitop3_b32(cnt[q], pbit, valid, 0x28);     // (a ^ b) & c
+            X[7] = __builtin_amdgcn_bitop3_b32(cnt[7], pbit, valid, 0x82);                                 // ~(a ^ b) & c
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                uint32_t ge = __builtin_amdgcn_bitop3_b32(pbit, mp[c * 32 + 8], valid, 0xA8);             // (a | b) & c
+#pragma unroll
+                for (int q = 0; q < 8; q++) ge = __builtin_amdgcn_bitop3_b32(X[q], ge, mp[c * 32 + q], 0xD4);
+                nerr[c] += __builtin_popcount(ge);
+            }
+        } else if constexpr (MODE == kBerPair) {
+            uint32_t T[8];
+#pragma unroll
+            for (int q = 0; q < 7; q++) T[q] = cnt[q];
+            T[7] = ~cnt[7];
+            const uint32_t pv1 = pbit & valid, pv0 = ~pbit & valid;
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                uint32_t g0 = ~0u, g1 = ~0u;
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    g0 = __builtin_amdgcn_bitop3_b32(T[q], g0, mp[c * 32 + q], 0xD4);
+                    g1 = __builtin_amdgcn_bitop3_b32(T[q], g1, mp[c * 32 + 8 + q], 0xD4);
+                }
+                g0 ^= mp[c * 32 + 16];
+                g1 ^= mp[c * 32 + 17];
+                nerr[c] += __builtin_popcount((pv1 & g1) | (pv0 & g0));
+            }
+        } else {
+            uint32_t T[8];
+#pragma unroll
+            for (int q = 0; q < 7; q++) T[q] = cnt[q];
+            T[7] = ~cnt[7];
+            uint32_t e[2] = {mp[8 * 32 + 0], mp[8 * 32 + 1]};
+#pragma unroll
+            for (int bv = 0; bv < 2; bv++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    uint32_t g = ~0u;
+#pragma unroll
+                    for (int q = 0; q < 8; q++) g = __builtin_amdgcn_bitop3_b32(T[q], g, mp[(bv * 4 + i) * 32 + q], 0xD4);
+                    e[bv] ^= g & mp[(bv * 4 + i) * 32 + 8];
+                }
+            nerr[0] += __builtin_popcount(((pbit & e[1]) | (~pbit & e[0])) & valid);
+        }
+    };
+
+#pragma unroll 1
+    for (unsigned t = 0; t < tk.L; t += 2) {
+        const unsigned u = (t & 31u) * 64 + lane;
+        const uint32_t x0 = ring[u + ka], x1 = ring[u + ka + 64], y0 = ring[u + ta], y1 = ring[u + ta + 64];
+        const uint32_t p0 = x0 ^ y0, p1 = x1 ^ y1;
+        ring[u] = p0; ring[u + 64] = p1;
+        ring[u + 32 * 64] = p0; ring[u + 33 * 64] = p1;
+        const uint32_t s0 = t >= tk.last_len ? ~0u : 0u, s1 = t + 1 >= tk.last_len ? ~0u : 0u;
+        lutopt256_step_parked_ber(a, pa, b, pb, cnt);
+        compare(p0, __builtin_amdgcn_bitop3_b32(vm_all, vm_last, s0, 0x70));      // a & ~(b & c)
+        lutopt256_step_parked_ber(b, pb, a, pa, cnt);
+        compare(p1, __builtin_amdgcn_bitop3_b32(vm_all, vm_last, s1, 0x70));
+    }
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        unsigned long long e64 = nerr[c];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) e64 += __shfl_xor(e64, off, 64);
+        if (lane == 0 && c < tk.ncfg) {
+            if (wave == 0) atomicAdd(&counters[2 * c], tk.nbits);
+            if (e64) atomicAdd(&counters[2 * c + 1], e64);
+        }
+    }
+    (void)mk;
+}
+
+// Host side of the fused kernel.  The instances are spread over several translation units (ber_kernels*.hip: hipcc spends
+// about a minute on each) and reached through ber_fused_go<MODE, NC>; a custom-matrix library (custom_fill_template.hip, ONE
+// unit, built at run time) instantiates a shorter list.
+template <int MODE, int NC>
+void ber_fused_go(const BerMasks &mk, const uint32_t *d_planes, const uint32_t *d_prbs_planes, const TrialF &tf, unsigned nlanes,
+                  unsigned long long *d_counters, hipStream_t st);
+#define BBB_BER_DEFINE_GO(MODE, NC)                                                                                              \
+    template <>                                                                                                                  \
+    void ber_fused_go<MODE, NC>(const BerMasks &mk, const uint32_t *d_planes, const uint32_t *d_prbs_planes, const TrialF &tf,   \
+                                unsigned nlanes, unsigned long long *d_counters, hipStream_t st) {                               \
+        hipLaunchKernelGGL((ber256_fused_kernel<MODE, NC>), dim3(nlanes / 64), dim3(64), 0, st, mk, d_planes, d_prbs_planes, tf, \
+                           nlanes, d_counters);                                                                                  \
+    }
+
+#define BBB_BER_DECLARE_GO(MODE, NC)                                                                                              \
+    template <>                                                                                                                   \
+    void ber_fused_go<MODE, NC>(const BerMasks &mk, const uint32_t *d_planes, const uint32_t *d_prbs_planes, const TrialF &tf,    \
+                                unsigned nlanes, unsigned long long *d_counters, hipStream_t st);
+BBB_BER_DECLARE_GO(kBerFast, 1) BBB_BER_DECLARE_GO(kBerFast, 4) BBB_BER_DECLARE_GO(kBerFast, 12)
+BBB_BER_DECLARE_GO(kBerPair, 1) BBB_BER_DECLARE_GO(kBerPair, 4) BBB_BER_DECLARE_GO(kBerPair, 12) BBB_BER_DECLARE_GO(kBerGeneral, 1)
+#ifndef BBB_BER_FEW_INSTANCES
+BBB_BER_DECLARE_GO(kBerFast, 2) BBB_BER_DECLARE_GO(kBerFast, 6) BBB_BER_DECLARE_GO(kBerFast, 8) BBB_BER_DECLARE_GO(kBerFast, 10)
+BBB_BER_DECLARE_GO(kBerFast, 11)
+#endif
+
+#if BBB_BER_PART == 0
 // counters: [ncfg][2] contiguous.  All trials of the group share t[0]'s stream geometry.
 int ber256_launch(const uint32_t *d_planes, const uint32_t *d_prbs_planes, const TrialDev *t, int ncfg, unsigned nlanes,
                   unsigned long long *d_counters, hipStream_t st) {
@@ -239,19 +409,82 @@ int ber256_launch(const uint32_t *d_planes, const uint32_t *d_prbs_planes, const
         tk.strict0[c] = (int8_t)d;
     }
     static const bool no_fast = env_knob("BBB_BER_NO_FAST", 0) != 0;     // (A/B timing of the two forms; -DBBB_EXPERIMENTS only)
-    if (fast && !no_fast)
-        hipLaunchKernelGGL(ber256_kernel<kBerFast>, dim3(nlanes / 64), dim3(64), 0, st, d_planes, d_prbs_planes, tk, nlanes,
-                           d_counters);
-    else if (simple)
-        hipLaunchKernelGGL(ber256_kernel<kBerPair>, dim3(nlanes / 64), dim3(64), 0, st, d_planes, d_prbs_planes, tk, nlanes,
-                           d_counters);
-    else if (ncfg == 1)
-        hipLaunchKernelGGL(ber256_kernel<kBerGeneral>, dim3(nlanes / 64), dim3(64), 0, st, d_planes, d_prbs_planes, tk, nlanes,
-                           d_counters);
-    else
-        return fail(BBB_EINVAL, "grouped trials must be single-threshold");
+    if (!simple && ncfg != 1) return fail(BBB_EINVAL, "grouped trials must be single-threshold");
+    const int mode = fast && !no_fast ? kBerFast : simple ? kBerPair : kBerGeneral;
+#ifdef BBB_EXPERIMENTS
+    if (env_knob("BBB_BER_OLD", 0)) {        // the round-1 kernel (A/B timing and counters)
+        if (mode == kBerFast)
+            hipLaunchKernelGGL(ber256_kernel<kBerFast>, dim3(nlanes / 64), dim3(64), 0, st, d_planes, d_prbs_planes, tk, nlanes, d_counters);
+        else if (mode == kBerPair)
+            hipLaunchKernelGGL(ber256_kernel<kBerPair>, dim3(nlanes / 64), dim3(64), 0, st, d_planes, d_prbs_planes, tk, nlanes, d_counters);
+        else
+            hipLaunchKernelGGL(ber256_kernel<kBerGeneral>, dim3(nlanes / 64), dim3(64), 0, st, d_planes, d_prbs_planes, tk, nlanes, d_counters);
+        BBB_HIP(hipGetLastError());
+        return BBB_OK;
+    }
+#endif
+    // the scalar masks of the comparators: bit q of a threshold as 0 / ~0
+    BerMasks mk{};
+    auto bits = [](uint32_t *dst, int thr) {
+        for (int q = 0; q < 8; q++) dst[q] = (thr >> q) & 1 ? ~0u : 0u;
+    };
+    TrialF tf{};
+    tf.k = tk.k; tf.tap = tk.tap; tf.ncfg = ncfg; tf.L = tk.L; tf.last_len = tk.last_len; tf.G = tk.G; tf.nbits = t[0].nbits;
+    if (mode == kBerGeneral) {
+        for (int bv = 0; bv < 2; bv++) {
+            for (int i = 0; i < 4; i++)
+                if (i < tk.nthr[0][bv]) {
+                    bits(mk.m[bv * 4 + i], tk.thr[0][bv][i]);
+                    mk.m[bv * 4 + i][8] = ~0u;
+                }
+            mk.m[8][bv] = tk.inv[0][bv] ? ~0u : 0u;
+        }
+        ber_fused_go<kBerGeneral, 1>(mk, d_planes, d_prbs_planes, tf, nlanes, d_counters, st);
+    } else {
+        // (instances exist for some group sizes: the next larger one runs copies of the last setting, whose counters are never read)
+        for (int c = 0; c < kMaxCfg; c++) {
+            const int s = c < ncfg ? c : ncfg - 1;
+            if (mode == kBerFast) {
+                bits(mk.m[c], tk.thrx[s]);
+                mk.m[c][8] = tk.strict0[s] == 0 ? ~0u : 0u;
+            } else {
+                bits(mk.m[c], tk.thr[s][0][0]);
+                bits(mk.m[c] + 8, tk.thr[s][1][0]);
+                mk.m[c][16] = tk.inv[s][0] ? ~0u : 0u;
+                mk.m[c][17] = tk.inv[s][1] ? ~0u : 0u;
+            }
+        }
+#define BBB_GO(MODE, NC) ber_fused_go<MODE, NC>(mk, d_planes, d_prbs_planes, tf, nlanes, d_counters, st)
+        if (mode == kBerFast) {
+#ifdef BBB_BER_FEW_INSTANCES
+            if (ncfg <= 1) BBB_GO(kBerFast, 1); else if (ncfg <= 4) BBB_GO(kBerFast, 4); else BBB_GO(kBerFast, 12);
+#else
+            if (ncfg <= 1) BBB_GO(kBerFast, 1); else if (ncfg <= 2) BBB_GO(kBerFast, 2); else if (ncfg <= 4) BBB_GO(kBerFast, 4);
+            else if (ncfg <= 6) BBB_GO(kBerFast, 6); else if (ncfg <= 8) BBB_GO(kBerFast, 8); else if (ncfg <= 10) BBB_GO(kBerFast, 10);
+            else if (ncfg <= 11) BBB_GO(kBerFast, 11); else BBB_GO(kBerFast, 12);
+#endif
+        } else {
+            if (ncfg <= 1) BBB_GO(kBerPair, 1); else if (ncfg <= 4) BBB_GO(kBerPair, 4); else BBB_GO(kBerPair, 12);
+        }
+#undef BBB_GO
+    }
     BBB_HIP(hipGetLastError());
     return BBB_OK;
 }
+#endif   // BBB_BER_PART == 0
+
+// the instances of this translation unit
+#ifdef BBB_BER_FEW_INSTANCES
+BBB_BER_DEFINE_GO(kBerFast, 1) BBB_BER_DEFINE_GO(kBerFast, 4) BBB_BER_DEFINE_GO(kBerFast, 12)
+BBB_BER_DEFINE_GO(kBerPair, 1) BBB_BER_DEFINE_GO(kBerPair, 4) BBB_BER_DEFINE_GO(kBerPair, 12) BBB_BER_DEFINE_GO(kBerGeneral, 1)
+#elif BBB_BER_PART == 0
+BBB_BER_DEFINE_GO(kBerFast, 11) BBB_BER_DEFINE_GO(kBerFast, 1) BBB_BER_DEFINE_GO(kBerGeneral, 1)
+#elif BBB_BER_PART == 1
+BBB_BER_DEFINE_GO(kBerFast, 12) BBB_BER_DEFINE_GO(kBerFast, 2) BBB_BER_DEFINE_GO(kBerPair, 1)
+#elif BBB_BER_PART == 2
+BBB_BER_DEFINE_GO(kBerFast, 10) BBB_BER_DEFINE_GO(kBerFast, 4) BBB_BER_DEFINE_GO(kBerPair, 4)
+#elif BBB_BER_PART == 3
+BBB_BER_DEFINE_GO(kBerFast, 8) BBB_BER_DEFINE_GO(kBerFast, 6) BBB_BER_DEFINE_GO(kBerPair, 12)
+#endif
 
 }  // namespace bbb

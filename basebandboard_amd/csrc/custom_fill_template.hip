@@ -118,6 +118,9 @@ std::string &last_error() {
     return s;
 }
 }  // namespace bbb
+// (one translation unit, built at run time: the short list of group sizes)
+#define BBB_BER_PART 0
+#define BBB_BER_FEW_INSTANCES 1
 #include "ber_kernels_impl.hpp"
 extern "C" int bbb_custom_ber(const uint32_t *planes_dev, const uint32_t *prbs_planes_dev, const void *trials, int ncfg,
                               uint32_t nlanes, uint64_t *counters_dev, void *hip_stream) {

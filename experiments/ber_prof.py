@@ -1,4 +1,6 @@
 """Design experiment: kernel timeline of one 11-point BER sweep call."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, basebandboard_amd as g
 from basebandboard_amd import channel
 u = g.LUTOPT.shipped(256)

@@ -4,8 +4,10 @@
 usage: isa_hist.py <file.hip> <kernel-name-substring> [min block size]
 Compiles csrc/<file.hip> to assembly for gfx950 and prints, for every basic block of the first kernel whose
 mangled name contains the substring, its size and the most frequent opcodes; inline-asm instructions
-(the generator's explicit v_accvgpr moves) are counted separately from hipcc's own."""
+(the generator's explicit v_accvgpr moves) are counted separately from hipcc's own.
+ISA_HIST_FLAGS in the environment adds compiler flags (-DBBB_BER_PART=3 ...)."""
 import collections
+import os
 import pathlib
 import re
 import subprocess
@@ -20,7 +22,7 @@ def main():
     with tempfile.TemporaryDirectory() as td:
         out = pathlib.Path(td) / "k.s"
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only",
-                               str(csrc / src), "-o", str(out)], cwd=str(csrc), stderr=subprocess.DEVNULL)
+                               *os.environ.get("ISA_HIST_FLAGS", "").split(), str(csrc / src), "-o", str(out)], cwd=str(csrc), stderr=subprocess.DEVNULL)
         lines = out.read_text().split("\n")
     start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\w*" + re.escape(name) + r"\w*:", l))
     end = next(i for i in range(start, len(lines)) if ".Lfunc_end" in lines[i])
