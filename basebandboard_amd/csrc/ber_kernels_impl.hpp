@@ -266,57 +266,107 @@ ber256_fused_kernel(BerMasks mk, const uint32_t *__restrict planes, const uint32
     for (int c = 0; c < NC; c++) nerr[c] = 0;
     const unsigned ka = (unsigned)(32 - tk.k) * 64, ta = (unsigned)(32 - tk.tap) * 64;
 
+    // Scalar masks.  Fast mode: the eq masks of all settings and the threshold masks of the first kRes settings live in SGPRs
+    // for the whole kernel; the threshold masks of the others are streamed through two 8-SGPR windows by s_load_dwordx8 --
+    // issued in front of the generator step (settings kRes, kRes + 1: the step hides their latency) and right after a window's
+    // setting is done (the resident settings' scans hide it).  Written as inline asm so that the loads stay where they are put:
+    // left to hipcc they sit in front of their first use and the one wave of the SIMD waits out every one of them (1.20 ms per
+    // 1e9 steps, 85 % VALU busy: profiles/r04_ber_new1_pmc.json).  A compiler-inserted s_waitcnt lgkmcnt(N) that does not know
+    // of these loads only waits longer than it had to.
+    typedef const uint32_t __attribute__((address_space(4))) *kptr_t;
+    typedef uint32_t s8_t __attribute__((ext_vector_type(8)));
+    const kptr_t mp = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();       // the table is the FIRST kernel argument: offset 0
+    constexpr int kRes = MODE == kBerFast ? (NC < 7 ? NC : 7) : 0;
+    uint32_t eqm[MODE == kBerFast ? NC : 1], tmr[kRes ? kRes : 1][8];
+    if constexpr (MODE == kBerFast) {
+#pragma unroll
+        for (int c = 0; c < NC; c++) eqm[c] = mp[c * 32 + 8];
+#pragma unroll
+        for (int c = 0; c < kRes; c++)
+#pragma unroll
+            for (int q = 0; q < 8; q++) tmr[c][q] = mp[c * 32 + q];
+    }
+    s8_t w0 = {0, 0, 0, 0, 0, 0, 0, 0}, w1 = w0;
+#define BBB_SLOAD8(w, c) asm volatile("s_load_dwordx8 %0, %1, %2" : "=&s"(w) : "s"(mp), "n"((c) * 128))
+    // the same, pinned between the scans around it: `dep` (a value the NEXT scan reads) passes through the statement, `after` (the
+    // counter the PREVIOUS scan wrote) is an input -- hipcc otherwise lets the load sink to just in front of its wait
+#define BBB_SLOAD8_AT(w, c, after, dep) asm volatile("s_load_dwordx8 %0, %2, %3" : "=&s"(w), "+v"(dep) : "s"(mp), "n"((c) * 128), "v"(after))
+#define BBB_SWAIT(w) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(w))
+#define BBB_SWAIT_AFTER(w, after) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(w) : "v"(after))      // not before `after` is computed
+    auto prefetch = [&]() {
+        if constexpr (MODE == kBerFast && NC > kRes) BBB_SLOAD8(w0, kRes);
+        if constexpr (MODE == kBerFast && NC > kRes + 1) BBB_SLOAD8(w1, kRes + 1);
+    };
+
     auto compare = [&](const uint32_t pbit, const uint32_t valid) {
-        // the table is the FIRST kernel argument: offset 0 of the kernel-argument segment (constant address space: scalar loads)
-        typedef const uint32_t __attribute__((address_space(4))) *kptr_t;
-        kptr_t mp = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
-        asm volatile("" : "+s"(mp));            // (opaque: the scalar loads below stay inside the step)
         if constexpr (MODE == kBerFast) {
             uint32_t X[8];
 #pragma unroll
             for (int q = 0; q < 7; q++) X[q] = __builtin_amdgcn_bitop3_b32(cnt[q], pbit, valid, 0x28);     // (a ^ b) & c
             X[7] = __builtin_amdgcn_bitop3_b32(cnt[7], pbit, valid, 0x82);                                 // ~(a ^ b) & c
+            auto scan = [&](const int c, auto tm) {
+                uint32_t ge = __builtin_amdgcn_bitop3_b32(pbit, eqm[c], valid, 0xA8);                      // (a | b) & c
 #pragma unroll
-            for (int c = 0; c < NC; c++) {
-                uint32_t ge = __builtin_amdgcn_bitop3_b32(pbit, mp[c * 32 + 8], valid, 0xA8);             // (a | b) & c
-#pragma unroll
-                for (int q = 0; q < 8; q++) ge = __builtin_amdgcn_bitop3_b32(X[q], ge, mp[c * 32 + q], 0xD4);
+                for (int q = 0; q < 8; q++) ge = __builtin_amdgcn_bitop3_b32(X[q], ge, tm[q], 0xD4);
                 nerr[c] += __builtin_popcount(ge);
+            };
+            if constexpr (NC > kRes) {
+                BBB_SWAIT(w0);
+                scan(kRes, w0);
+                if constexpr (NC > kRes + 2) BBB_SLOAD8_AT(w0, kRes + 2, nerr[kRes], X[0]);
             }
-        } else if constexpr (MODE == kBerPair) {
-            uint32_t T[8];
-#pragma unroll
-            for (int q = 0; q < 7; q++) T[q] = cnt[q];
-            T[7] = ~cnt[7];
-            const uint32_t pv1 = pbit & valid, pv0 = ~pbit & valid;
-#pragma unroll
-            for (int c = 0; c < NC; c++) {
-                uint32_t g0 = ~0u, g1 = ~0u;
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    g0 = __builtin_amdgcn_bitop3_b32(T[q], g0, mp[c * 32 + q], 0xD4);
-                    g1 = __builtin_amdgcn_bitop3_b32(T[q], g1, mp[c * 32 + 8 + q], 0xD4);
-                }
-                g0 ^= mp[c * 32 + 16];
-                g1 ^= mp[c * 32 + 17];
-                nerr[c] += __builtin_popcount((pv1 & g1) | (pv0 & g0));
+            if constexpr (NC > kRes + 1) {
+                if constexpr (NC > kRes + 2) asm volatile("" : "+s"(w1));       // (already landed: the wait above was for all)
+                scan(kRes + 1, w1);
+                if constexpr (NC > kRes + 3) BBB_SLOAD8_AT(w1, kRes + 3, nerr[kRes + 1], X[0]);
             }
+#pragma unroll
+            for (int c = 0; c < kRes; c++) scan(c, tmr[c]);
+            if constexpr (NC > kRes + 2) {
+                BBB_SWAIT_AFTER(w0, nerr[kRes - 1]);
+                scan(kRes + 2, w0);
+                if constexpr (NC > kRes + 4) BBB_SLOAD8_AT(w0, kRes + 4, nerr[kRes + 2], X[0]);
+            }
+            if constexpr (NC > kRes + 3) scan(kRes + 3, w1);
+            if constexpr (NC > kRes + 4) {
+                BBB_SWAIT_AFTER(w0, nerr[kRes + 3]);
+                scan(kRes + 4, w0);
+            }
+            static_assert(NC <= kRes + 5, "two windows serve five streamed settings");
         } else {
+            kptr_t mo = mp;
+            asm volatile("" : "+s"(mo));            // (opaque: the scalar loads below stay inside the step)
             uint32_t T[8];
 #pragma unroll
             for (int q = 0; q < 7; q++) T[q] = cnt[q];
             T[7] = ~cnt[7];
-            uint32_t e[2] = {mp[8 * 32 + 0], mp[8 * 32 + 1]};
+            if constexpr (MODE == kBerPair) {
+                const uint32_t pv1 = pbit & valid, pv0 = ~pbit & valid;
 #pragma unroll
-            for (int bv = 0; bv < 2; bv++)
+                for (int c = 0; c < NC; c++) {
+                    uint32_t g0 = ~0u, g1 = ~0u;
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    uint32_t g = ~0u;
-#pragma unroll
-                    for (int q = 0; q < 8; q++) g = __builtin_amdgcn_bitop3_b32(T[q], g, mp[(bv * 4 + i) * 32 + q], 0xD4);
-                    e[bv] ^= g & mp[(bv * 4 + i) * 32 + 8];
+                    for (int q = 0; q < 8; q++) {
+                        g0 = __builtin_amdgcn_bitop3_b32(T[q], g0, mo[c * 32 + q], 0xD4);
+                        g1 = __builtin_amdgcn_bitop3_b32(T[q], g1, mo[c * 32 + 8 + q], 0xD4);
+                    }
+                    g0 ^= mo[c * 32 + 16];
+                    g1 ^= mo[c * 32 + 17];
+                    nerr[c] += __builtin_popcount((pv1 & g1) | (pv0 & g0));
                 }
-            nerr[0] += __builtin_popcount(((pbit & e[1]) | (~pbit & e[0])) & valid);
+            } else {
+                uint32_t e[2] = {mo[8 * 32 + 0], mo[8 * 32 + 1]};
+#pragma unroll
+                for (int bv = 0; bv < 2; bv++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        uint32_t g = ~0u;
+#pragma unroll
+                        for (int q = 0; q < 8; q++) g = __builtin_amdgcn_bitop3_b32(T[q], g, mo[(bv * 4 + i) * 32 + q], 0xD4);
+                        e[bv] ^= g & mo[(bv * 4 + i) * 32 + 8];
+                    }
+                nerr[0] += __builtin_popcount(((pbit & e[1]) | (~pbit & e[0])) & valid);
+            }
         }
     };
 
@@ -328,11 +378,17 @@ ber256_fused_kernel(BerMasks mk, const uint32_t *__restrict planes, const uint32
         ring[u] = p0; ring[u + 64] = p1;
         ring[u + 32 * 64] = p0; ring[u + 33 * 64] = p1;
         const uint32_t s0 = t >= tk.last_len ? ~0u : 0u, s1 = t + 1 >= tk.last_len ? ~0u : 0u;
+        prefetch();
         lutopt256_step_parked_ber(a, pa, b, pb, cnt);
         compare(p0, __builtin_amdgcn_bitop3_b32(vm_all, vm_last, s0, 0x70));      // a & ~(b & c)
+        prefetch();
         lutopt256_step_parked_ber(b, pb, a, pa, cnt);
         compare(p1, __builtin_amdgcn_bitop3_b32(vm_all, vm_last, s1, 0x70));
     }
+#undef BBB_SLOAD8
+#undef BBB_SLOAD8_AT
+#undef BBB_SWAIT
+#undef BBB_SWAIT_AFTER
 #pragma unroll
     for (int c = 0; c < NC; c++) {
         unsigned long long e64 = nerr[c];

@@ -465,7 +465,7 @@ def generate_packed512(taps):
 # fewer other live values) takes 230: 71 parked planes instead of 121, and hipcc adds no spills of its own up to there
 # (budget -> registers / VALU per step: 180 -> 436 / 1185, 200 -> 422 / 1120, 220 -> 432 / 1080, 230 -> 434 / 1060,
 # 240 -> 460 / 1054: the guests beside the kernel need 72 of the 512)
-BER_BUDGET = 230             # the fused BER kernel: the PLANES kernel's loop plus the comparators' live values (see ber_kernels_impl.hpp)
+BER_BUDGET = 222             # the fused BER kernel: the PLANES kernel's loop plus the comparators' live values (see ber_kernels_impl.hpp)
 PARK_VARIANTS = (("", 180), ("_hi", 230), ("_ber", BER_BUDGET))
 PACKED512_BUDGET = 230        # the packed n512 kernel: state registers resident in VGPRs (its counters and output stage need the rest)
 
