@@ -170,7 +170,7 @@ def sweep_bits(trials, runner, rank=0, world=1, group=None):
     an Eb/N0 sweep keeps its one-pass-per-noise-stream grouping on every rank."""
     import torch.distributed as dist
     mine = shard_trials(trials, rank, world, _lib.SHARD_BITS)
-    total = runner(mine, len(mine)).clone()
+    total = runner(mine, len(mine))
     if world > 1:
         if dist.get_backend(group) == "gloo" and total.is_cuda:      # CPU rehearsal of a GPU sweep
             host = total.cpu()
@@ -187,7 +187,7 @@ def sweep_seeds(trials, runner, world=1, group=None):
     pass over its noise stream for the whole sweep, and the counters of the ranks are summed with ONE
     all-reduce: `world` times the bits per point in the time of one sweep.  Returns int64 [len(trials), 2]."""
     import torch.distributed as dist
-    total = runner(list(trials), len(trials)).clone()
+    total = runner(list(trials), len(trials))
     if world > 1:
         if dist.get_backend(group) == "gloo" and total.is_cuda:      # CPU rehearsal of a GPU sweep
             host = total.cpu()

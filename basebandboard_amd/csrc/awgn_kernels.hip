@@ -162,6 +162,36 @@ seed_level_kernel(const uint32_t *__restrict tabs, int k, int e, unsigned long l
     }
 }
 
+// PRBS start states for the BER kernels (round 4): k <= 31, so a state is one word and a jump table at most 512 bytes; all of
+// them (levels 1..6 x 15 digits: 45 KiB) sit in LDS and thread g composes the jumps of generator g digit by digit -- one launch
+// (plus bitslice_kernel<1>) where the generic chain took seven on the side stream and held CUs beside the generator's own seeding.
+__global__ void __launch_bounds__(256)
+prbs_seed_states_kernel(const uint32_t *__restrict tabs, Seed16 s, int k, int levels, unsigned long long G, uint32_t *__restrict S) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t tab[];       // [e - 1][d - 1][ceil(k / 4) nibbles][16]  (W32 = 1, C = 1)
+    __shared__ uint32_t first[16];
+    const int nnib = (k + 3) / 4, nt = nnib * 16;
+    for (int i = threadIdx.x; i < (levels - 1) * 15 * nt; i += blockDim.x) tab[i] = tabs[15 * nt + i];
+    if (threadIdx.x < 16) first[threadIdx.x] = s.w[threadIdx.x][0];
+    __syncthreads();
+    // a block takes a contiguous stretch of generators, thread-strided: neighbouring lanes differ in the LOW digits only
+    const unsigned long long per = 256ull * 8;
+    for (unsigned long long g = (unsigned long long)blockIdx.x * per + threadIdx.x; g < G && g < (blockIdx.x + 1ull) * per; g += 256) {
+        uint32_t x = first[g & 15];
+        for (int e = 1; e < levels; e++) {
+            const unsigned d = (unsigned)(g >> (4 * e)) & 15u;
+            if (d) {
+                const uint32_t *t = tab + ((e - 1) * 15 + (d - 1)) * nt;
+                uint32_t y = 0;
+#pragma unroll
+                for (int n = 0; n < 8; n++)
+                    if (n < nnib) y ^= t[n * 16 + ((x >> (4 * n)) & 15u)];
+                x = y;
+            }
+        }
+        S[g] = x;
+    }
+}
+
 // Word-major packed states -> bit planes.  Thread (LG, wq) gathers word wq of the 32 generators of
 // lane LG and transposes: planes[(32*wq + p) * nlanes + LG] bit j = state bit 32*wq+p of g(LG, j).
 template <int W32>
@@ -1124,6 +1154,8 @@ static int seed_and_slice(int k, const uint32_t *d_tabs, const uint32_t *s16, ui
             if (dev >= 0 && dev < 64) attr_set[dev] = true;
         }
     }
+    // (tried in round 4: levels 1..3 composed per thread from the tables in global memory, one launch instead of four -- 46 us
+    // where the four take 33: uncoalesced 32-byte lookups pull a 128-byte line each through the vector cache)
     hipLaunchKernelGGL((seed_store16_kernel<W32>), dim3(1), dim3(64), 0, st, s, (unsigned long long)G,
                        (unsigned long long)stride, d_states);
     for (int e = 1; e < levels; e++) {               // level 0 (states 1..15) was done on the host
@@ -1135,6 +1167,24 @@ static int seed_and_slice(int k, const uint32_t *d_tabs, const uint32_t *s16, ui
     const uint64_t threads = (uint64_t)nlanes * (uint64_t)((k + 31) / 32);
     hipLaunchKernelGGL((bitslice_kernel<W32>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, d_states,
                        (unsigned long long)G, (unsigned long long)stride, nlanes, k, d_planes);
+    BBB_HIP(hipGetLastError());
+    return BBB_OK;
+}
+
+int prbs_seed_planes_launch(int k, const uint32_t *d_tabs, const uint32_t *s16, uint64_t G, uint32_t *d_states, unsigned nlanes,
+                            uint32_t *d_planes, hipStream_t st) {
+    if (k < 2 || k > 31) return fail(BBB_EINVAL, "PRBS order must be below 32");
+    Seed16 s{};
+    for (int i = 0; i < 16; i++) s.w[i][0] = s16[i * 16];
+    int levels = 0;
+    while ((1ull << (4 * levels)) < G) levels++;
+    if (levels < 1) levels = 1;
+    if (levels > 7) return fail(BBB_EINVAL, "too many generators for the PRBS jump plan");
+    const size_t lds = (size_t)(levels - 1) * 15 * ((k + 3) / 4) * 16 * sizeof(uint32_t);        // <= 45 KiB
+    hipLaunchKernelGGL(prbs_seed_states_kernel, dim3((unsigned)((G + 2047) / 2048)), dim3(256), lds, st, d_tabs, s, k, levels,
+                       (unsigned long long)G, d_states);
+    hipLaunchKernelGGL((bitslice_kernel<1>), dim3((nlanes + 255) / 256), dim3(256), 0, st, d_states, (unsigned long long)G,
+                       (unsigned long long)G, nlanes, k, d_planes);
     BBB_HIP(hipGetLastError());
     return BBB_OK;
 }

@@ -13,6 +13,10 @@ namespace bbb {
 // seeding is to run beside the transmitter variant of the sample kernel, which leaves less LDS free
 int awgn_seed_launch(int k, const uint32_t *d_tabs, const uint32_t *s16, uint64_t G, uint32_t *d_states,
                      uint64_t stride, unsigned nlanes, uint32_t *d_planes, hipStream_t st, int slice_mode = 0, int parts = 2);
+// PRBS start states (k <= 31) of the BER kernels' generators, d_states[G] -> bit planes [k][nlanes], two launches; d_tabs = the radix-16
+// plan of the LFSR's jump matrix (W32 = 1), s16 as above
+int prbs_seed_planes_launch(int k, const uint32_t *d_tabs, const uint32_t *s16, uint64_t G, uint32_t *d_states, unsigned nlanes,
+                            uint32_t *d_planes, hipStream_t st);
 // awgn512.hip: generated kernel for the shipped n512 matrix (packed state, 16 generators per lane, int16 out)
 bool awgn512p_matches(int k, const uint16_t *taps, const uint32_t *row_off);
 int bitslice512p_launch(const uint32_t *d_states, uint64_t G, uint64_t stride, unsigned nlanes, uint32_t *d_planes, hipStream_t st);

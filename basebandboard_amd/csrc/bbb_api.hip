@@ -666,7 +666,6 @@ int ber_run(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, unsigned long lo
         // so that its chain of small launches runs beside the generator's (both are latency, not work)
         JumpPlan *pp;
         if ((rc = get_prbs_plan(h, c.prbs_k, L, &pp))) return rc;
-        if ((rc = grow(&h->d_pstates, &h->pstates_cap, (size_t)G))) return rc;
         if ((rc = grow(&h->d_pplanes, &h->pplanes_cap, (size_t)32 * nlanes))) return rc;
         uint64_t ps0 = 0;
         if ((rc = prbs_state_at_host(c.prbs_k, c.prbs_state, c.first_bit, &ps0))) return rc;
@@ -678,7 +677,8 @@ int ber_run(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, unsigned long lo
             if (!*e) BBB_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
         BBB_HIP(hipEventRecord(h->ber_fork, h->cs));                  // (the previous trial's kernel may still read d_pplanes)
         BBB_HIP(hipStreamWaitEvent(h->side, h->ber_fork, 0));
-        if ((rc = awgn_seed_launch(c.prbs_k, pp->d_cols, ps16, G, h->d_pstates, G, nlanes, h->d_pplanes, h->side))) return rc;
+        if ((rc = grow(&h->d_pstates, &h->pstates_cap, (size_t)G))) return rc;
+        if ((rc = prbs_seed_planes_launch(c.prbs_k, pp->d_cols, ps16, G, h->d_pstates, nlanes, h->d_pplanes, h->side))) return rc;
         BBB_HIP(hipEventRecord(h->ber_join, h->side));
         if ((rc = prepare_planes(h, c.warmup + c.first_bit, L, G, nlanes))) return rc;
         BBB_HIP(hipStreamWaitEvent(h->cs, h->ber_join, 0));
