@@ -104,6 +104,64 @@ def run_trials_into(urng, trials, counters):
     return counters
 
 
+class ContinuedTrials:
+    """A trial group continued over several calls (bbb_ber_run_*): `trials` share PRBS, offsets and nbits (= bits per call)
+    and read ONE noise stream; a block of `calls_per_block` calls shares one seeding of the generators, and after every
+    `calls_per_block`-th call the totals equal `run_trials` over that block's bits, bit for bit.  The Monte-Carlo loop
+    that adds bits until it has seen enough errors:
+
+        with ContinuedTrials(urng, trials, 8) as run:
+            while min(e for _, e in run.next()) < 100: pass
+    """
+
+    def __init__(self, urng, trials, calls_per_block):
+        if not trials:
+            raise ValueError("no trials")
+        self.urng, self.ntrials = urng, len(trials)
+        cfgs = (_lib.TrialCfg * len(trials))(*[t.as_c() for t in trials])
+        self._r = C.c_void_p()
+        urng._bind_stream()
+        _lib.check(_lib.lib().bbb_ber_run_open(urng._h, cfgs, len(trials), int(calls_per_block), C.byref(self._r)), "bbb_ber_run_open")
+
+    def next(self, read=True):
+        """One more call; returns the run's totals [(bits, errors)] so far (read=False: queued only, returns None)."""
+        self.urng._bind_stream()
+        out = (_lib.Ber * self.ntrials)() if read else None
+        _lib.check(_lib.lib().bbb_ber_run_next(self._r, out), "bbb_ber_run_next")
+        return [(o.bits, o.errors) for o in out] if read else None
+
+    def next_into(self, counters):
+        """One more call, its counters ADDED to an int64 CUDA tensor [ntrials, 2], without synchronising."""
+        if counters.dtype != torch.int64 or not counters.is_cuda or not counters.is_contiguous() or counters.numel() < 2 * self.ntrials:
+            raise ValueError("counters must be a contiguous int64 CUDA tensor with 2 words per trial")
+        self.urng._bind_stream()
+        _lib.check(_lib.lib().bbb_ber_run_next_dev(self._r, C.c_void_p(counters.data_ptr())), "bbb_ber_run_next_dev")
+        return counters
+
+    def tell(self):
+        """(calls made so far, first bit of the next block to start)"""
+        a, b = C.c_uint64(), C.c_uint64()
+        _lib.check(_lib.lib().bbb_ber_run_tell(self._r, C.byref(a), C.byref(b)), "bbb_ber_run_tell")
+        return a.value, b.value
+
+    def close(self):
+        if self._r:
+            _lib.lib().bbb_ber_run_close(self._r)
+            self._r = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ---- sharding a sweep over the GPUs of this process: the C ABI's own collective ----------------
 
 def shard_trials(trials, rank, world, mode=_lib.SHARD_TRIALS):

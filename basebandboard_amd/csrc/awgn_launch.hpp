@@ -63,12 +63,17 @@ struct TrialDev {            // one trial as the kernel sees it
     int32_t prbs_k, prbs_tap;
     int32_t nthr[2];         // number of decision-flip thresholds for bit = 0 / bit = 1
     int32_t thr[2][4];       // error indicator for bit b = XOR_i [ T >= thr[b][i] ],  T = sample + 128 (mod 256)
-    uint32_t L;              // bits per generator
-    uint64_t G, nbits;
+    uint32_t L;              // bits per generator IN THIS LAUNCH (even)
+    uint64_t G, nbits;       // generators; bits this launch counts
+    uint32_t flags, last_len;   // kTrialLastLen: the last generator runs `last_len` (<= L, may be 0) of the L steps instead of
+                                // nbits - (G - 1) L; kTrialSaveState: the kernel leaves the generator's and the PRBS state in
+                                // the plane buffers (the next launch of a continued trial starts from them)
 };
+enum { kTrialLastLen = 1, kTrialSaveState = 2 };
 #define BBB_BER_MAX_GROUP 12
 // one launch for `ncfg` channel settings that share one noise / PRBS stream (same geometry in t[0..ncfg))
-int ber256_launch(const uint32_t *d_planes, const uint32_t *d_prbs_planes, const TrialDev *t, int ncfg, unsigned nlanes,
+// d_planes: the bit-sliced states OF the first sample (one clock past the stream position), d_prbs_planes: the LFSR states
+int ber256_launch(uint32_t *d_planes, uint32_t *d_prbs_planes, const TrialDev *t, int ncfg, unsigned nlanes,
                   unsigned long long *d_counters, hipStream_t st);
 int prbs_state_at_host(int k, uint64_t init_state, uint64_t nbits, uint64_t *state);
 

@@ -680,7 +680,8 @@ int ber_run(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, unsigned long lo
         if ((rc = grow(&h->d_pstates, &h->pstates_cap, (size_t)G))) return rc;
         if ((rc = prbs_seed_planes_launch(c.prbs_k, pp->d_cols, ps16, G, h->d_pstates, nlanes, h->d_pplanes, h->side))) return rc;
         BBB_HIP(hipEventRecord(h->ber_join, h->side));
-        if ((rc = prepare_planes(h, c.warmup + c.first_bit, L, G, nlanes))) return rc;
+        // (the BER kernels take the state OF their first sample: one clock past the stream position)
+        if ((rc = prepare_planes(h, c.warmup + c.first_bit + 1, L, G, nlanes))) return rc;
         BBB_HIP(hipStreamWaitEvent(h->cs, h->ber_join, 0));
         if (h->specialised) {
             if ((rc = ber256_launch(h->d_planes, h->d_pplanes, &td[(size_t)i], n, nlanes, counters_dev + 2 * (size_t)i, h->cs))) return rc;
@@ -1603,6 +1604,171 @@ int bbb_ber_trials(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, bbb_ber *
         out[i].bits = host[2 * (size_t)i];
         out[i].errors = host[2 * (size_t)i + 1];
     }
+    return BBB_OK;
+}
+
+/* ---- a trial group continued over several calls ---------------------------------------------------------- */
+
+// One seeding per BLOCK of m calls: the block's m n bits are cut into G segments of Lb = m Lc steps, call c runs steps
+// [c Lc, (c + 1) Lc) of every generator and leaves the states it ends in (TrialDev.flags: kTrialSaveState) in the run's own
+// plane buffers, where call c + 1 finds them.  The bit / sample pairs of a block are those of ONE bbb_ber_trials call over
+// its m n bits, visited in another order: after every m-th call the totals are that call's counters, bit for bit.
+struct bbb_ber_run {
+    bbb_lutopt *h = nullptr;
+    std::vector<bbb_trial_cfg> cfgs;
+    std::vector<TrialDev> td;
+    uint32_t m = 1, call = 0;
+    uint64_t n = 0, block = 0, Lb = 0, G = 0;
+    unsigned nlanes = 0;
+    uint32_t *d_states = nullptr, *d_planes = nullptr, *d_pstates = nullptr, *d_pplanes = nullptr;
+    size_t states_cap = 0, planes_cap = 0, pstates_cap = 0, pplanes_cap = 0;
+    unsigned long long *d_totals = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+
+int bbb_ber_run_open(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, uint32_t calls_per_block, bbb_ber_run **out) {
+    if (!h || !cfgs || !out || ncfg < 1) return fail(BBB_EINVAL, "null argument");
+    if (ncfg > BBB_BER_MAX_GROUP) return fail(BBB_EINVAL, "a continued trial group holds at most BBB_BER_MAX_GROUP settings");
+    if (calls_per_block < 1 || calls_per_block > 4096) return fail(BBB_EINVAL, "calls_per_block must be in 1..4096");
+    if (h->device < 0) return fail(BBB_ENODEV, "host-only handle (device -1) cannot run trials");
+    if (!h->specialised && !h->custom_ber)
+        return fail(BBB_EUNSUP, "BER trials need the shipped n256 matrix, or a k = 256 matrix with its own kernels attached");
+    BBB_HIP(hipSetDevice(h->device));
+    const bbb_trial_cfg &c0 = cfgs[0];
+    if (c0.nbits == 0) return fail(BBB_EINVAL, "nbits (bits per call) must be positive");
+    std::unique_ptr<bbb_ber_run> r(new bbb_ber_run);
+    r->h = h;
+    r->cfgs.assign(cfgs, cfgs + ncfg);
+    r->td.resize((size_t)ncfg);
+    for (int i = 0; i < ncfg; i++) {
+        const bbb_trial_cfg &c = cfgs[i];
+        const int tap = prbs_tap(c.prbs_k);
+        if (!tap) return fail(BBB_EINVAL, "k=" + std::to_string(c.prbs_k) + " invalid for PRBS");
+        if (c.prbs_state == 0 || (c.prbs_state >> c.prbs_k)) return fail(BBB_EINVAL, "PRBS state must be in [1, 2^k)");
+        if (c.amp < 0 || c.amp > 2047 || c.noise_var < 0 || c.noise_var > 15) return fail(BBB_EINVAL, "amp must be 0..2047 and noise_var 0..15");
+        if (c.prbs_k != c0.prbs_k || c.prbs_state != c0.prbs_state || c.warmup != c0.warmup || c.first_bit != c0.first_bit || c.nbits != c0.nbits)
+            return fail(BBB_EINVAL, "the settings of a continued trial group must share the PRBS, the offsets and nbits (they read one noise stream)");
+        r->td[(size_t)i].prbs_k = c.prbs_k;
+        r->td[(size_t)i].prbs_tap = tap;
+        int rc = channel_thresholds(c.amp, c.noise_var, &r->td[(size_t)i]);
+        if (rc) return rc;
+        int real[2] = {0, 0};
+        for (int bv = 0; bv < 2; bv++)
+            for (int j = 0; j < r->td[(size_t)i].nthr[bv]; j++) real[bv] += r->td[(size_t)i].thr[bv][j] > 0 && r->td[(size_t)i].thr[bv][j] < 256;
+        if (ncfg > 1 && (real[0] != 1 || real[1] != 1))
+            return fail(BBB_EINVAL, "grouped trials must be single-threshold (a wrap-around setting runs alone)");
+    }
+    r->m = calls_per_block;
+    r->n = c0.nbits;
+    const uint64_t nblock = r->n * (uint64_t)r->m;
+    if (nblock / r->m != r->n || c0.warmup + c0.first_bit + nblock < nblock) return fail(BBB_EINVAL, "bits per block overflow");
+    // segments in multiples of 2 m steps: every call runs an even number of steps of every generator
+    partition(h, nblock, 2 * r->m, &r->Lb, &r->G, &r->nlanes);
+    if (r->Lb / r->m >= (1ull << 27)) return fail(BBB_EINVAL, "nbits too large for one call (about 2^47): lower it");
+    BBB_HIP(hipMalloc((void **)&r->d_totals, 2 * (size_t)ncfg * sizeof(unsigned long long)));
+    BBB_HIP(hipMemset(r->d_totals, 0, 2 * (size_t)ncfg * sizeof(unsigned long long)));
+    *out = r.release();
+    return BBB_OK;
+}
+
+// queues the next call of the run on the handle's stream; its counters are ADDED to counters_dev (device, [ncfg][2])
+static int ber_run_step(bbb_ber_run *r, unsigned long long *counters_dev) {
+    bbb_lutopt *h = r->h;
+    BBB_HIP(hipSetDevice(h->device));
+    int rc = begin_op(h, false);
+    if (rc) return rc;
+    const bbb_trial_cfg &c = r->cfgs[0];
+    const int ncfg = (int)r->cfgs.size();
+    const uint64_t nblock = r->n * (uint64_t)r->m, block_first = c.first_bit + r->block * nblock;
+    if (block_first + nblock < block_first || c.warmup + block_first + nblock + 1 < nblock) return fail(BBB_EINVAL, "stream position overflows");
+    if (r->call == 0) {
+        // a new block: start states of its G generators, one clock past the stream position (the kernels take the state OF
+        // their first sample), into the run's own buffers -- other calls on the handle keep theirs
+        JumpPlan *plan, *pp;
+        if ((rc = get_plan(h, r->Lb, &plan))) return rc;
+        if ((rc = get_prbs_plan(h, c.prbs_k, r->Lb, &pp))) return rc;
+        if ((rc = grow(&r->d_states, &r->states_cap, (size_t)r->G * h->W32))) return rc;
+        if ((rc = grow(&r->d_planes, &r->planes_cap, (size_t)h->k * r->nlanes))) return rc;
+        if ((rc = grow(&r->d_pstates, &r->pstates_cap, (size_t)r->G))) return rc;
+        if ((rc = grow(&r->d_pplanes, &r->pplanes_cap, (size_t)32 * r->nlanes))) return rc;
+        uint64_t s0[8];
+        h->pw->apply(c.warmup + block_first + 1, h->init, s0);
+        uint32_t s16[256];
+        first16(*plan, s0, s16);
+        uint64_t ps0 = 0;
+        if ((rc = prbs_state_at_host(c.prbs_k, c.prbs_state, block_first, &ps0))) return rc;
+        uint64_t ps64[8] = {ps0};
+        uint32_t ps16[256];
+        first16(*pp, ps64, ps16);
+        if (!h->side) BBB_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        for (hipEvent_t *e : {&r->fork, &r->join})
+            if (!*e) BBB_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        BBB_HIP(hipEventRecord(r->fork, h->cs));                      // (the previous block's last kernel still reads the buffers)
+        BBB_HIP(hipStreamWaitEvent(h->side, r->fork, 0));
+        if ((rc = prbs_seed_planes_launch(c.prbs_k, pp->d_cols, ps16, r->G, r->d_pstates, r->nlanes, r->d_pplanes, h->side))) return rc;
+        BBB_HIP(hipEventRecord(r->join, h->side));
+        if ((rc = awgn_seed_launch(h->k, plan->d_cols, s16, r->G, r->d_states, r->G, r->nlanes, r->d_planes, h->cs))) return rc;
+        BBB_HIP(hipStreamWaitEvent(h->cs, r->join, 0));
+    }
+    const uint64_t Lc = r->Lb / r->m;
+    // the (possibly short) last generator of the block: it owns block_len - (G - 1) Lb steps, of which this call sees
+    // those inside [call Lc, (call + 1) Lc)
+    const uint64_t last_total = nblock - (r->G - 1) * r->Lb, lo = (uint64_t)r->call * Lc;
+    const uint64_t last_len = last_total <= lo ? 0 : (last_total - lo < Lc ? last_total - lo : Lc);
+    const uint64_t bits_now = (r->G - 1) * Lc + last_len;
+    for (int i = 0; i < ncfg; i++) {
+        TrialDev &t = r->td[(size_t)i];
+        t.L = (uint32_t)Lc; t.G = r->G; t.nbits = bits_now;
+        t.flags = kTrialLastLen | kTrialSaveState; t.last_len = (uint32_t)last_len;
+    }
+    if (h->specialised) {
+        if ((rc = ber256_launch(r->d_planes, r->d_pplanes, r->td.data(), ncfg, r->nlanes, counters_dev, h->cs))) return rc;
+    } else {
+        const int e = h->custom_ber(r->d_planes, r->d_pplanes, r->td.data(), ncfg, r->nlanes, (uint64_t *)counters_dev, (void *)h->cs);
+        if (e) return fail(e < 0 ? e : BBB_EHIP, "custom BER kernel failed");
+    }
+    if (++r->call == r->m) { r->call = 0; r->block++; }
+    return BBB_OK;
+}
+
+int bbb_ber_run_next_dev(bbb_ber_run *r, uint64_t *counters_dev) {
+    if (!r || !counters_dev) return fail(BBB_EINVAL, "null argument");
+    return ber_run_step(r, (unsigned long long *)counters_dev);
+}
+
+int bbb_ber_run_next(bbb_ber_run *r, bbb_ber *totals) {
+    if (!r) return fail(BBB_EINVAL, "null argument");
+    int rc = ber_run_step(r, r->d_totals);
+    if (rc || !totals) return rc;
+    const size_t need = 2 * r->cfgs.size();
+    std::vector<unsigned long long> host(need);
+    BBB_HIP(hipMemcpyAsync(host.data(), r->d_totals, need * sizeof(unsigned long long), hipMemcpyDeviceToHost, r->h->stream));
+    BBB_HIP(hipStreamSynchronize(r->h->stream));
+    for (size_t i = 0; i < r->cfgs.size(); i++) {
+        totals[i].bits = host[2 * i];
+        totals[i].errors = host[2 * i + 1];
+    }
+    return BBB_OK;
+}
+
+int bbb_ber_run_tell(const bbb_ber_run *r, uint64_t *calls_done, uint64_t *next_block_first_bit) {
+    if (!r) return fail(BBB_EINVAL, "null argument");
+    if (calls_done) *calls_done = r->block * r->m + r->call;
+    if (next_block_first_bit) *next_block_first_bit = r->cfgs[0].first_bit + (r->block + (r->call ? 1 : 0)) * r->n * (uint64_t)r->m;
+    return BBB_OK;
+}
+
+int bbb_ber_run_close(bbb_ber_run *r) {
+    if (!r) return BBB_OK;
+    if (r->h && r->h->device >= 0) (void)hipSetDevice(r->h->device);
+    if (r->h && r->h->stream) (void)hipStreamSynchronize(r->h->stream);
+    if (r->h && r->h->cs_valid) (void)hipStreamSynchronize(r->h->cs);
+    if (r->h && r->h->side) (void)hipStreamSynchronize(r->h->side);
+    for (void *p : {(void *)r->d_states, (void *)r->d_planes, (void *)r->d_pstates, (void *)r->d_pplanes, (void *)r->d_totals})
+        if (p) (void)hipFree(p);
+    for (hipEvent_t e : {r->fork, r->join})
+        if (e) (void)hipEventDestroy(e);
+    delete r;
     return BBB_OK;
 }
 

@@ -7,208 +7,23 @@ namespace bbb {
 
 constexpr int kMaxCfg = BBB_BER_MAX_GROUP;   // channel settings evaluated per launch on ONE noise / PRBS stream
 
-struct TrialK {              // kernel-argument form (uniform -> SGPRs / scalar loads)
-    int32_t k, tap, ncfg;
-    uint32_t L, last_len;
-    unsigned long long G;
-    int8_t nthr[kMaxCfg][2];     // thresholds in use for bit = 0 / 1
-    int8_t inv[kMaxCfg][2];      // constant term of the parity
-    int16_t thr[kMaxCfg][2][4];  // each in 1..255
-    // fast path (every non-wrapping channel): with X = bit ? ~T : T the error indicator of BOTH bit values is
-    // one comparison [X >= thrx] -- for bit = 0 strict ([X > thrx]) when strict0 is set
-    int16_t thrx[kMaxCfg];
-    int8_t strict0[kMaxCfg];
-};
-
-// [T >= thr] for 32 samples: scan from the LSB; where the threshold bit is 1 the running result
-// ANDs with T's bit, where it is 0 it ORs.  The per-bit mask is a scalar (SALU) value, the
-// update one V_BITOP3 with a scalar operand.
-__device__ __forceinline__ uint32_t ge_thr(const uint32_t (&T)[8], int thr) {
-    uint32_t ge = ~0u;
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-        const uint32_t tm = (uint32_t)(((int32_t)((uint32_t)thr << (31 - q))) >> 31);   // scalar: 0 or ~0
-        // tm ? (T & ge) : (T | ge)   -- truth table over (a = T, b = ge, c = tm) = 0xD4
-        ge = __builtin_amdgcn_bitop3_b32(T[q], ge, tm, 0xD4);
-    }
-    return ge;
-}
-
 // kBerGeneral: one channel setting per launch, any number (<= 4) of thresholds per bit value
 //              (12-bit wrap-around cases).
 // kBerPair   : up to kMaxCfg settings per launch, each with exactly ONE threshold per bit value plus an
 //              optional complement: two 8-instruction scans per setting.
 // kBerFast   : the same for every non-wrapping channel (bit 0 errs when T >= thr0, bit 1 when T < thr1,
-//              thr0 + thr1 = 256 or 257): ONE scan per setting on X = bit ? ~T : T; two passes of six
-//              settings over the staged planes so that the 48 scalar masks of a pass stay in SGPRs.
+//              thr0 + thr1 = 256 or 257): ONE scan per setting on X = bit ? ~T : T.
+// [T >= thr] for 32 samples: scan from the LSB; where the threshold bit is 1 the running result ANDs with T's bit, where
+// it is 0 it ORs: tm ? (T & ge) : (T | ge) = one V_BITOP3 (truth table 0xD4 over a = T, b = ge, c = tm) with the per-bit
+// mask tm a scalar (0 or ~0).
 enum { kBerFast = 0, kBerPair = 1, kBerGeneral = 2 };
-template <int MODE>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
-ber256_kernel(const uint32_t *__restrict planes, const uint32_t *__restrict prbs_planes, TrialK tk, unsigned nlanes,
-              unsigned long long *__restrict counters) {
-    constexpr bool GENERAL = MODE == kBerGeneral;
-    constexpr int NC = GENERAL ? 1 : kMaxCfg;
-    constexpr int kRound = 8;                 // steps staged per round
-    __shared__ uint32_t PR[32 * 64];          // PRBS state planes, circular: slot (head + i) % k = state bit i
-    __shared__ uint32_t Z[kRound * 8 * 64];   // count planes of the round's steps
-    __shared__ uint32_t ZP[kRound * 64];      // PRBS bit plane of the round's steps (for the second comparator pass)
-    const unsigned lane = threadIdx.x;
-    const unsigned long long wave = blockIdx.x;
-    const unsigned long long LG = wave * 64 + lane;
-
-    // lutopt256_step_parked yields the sample of the state it is GIVEN (and its successor): the planes
-    // hold the state before the first sample, so advance once
-    uint32_t a[256], b[256], pa[256], pb[256], cnt[8];
-#pragma unroll
-    for (int p = 0; p < 256; p++) b[p] = planes[(size_t)p * nlanes + LG];
-    lutopt256_advance(b, a);
-#define BBB_PARK(p) BBB_ACC_WRITE(pa[p], a[p]);
-    LUTOPT256_FOR_PARKED(BBB_PARK)
-#undef BBB_PARK
-    for (int i = 0; i < tk.k; i++) PR[i * 64 + lane] = prbs_planes[(size_t)i * nlanes + LG];
-
-    // which of this lane's 32 generators exist, and which one is the (possibly short) last one
-    uint32_t vm_all = 0, vm_last = 0;
-    for (unsigned j = 0; j < 32; j++) {
-        const unsigned long long g = gen_index(wave, lane, j);
-        if (g < tk.G) vm_all |= 1u << j;
-        if (g + 1 == tk.G) vm_last |= 1u << j;
-    }
-    uint32_t nerr[NC];
-#pragma unroll
-    for (int c = 0; c < NC; c++) nerr[c] = 0;
-    uint32_t nbit = 0;
-    int head = 0;
-    // thresholds of the simple path, as scalars
-    int thr0[NC], thr1[NC];
-    uint32_t inv0[NC], inv1[NC];
-#pragma unroll
-    for (int c = 0; c < NC; c++) {
-        thr0[c] = tk.thr[c][0][0]; thr1[c] = tk.thr[c][1][0];
-        inv0[c] = tk.inv[c][0] ? ~0u : 0u; inv1[c] = tk.inv[c][1] ? ~0u : 0u;
-    }
-
-    // The noise loop is the sample kernel's (same generated step, same explicit AGPR placement); the
-    // 8 count planes of every step are staged in LDS and the comparators run once per round of kRound
-    // steps in a loop of their own, so that their live values never compete with the 256-plane state.
-    const unsigned rounds = (tk.L + kRound - 1) / kRound;
-#pragma unroll 1
-    for (unsigned r = 0; r < rounds; r++) {
-#pragma unroll 1
-        for (unsigned tt = 0; tt < kRound / 2; tt++) {
-            lutopt256_step_parked(a, pa, b, pb, cnt);
-#pragma unroll
-            for (int i = 0; i < 8; i++) Z[((2 * tt) * 8 + i) * 64 + lane] = cnt[i];
-            lutopt256_step_parked(b, pb, a, pa, cnt);
-#pragma unroll
-            for (int i = 0; i < 8; i++) Z[((2 * tt + 1) * 8 + i) * 64 + lane] = cnt[i];
-        }
-        const unsigned t0 = r * kRound;
-        const unsigned nt = tk.L - t0 < (unsigned)kRound ? tk.L - t0 : (unsigned)kRound;
-        // pass 0 also advances the PRBS and leaves its bit plane in ZP for the later pass(es)
-        constexpr int kPerPass = MODE == kBerFast ? 6 : NC;        // comparator masks of a pass must fit the SGPR file
-        constexpr int kPasses = (NC + kPerPass - 1) / kPerPass;
-#pragma unroll
-        for (int pass = 0; pass < kPasses; pass++) {
-            if (pass * kPerPass >= tk.ncfg) break;
-            // per-bit masks of this pass's thresholds (fast path): scalars, one V_BITOP3 operand each
-            uint32_t tmx[kPerPass][8], eqm[kPerPass];
-            if (MODE == kBerFast) {
-#pragma unroll
-                for (int c = 0; c < kPerPass; c++) {
-                    const int cc = pass * kPerPass + c < NC ? pass * kPerPass + c : NC - 1;
-                    int th = tk.thrx[cc];
-                    asm volatile("" : "+s"(th));       // recompute the masks here, every round: hoisted out of the
-                                                       // round loop, the 96 of them would be spilled to VGPR lanes
-#pragma unroll
-                    for (int q = 0; q < 8; q++) tmx[c][q] = (uint32_t)(((int32_t)((uint32_t)th << (31 - q))) >> 31);
-                    // ~0 where bit 0 uses ">=" too; through readfirstlane so that it stays a scalar MASK operand of
-                    // one V_OR (as a condition it costs a select and two lane reads per setting)
-                    eqm[c] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(0u - (uint32_t)(tk.strict0[cc] == 0)));
-                }
-            }
-#pragma unroll 1
-            for (unsigned u = 0; u < nt; u++) {
-                const unsigned t = t0 + u;
-                uint32_t pb_;
-                if (pass == 0) {
-                    // PRBS: bit = s[k-1] ^ s[tap-1]; shift in at position 0 (prbs.py:34-35)
-                    int i1 = head + tk.k - 1;   if (i1 >= tk.k) i1 -= tk.k;
-                    int i2 = head + tk.tap - 1; if (i2 >= tk.k) i2 -= tk.k;
-                    pb_ = PR[i1 * 64 + lane] ^ PR[i2 * 64 + lane];
-                    head = head == 0 ? tk.k - 1 : head - 1;       // new slot 0 overwrites the old s[k-1]
-                    PR[head * 64 + lane] = pb_;
-                    if (kPasses > 1) ZP[u * 64 + lane] = pb_;
-                } else {
-                    pb_ = ZP[u * 64 + lane];
-                }
-                // T = sample + 128: flip the int8 sign plane back
-                uint32_t T[8];
-#pragma unroll
-                for (int q = 0; q < 7; q++) T[q] = Z[(u * 8 + q) * 64 + lane];
-                T[7] = ~Z[(u * 8 + 7) * 64 + lane];
-                const uint32_t valid = t < tk.last_len ? vm_all : (vm_all & ~vm_last);
-                if (pass == 0) nbit += __builtin_popcount(valid);
-                if (MODE == kBerGeneral) {
-                    uint32_t e0 = tk.inv[0][0] ? ~0u : 0u, e1 = tk.inv[0][1] ? ~0u : 0u;
-                    for (int i = 0; i < tk.nthr[0][0]; i++) e0 ^= ge_thr(T, tk.thr[0][0][i]);
-                    for (int i = 0; i < tk.nthr[0][1]; i++) e1 ^= ge_thr(T, tk.thr[0][1][i]);
-                    nerr[0] += __builtin_popcount(((pb_ & e1) | (~pb_ & e0)) & valid);
-                } else if (MODE == kBerPair) {
-                    const uint32_t pv1 = pb_ & valid, pv0 = ~pb_ & valid;
-#pragma unroll
-                    for (int c = 0; c < NC; c++) {
-                        if (c < tk.ncfg) {
-                            const uint32_t e0 = ge_thr(T, thr0[c]) ^ inv0[c], e1 = ge_thr(T, thr1[c]) ^ inv1[c];
-                            nerr[c] += __builtin_popcount((pv1 & e1) | (pv0 & e0));
-                        }
-                    }
-                } else {
-                    // X = bit ? ~T : T; error <=> X >= thrx (bit = 1) / X >= thrx + strict0 (bit = 0): ONE scan per
-                    // setting, started from `bit | eq` (an LSB-first scan started from 0 yields the strict comparison)
-                    uint32_t X[8];
-#pragma unroll
-                    for (int q = 0; q < 8; q++) X[q] = T[q] ^ pb_;
-#pragma unroll
-                    for (int c = 0; c < kPerPass; c++) {
-                        // (settings beyond ncfg are evaluated too, on a copy of the last one: no branch per setting;
-                        // their counters are never read)
-                        const int cc = pass * kPerPass + c;
-                        if (cc < NC) {
-                            uint32_t ge = pb_ | eqm[c];
-#pragma unroll
-                            for (int q = 0; q < 8; q++) ge = __builtin_amdgcn_bitop3_b32(X[q], ge, tmx[c][q], 0xD4);
-                            nerr[cc] += __builtin_popcount(ge & valid);
-                        }
-                    }
-                }
-            }
-        }
-    }
-    unsigned long long b64 = nbit;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) b64 += __shfl_xor(b64, off, 64);
-#pragma unroll
-    for (int c = 0; c < NC; c++) {
-        if (c < tk.ncfg) {
-            unsigned long long e64 = nerr[c];
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) e64 += __shfl_xor(e64, off, 64);
-            if (lane == 0) {
-                atomicAdd(&counters[2 * c], b64);
-                if (e64) atomicAdd(&counters[2 * c + 1], e64);
-            }
-        }
-    }
-}
-
 
 // ---------------------------------------------------------------------------------------------
-// The fused trial kernel, PLANES generation (round 4).  ber256_kernel above (kept for the A/B runs of the experiments build)
-// is the round-1 design: the budget-180 step (242 AGPR moves), eight steps of count planes staged through LDS, a comparator
-// loop of its own per round, the PRBS planes in a circular LDS buffer with scalar index arithmetic: 1368 issued VALU
-// instructions per step and wave (SQ_INSTS_VALU, profiles/r04_ber_old_pmc.json) where the sample kernel of the stream
-// needs 1061.  This one is the sample kernel's loop -- lutopt256_step_parked_ber, no round end, no LDS staging -- with the
+// The fused trial kernel, PLANES generation (round 4).  Its predecessor (rounds 1-3: docs/DESIGN_rounds_1_2.md) used the
+// budget-180 step (242 AGPR moves), staged eight steps of count planes through LDS for a comparator loop of its own per round
+// and kept the PRBS planes in a circular LDS buffer with scalar index arithmetic: 1368 issued VALU instructions per step and
+// wave (SQ_INSTS_VALU, profiles/r04_ber_old_pmc.json) where the sample kernel of the stream needs 1061.  This one is the
+// sample kernel's loop -- lutopt256_step_parked_ber, no round end, no LDS staging -- with the
 // comparators run on the count planes while they are still in registers:
 //   X[q] = (T[q] ^ bit) & valid                      8 V_BITOP3 per step (T[7] = ~cnt[7]: folded into the truth table)
 //   per setting  ge = (bit | eq) & valid             1
@@ -233,14 +48,14 @@ extern "C" int bbb_exp_ber_debug_read(unsigned long long *out) { return (int)hip
 #define BBB_BER_STAMP(i)
 #endif
 struct TrialF {
-    int32_t k, tap, ncfg;
+    int32_t k, tap, ncfg, save;     // save: leave the generator's and the PRBS state behind (a continued trial)
     uint32_t L, last_len;
     unsigned long long G, nbits;
 };
 
 template <int MODE, int NC>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
-ber256_fused_kernel(BerMasks mk, const uint32_t *__restrict planes, const uint32_t *__restrict prbs_planes, TrialF tk, unsigned nlanes,
+ber256_fused_kernel(BerMasks mk, uint32_t *__restrict planes, uint32_t *__restrict prbs_planes, TrialF tk, unsigned nlanes,
                     unsigned long long *__restrict counters) {
     __shared__ uint32_t ring[64 * 64];
     const unsigned lane = threadIdx.x;
@@ -249,13 +64,21 @@ ber256_fused_kernel(BerMasks mk, const uint32_t *__restrict planes, const uint32
     __builtin_amdgcn_s_setprio(3);
     BBB_BER_STAMP(0);
 
+    // `planes` = the state OF the first sample (the host seeds one clock past the stream position: no advance in front of the
+    // loop, and a continued trial -- bbb_ber_run_* -- finds the state this kernel left); the parked planes go straight to
+    // their AGPRs (scalar base per plane + ONE 32-bit lane offset)
     uint32_t a[256], b[256], pa[256], pb[256], cnt[8];
-#pragma unroll
-    for (int p = 0; p < 256; p++) b[p] = planes[(size_t)p * nlanes + LG];
-    lutopt256_advance(b, a);
-#define BBB_PARK(p) BBB_ACC_WRITE(pa[p], a[p]);
-    LUTOPT256_FOR_PARKED_BER(BBB_PARK)
+    {
+        const uint32_t voff = (uint32_t)LG * 4u;
+#define BBB_PLANE(p) (*reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(planes + (size_t)(p) * nlanes) + (unsigned long long)voff))
+#define BBB_PARK(p) { const uint32_t v_ = BBB_PLANE(p); BBB_ACC_WRITE(pa[p], v_); }
+        LUTOPT256_FOR_PARKED_BER(BBB_PARK)
 #undef BBB_PARK
+#pragma unroll
+        for (int p = 0; p < 256; p++)
+            if (!lutopt256_ber_is_parked(p)) a[p] = BBB_PLANE(p);
+#undef BBB_PLANE
+    }
     // ring slot 31 - i (and its copy 63 - i) = b[-1 - i] = LFSR state bit i (prbs.py:34-35: the new bit enters at position 0)
     for (int i = 0; i < tk.k; i++) {
         const uint32_t v = prbs_planes[(size_t)i * nlanes + LG];
@@ -417,6 +240,16 @@ ber256_fused_kernel(BerMasks mk, const uint32_t *__restrict planes, const uint32
             if (e64) atomicAdd(&counters[2 * c + 1], e64);
         }
     }
+    if (tk.save) {
+        // L is even: the state of the NEXT sample is in a / pa.  Every lane rewrites its own words of the buffers it read.
+#define BBB_SAVE(p) { uint32_t v_; BBB_ACC_READ(v_, pa[p]); planes[(size_t)(p) * nlanes + LG] = v_; }
+        LUTOPT256_FOR_PARKED_BER(BBB_SAVE)
+#undef BBB_SAVE
+#pragma unroll
+        for (int p = 0; p < 256; p++)
+            if (!lutopt256_ber_is_parked(p)) planes[(size_t)p * nlanes + LG] = a[p];
+        for (int i = 0; i < tk.k; i++) prbs_planes[(size_t)i * nlanes + LG] = ring[((tk.L - 1u - (unsigned)i) & 31u) * 64 + lane];
+    }
     BBB_BER_STAMP(3);
     (void)mk;
 }
@@ -425,11 +258,11 @@ ber256_fused_kernel(BerMasks mk, const uint32_t *__restrict planes, const uint32
 // about a minute on each) and reached through ber_fused_go<MODE, NC>; a custom-matrix library (custom_fill_template.hip, ONE
 // unit, built at run time) instantiates a shorter list.
 template <int MODE, int NC>
-void ber_fused_go(const BerMasks &mk, const uint32_t *d_planes, const uint32_t *d_prbs_planes, const TrialF &tf, unsigned nlanes,
+void ber_fused_go(const BerMasks &mk, uint32_t *d_planes, uint32_t *d_prbs_planes, const TrialF &tf, unsigned nlanes,
                   unsigned long long *d_counters, hipStream_t st);
 #define BBB_BER_DEFINE_GO(MODE, NC)                                                                                              \
     template <>                                                                                                                  \
-    void ber_fused_go<MODE, NC>(const BerMasks &mk, const uint32_t *d_planes, const uint32_t *d_prbs_planes, const TrialF &tf,   \
+    void ber_fused_go<MODE, NC>(const BerMasks &mk, uint32_t *d_planes, uint32_t *d_prbs_planes, const TrialF &tf,   \
                                 unsigned nlanes, unsigned long long *d_counters, hipStream_t st) {                               \
         hipLaunchKernelGGL((ber256_fused_kernel<MODE, NC>), dim3(nlanes / 64), dim3(64), 0, st, mk, d_planes, d_prbs_planes, tf, \
                            nlanes, d_counters);                                                                                  \
@@ -437,7 +270,7 @@ void ber_fused_go(const BerMasks &mk, const uint32_t *d_planes, const uint32_t *
 
 #define BBB_BER_DECLARE_GO(MODE, NC)                                                                                              \
     template <>                                                                                                                   \
-    void ber_fused_go<MODE, NC>(const BerMasks &mk, const uint32_t *d_planes, const uint32_t *d_prbs_planes, const TrialF &tf,    \
+    void ber_fused_go<MODE, NC>(const BerMasks &mk, uint32_t *d_planes, uint32_t *d_prbs_planes, const TrialF &tf,    \
                                 unsigned nlanes, unsigned long long *d_counters, hipStream_t st);
 BBB_BER_DECLARE_GO(kBerFast, 1) BBB_BER_DECLARE_GO(kBerFast, 4) BBB_BER_DECLARE_GO(kBerFast, 12)
 BBB_BER_DECLARE_GO(kBerPair, 1) BBB_BER_DECLARE_GO(kBerPair, 4) BBB_BER_DECLARE_GO(kBerPair, 12) BBB_BER_DECLARE_GO(kBerGeneral, 1)
@@ -448,71 +281,59 @@ BBB_BER_DECLARE_GO(kBerFast, 11)
 
 #if BBB_BER_PART == 0
 // counters: [ncfg][2] contiguous.  All trials of the group share t[0]'s stream geometry.
-int ber256_launch(const uint32_t *d_planes, const uint32_t *d_prbs_planes, const TrialDev *t, int ncfg, unsigned nlanes,
+int ber256_launch(uint32_t *d_planes, uint32_t *d_prbs_planes, const TrialDev *t, int ncfg, unsigned nlanes,
                   unsigned long long *d_counters, hipStream_t st) {
     if (ncfg < 1 || ncfg > kMaxCfg) return fail(BBB_EINVAL, "bad trial group size");
-    TrialK tk{};
-    tk.k = t[0].prbs_k;
-    tk.tap = t[0].prbs_tap;
-    tk.ncfg = ncfg;
-    tk.L = t[0].L;
-    tk.G = t[0].G;
-    tk.last_len = (uint32_t)(t[0].nbits - (t[0].G - 1) * (uint64_t)t[0].L);
+    if (t[0].L & 1) return fail(BBB_EINVAL, "segment length must be even");
+    // thresholds strictly inside (0, 256) and the constant term of each bit value's parity
+    int nthr[kMaxCfg][2], inv[kMaxCfg][2], thr[kMaxCfg][2][4];
     for (int c = 0; c < ncfg; c++)
         for (int bv = 0; bv < 2; bv++) {
-            int n = 0, inv = 0;
+            int n = 0, iv = 0;
             for (int i = 0; i < t[c].nthr[bv]; i++) {
                 const int th = t[c].thr[bv][i];
-                if (th <= 0) { inv ^= 1; continue; }     // [T >= 0] is always true
-                if (th >= 256) continue;                 // [T >= 256] never
-                tk.thr[c][bv][n++] = (int16_t)th;
+                if (th <= 0) { iv ^= 1; continue; }     // [T >= 0] is always true
+                if (th >= 256) continue;                // [T >= 256] never
+                thr[c][bv][n++] = th;
             }
-            tk.nthr[c][bv] = (int8_t)n;
-            tk.inv[c][bv] = (int8_t)inv;
+            nthr[c][bv] = n;
+            inv[c][bv] = iv;
         }
     // the straight-line multi-setting kernel needs exactly one threshold per bit value
     bool simple = true;
     for (int c = 0; c < ncfg; c++)
-        for (int bv = 0; bv < 2; bv++) simple = simple && tk.nthr[c][bv] == 1;
+        for (int bv = 0; bv < 2; bv++) simple = simple && nthr[c][bv] == 1;
     // fast path: bit 0 errs when T >= thr0, bit 1 when T < thr1, and thr0 - (256 - thr1) is 0 or 1 (the two
-    // thresholds mirror each other up to the rounding of amp / noise_var): one comparison on X = bit ? ~T : T
+    // thresholds mirror each other up to the rounding of amp / noise_var): one comparison on X = bit ? ~T : T,
+    // X >= thrx (bit = 1) / X >= thrx + strict0 (bit = 0)
     bool fast = simple;
+    int thrx[kMaxCfg], strict0[kMaxCfg];
     for (int c = 0; c < ncfg && fast; c++) {
-        const int d = tk.thr[c][0][0] - (256 - tk.thr[c][1][0]);
-        fast = tk.inv[c][0] == 0 && tk.inv[c][1] == 1 && (d == 0 || d == 1);
-        tk.thrx[c] = (int16_t)(256 - tk.thr[c][1][0]);
-        tk.strict0[c] = (int8_t)d;
+        const int d = thr[c][0][0] - (256 - thr[c][1][0]);
+        fast = inv[c][0] == 0 && inv[c][1] == 1 && (d == 0 || d == 1);
+        thrx[c] = 256 - thr[c][1][0];
+        strict0[c] = d;
     }
     static const bool no_fast = env_knob("BBB_BER_NO_FAST", 0) != 0;     // (A/B timing of the two forms; -DBBB_EXPERIMENTS only)
     if (!simple && ncfg != 1) return fail(BBB_EINVAL, "grouped trials must be single-threshold");
     const int mode = fast && !no_fast ? kBerFast : simple ? kBerPair : kBerGeneral;
-#ifdef BBB_EXPERIMENTS
-    if (env_knob("BBB_BER_OLD", 0)) {        // the round-1 kernel (A/B timing and counters)
-        if (mode == kBerFast)
-            hipLaunchKernelGGL(ber256_kernel<kBerFast>, dim3(nlanes / 64), dim3(64), 0, st, d_planes, d_prbs_planes, tk, nlanes, d_counters);
-        else if (mode == kBerPair)
-            hipLaunchKernelGGL(ber256_kernel<kBerPair>, dim3(nlanes / 64), dim3(64), 0, st, d_planes, d_prbs_planes, tk, nlanes, d_counters);
-        else
-            hipLaunchKernelGGL(ber256_kernel<kBerGeneral>, dim3(nlanes / 64), dim3(64), 0, st, d_planes, d_prbs_planes, tk, nlanes, d_counters);
-        BBB_HIP(hipGetLastError());
-        return BBB_OK;
-    }
-#endif
     // the scalar masks of the comparators: bit q of a threshold as 0 / ~0
     BerMasks mk{};
-    auto bits = [](uint32_t *dst, int thr) {
-        for (int q = 0; q < 8; q++) dst[q] = (thr >> q) & 1 ? ~0u : 0u;
+    auto bits = [](uint32_t *dst, int th) {
+        for (int q = 0; q < 8; q++) dst[q] = (th >> q) & 1 ? ~0u : 0u;
     };
     TrialF tf{};
-    tf.k = tk.k; tf.tap = tk.tap; tf.ncfg = ncfg; tf.L = tk.L; tf.last_len = tk.last_len; tf.G = tk.G; tf.nbits = t[0].nbits;
+    tf.k = t[0].prbs_k; tf.tap = t[0].prbs_tap; tf.ncfg = ncfg; tf.L = t[0].L; tf.G = t[0].G; tf.nbits = t[0].nbits;
+    tf.save = (t[0].flags & kTrialSaveState) != 0;
+    tf.last_len = (t[0].flags & kTrialLastLen) ? t[0].last_len : (uint32_t)(t[0].nbits - (t[0].G - 1) * (uint64_t)t[0].L);
     if (mode == kBerGeneral) {
         for (int bv = 0; bv < 2; bv++) {
             for (int i = 0; i < 4; i++)
-                if (i < tk.nthr[0][bv]) {
-                    bits(mk.m[bv * 4 + i], tk.thr[0][bv][i]);
+                if (i < nthr[0][bv]) {
+                    bits(mk.m[bv * 4 + i], thr[0][bv][i]);
                     mk.m[bv * 4 + i][8] = ~0u;
                 }
-            mk.m[8][bv] = tk.inv[0][bv] ? ~0u : 0u;
+            mk.m[8][bv] = inv[0][bv] ? ~0u : 0u;
         }
         ber_fused_go<kBerGeneral, 1>(mk, d_planes, d_prbs_planes, tf, nlanes, d_counters, st);
     } else {
@@ -520,13 +341,13 @@ int ber256_launch(const uint32_t *d_planes, const uint32_t *d_prbs_planes, const
         for (int c = 0; c < kMaxCfg; c++) {
             const int s = c < ncfg ? c : ncfg - 1;
             if (mode == kBerFast) {
-                bits(mk.m[c], tk.thrx[s]);
-                mk.m[c][8] = tk.strict0[s] == 0 ? ~0u : 0u;
+                bits(mk.m[c], thrx[s]);
+                mk.m[c][8] = strict0[s] == 0 ? ~0u : 0u;
             } else {
-                bits(mk.m[c], tk.thr[s][0][0]);
-                bits(mk.m[c] + 8, tk.thr[s][1][0]);
-                mk.m[c][16] = tk.inv[s][0] ? ~0u : 0u;
-                mk.m[c][17] = tk.inv[s][1] ? ~0u : 0u;
+                bits(mk.m[c], thr[s][0][0]);
+                bits(mk.m[c] + 8, thr[s][1][0]);
+                mk.m[c][16] = inv[s][0] ? ~0u : 0u;
+                mk.m[c][17] = inv[s][1] ? ~0u : 0u;
             }
         }
 #define BBB_GO(MODE, NC) ber_fused_go<MODE, NC>(mk, d_planes, d_prbs_planes, tf, nlanes, d_counters, st)

@@ -122,7 +122,7 @@ std::string &last_error() {
 #define BBB_BER_PART 0
 #define BBB_BER_FEW_INSTANCES 1
 #include "ber_kernels_impl.hpp"
-extern "C" int bbb_custom_ber(const uint32_t *planes_dev, const uint32_t *prbs_planes_dev, const void *trials, int ncfg,
+extern "C" int bbb_custom_ber(uint32_t *planes_dev, uint32_t *prbs_planes_dev, const void *trials, int ncfg,
                               uint32_t nlanes, uint64_t *counters_dev, void *hip_stream) {
     return bbb::ber256_launch(planes_dev, prbs_planes_dev, (const bbb::TrialDev *)trials, ncfg, nlanes,
                               (unsigned long long *)counters_dev, (hipStream_t)hip_stream);

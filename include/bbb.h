@@ -235,8 +235,10 @@ typedef int (*bbb_custom_fill_fn)(const uint32_t *planes_dev, int8_t *dst_dev, u
                                   uint32_t nlanes, void *hip_stream);
 int bbb_lutopt_set_custom_fill(bbb_lutopt *h, bbb_custom_fill_fn fn);
 /* The same for the fused BER trial (k = 256 only): `trials` points at the library's internal per-trial records
- * (csrc/awgn_launch.hpp, TrialDev) and is passed through unchanged; returns 0 or a BBB_E* code. */
-typedef int (*bbb_custom_ber_fn)(const uint32_t *planes_dev, const uint32_t *prbs_planes_dev, const void *trials, int ncfg,
+ * (csrc/awgn_launch.hpp, TrialDev) and is passed through unchanged; returns 0 or a BBB_E* code.  Here planes_dev holds
+ * the state OF the first sample (one clock further than for the sample kernel), and a continued trial (bbb_ber_run_*)
+ * has the kernel write the states it ends in back to both buffers. */
+typedef int (*bbb_custom_ber_fn)(uint32_t *planes_dev, uint32_t *prbs_planes_dev, const void *trials, int ncfg,
                                  uint32_t nlanes, uint64_t *counters_dev, void *hip_stream);
 int bbb_lutopt_set_custom_ber(bbb_lutopt *h, bbb_custom_ber_fn fn);
 /* Load a library built from csrc/custom_fill_template.hip for THIS handle's matrix (basebandboard_amd/
@@ -273,6 +275,28 @@ int bbb_ber_trials(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, bbb_ber *
 /* Same, adding into device counters counters_dev[2*i] (bits), [2*i+1] (errors) without
  * synchronising -- the buffer a multi-GPU host hands to one RCCL all-reduce (ncclUint64, sum). */
 int bbb_ber_trials_dev(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, uint64_t *counters_dev);
+
+/* A trial group CONTINUED over several calls (round 4).  One bbb_ber_trials call spends 0.16 ms in front of its kernel on
+ * the start states of 2 M generators, whatever its length; a Monte-Carlo run that keeps adding bits until it has seen
+ * enough errors pays that per call.  Here a BLOCK of calls_per_block (m) calls shares ONE seeding: the block's m * nbits
+ * bits are cut into the generators' segments once, call c runs the c-th m-th of every segment and the kernel leaves the
+ * generators' and the PRBS states where the next call finds them (in buffers the run owns: other calls on the handle do
+ * not disturb it).  cfgs: up to BBB_BER_MAX_GROUP settings that share prbs_k, prbs_state, warmup, first_bit and nbits
+ * (= bits per call; single-threshold channels unless ncfg = 1) -- one pass over the noise stream serves all of them.
+ * Block b covers bits [first_bit + b m nbits, first_bit + (b + 1) m nbits).  The (bit, sample) pairs of a block are
+ * exactly those of one bbb_ber_trials call over it, visited in another order: after every m-th call the totals equal
+ * that call's counters bit for bit (between block ends a call may count up to one segment fewer or more bits than
+ * nbits; `bits` always says how many were counted).  The reference's counterpart is the free-running generator itself:
+ * one LFSR, one LUTOPT, clocked for as long as the test lasts (gateware/bbb/tx.py:56-81, prbs.py:32-35).
+ * _next: runs the next call on the handle's stream and returns the running totals of the whole run (host, synchronises;
+ * totals may be NULL: no read-back, no synchronisation).  _next_dev: ADDS the call's counters to counters_dev
+ * ([ncfg][2] uint64, device) without synchronising.  _tell: calls made so far / first bit of the next block to start. */
+typedef struct bbb_ber_run bbb_ber_run;
+int bbb_ber_run_open(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, uint32_t calls_per_block, bbb_ber_run **out);
+int bbb_ber_run_next(bbb_ber_run *r, bbb_ber *totals);
+int bbb_ber_run_next_dev(bbb_ber_run *r, uint64_t *counters_dev);
+int bbb_ber_run_tell(const bbb_ber_run *r, uint64_t *calls_done, uint64_t *next_block_first_bit);
+int bbb_ber_run_close(bbb_ber_run *r);
 
 /* The sweep sharded over the GPUs of ONE process (BASELINE.json configs[4]).  The
  * reference's only multi-worker program has this shape -- workers plus one channel back,

@@ -292,3 +292,61 @@ def test_thread_per_device_body_rehearsed_on_one_gpu():
         got, tot = res[f"seeds{nd}"]
         assert got == tot and got != res["want"]
         assert res[f"device{nd}"] == 0
+
+
+# ---- a trial group continued over several calls (bbb_ber_run_*) -------------------------------------------------
+
+@pytest.mark.parametrize("k,nper,m,first", [(31, 100_003, 4, 0), (7, 12_345, 3, 77), (20, 70_000, 1, 5), (23, 262_144, 8, 1 << 20)])
+def test_continued_trials_equal_one_trial_over_the_block(gpu, oracle, k, nper, m, first):
+    """After every m-th call the totals of a continued run are those of ONE trial over the blocks so far -- against the
+    oracle (sequential CPU restatement) and against bbb_ber_trials on the same ranges."""
+    u = gpu.LUTOPT.shipped(256, init=0x1234567)
+    settings = [(100, 8), (64, 8), (37, 3)]
+    ts = [gpu.Trial(nbits=nper, amp=a, noise_var=nv, prbs_k=k, prbs_state=5, warmup=16, first_bit=first) for a, nv in settings]
+    m_or = oracle.Lutopt(path=oracle.data_path(256))
+    with gpu.ContinuedTrials(u, ts, m) as run:
+        seen = []
+        for call in range(2 * m):
+            tot = run.next()
+            seen.append(tot)
+            if (call + 1) % m == 0:
+                nb = (call + 1) * nper
+                for (bits, errs), (a, nv) in zip(tot, settings):
+                    assert (bits, errs) == m_or.ber_trial(0x1234567, k, 5, a, nv, 16, first, nb)
+                whole = gpu.run_trials(u, [gpu.Trial(nbits=nb, amp=a, noise_var=nv, prbs_k=k, prbs_state=5, warmup=16, first_bit=first)
+                                           for a, nv in settings])
+                assert tot == whole
+        assert run.tell() == (2 * m, first + 2 * m * nper)
+        # between block ends every call adds about nper bits, and the counters never go down
+        for prev, cur in zip(seen, seen[1:]):
+            for (b0, e0), (b1, e1) in zip(prev, cur):
+                assert 0 < b1 - b0 <= nper + 2 * m * 64 and e1 >= e0
+
+
+def test_continued_trials_leave_the_handle_alone(gpu, oracle):
+    """Other calls on the handle between two calls of a run (a fill, other trials, a staged stream) do not disturb it: the run
+    owns its state buffers."""
+    u = gpu.LUTOPT.shipped(256)
+    g = gpu.CLTGRNG(u)
+    t = gpu.Trial(nbits=50_000, amp=90, noise_var=8)
+    m_or = oracle.Lutopt(path=oracle.data_path(256))
+    c = torch.zeros((1, 2), dtype=torch.int64, device="cuda")
+    with gpu.ContinuedTrials(u, [t], 3) as run:
+        for call in range(3):
+            run.next_into(c)
+            g.generate(100_000, first_step=123)
+            gpu.run_trials(u, [gpu.Trial(nbits=33_333, amp=50, noise_var=5, first_bit=9)])
+        torch.cuda.synchronize()
+    assert tuple(c.cpu().tolist()[0]) == m_or.ber_trial(1, 31, 1, 90, 8, 16, 0, 150_000)
+
+
+def test_continued_trials_reject_mixed_groups(gpu):
+    u = gpu.LUTOPT.shipped(256)
+    with pytest.raises(ValueError):
+        gpu.ContinuedTrials(u, [gpu.Trial(nbits=10, amp=10, noise_var=1), gpu.Trial(nbits=11, amp=10, noise_var=1)], 2)
+    with pytest.raises(ValueError):
+        gpu.ContinuedTrials(u, [gpu.Trial(nbits=10, amp=10, noise_var=1)], 0)
+    with pytest.raises(ValueError):       # a wrap-around setting cannot share a launch
+        gpu.ContinuedTrials(u, [gpu.Trial(nbits=1000, amp=1900, noise_var=15), gpu.Trial(nbits=1000, amp=10, noise_var=1)], 2)
+    with gpu.ContinuedTrials(u, [gpu.Trial(nbits=1000, amp=1900, noise_var=15)], 2) as run:      # alone it runs (general kernel)
+        assert run.next()[0][0] > 0
