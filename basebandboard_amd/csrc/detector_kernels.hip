@@ -103,13 +103,20 @@ template <int K> struct DetLag {
 };
 struct DetAux { u64 fh[3]; int n; };          // fh[NH-1] = the newest feedback word; n = how many are valid
 
-// 64 bits of the history starting at bit OFF (bit 0 = the oldest bit of fh[0])
+// 64 bits of the history starting at bit OFF (bit 0 = the oldest bit of fh[0]): two V_ALIGNBIT_B32 over three of the
+// history's dwords (a 64-bit shift pair + OR costs five to six instructions, two of them quarter rate)
 template <int OFF, int NH>
 __device__ __forceinline__ u64 det_hist_window(const u64 (&fh)[3]) {
-    constexpr int i = OFF / 64, sh = OFF % 64;
-    static_assert(i < NH && (sh == 0 || i + 1 < NH), "window must lie inside the history");
-    if (sh == 0) return fh[i];
-    return (fh[i] >> sh) | (fh[i + 1] << (64 - sh));
+    constexpr int i = OFF / 32, sh = OFF % 32;
+    static_assert(OFF >= 0 && OFF + 64 <= 64 * NH, "window must lie inside the history");
+    auto dw = [&](int j) -> uint32_t { return (j & 1) ? (uint32_t)(fh[j >> 1] >> 32) : (uint32_t)fh[j >> 1]; };
+    if constexpr (sh == 0) {
+        return (u64)dw(i) | ((u64)dw(i + 1) << 32);
+    } else {
+        const uint32_t lo = __builtin_amdgcn_alignbit(dw(i + 1), dw(i), sh);
+        const uint32_t hi = __builtin_amdgcn_alignbit(dw(i + 2), dw(i + 1), sh);
+        return (u64)lo | ((u64)hi << 32);
+    }
 }
 
 template <int K, bool EMIT>
@@ -231,12 +238,63 @@ __device__ __forceinline__ void det_span(DetState &s, const u64 *__restrict src,
 // The same for a whole wave of 64 consecutive full chunks: the 64 lanes' next 16 words (128 bytes each) are fetched
 // together as 64 full lines (8 load instructions, each covering 8 rows) into LDS and every lane then reads its own
 // row -- one line request per 128 bytes instead of one per 16 bytes.  [first, first + nw) per lane, nw a multiple of 16.
-template <int K, bool EMIT>
+// OUT: the err / reload words are wanted (a totals-only call holds none of the 16 words' outputs: 96 registers less, twice the
+// waves per SIMD -- the chunk pass is bound by the latency of its tile loads, not by its instructions)
+template <int K, bool EMIT, bool OUT>
 __device__ __forceinline__ void det_span_tiled(DetState &s, const u64 *__restrict src, u64 first_row0, u64 row_stride, u64 nw,
                                                u64 my_first, u64 nbits, u64 *__restrict err, u64 *__restrict reload,
                                                DetCount &cnt, u64x2 (*tile)[9], unsigned lane) {
     DetAux a;
     a.n = 0;
+    // The CLEAN word (round 4).  In the streams this detector is made for almost every word is error free while the detector
+    // is locked with an empty error history.  Then nothing of the machine moves but the free-running LFSR, and its next 64
+    // feedback bits are a function of the last NH feedback words -- which, on a clean stretch, are the (one bit delayed)
+    // input words themselves.  So a lane in that state (`clean`: reload_ctr == 0, err_sr == 0, history valid) keeps NO
+    // DetState: per word it forms V = the input delayed by the bit_in register, predicts F from the history (four
+    // V_ALIGNBIT + two XOR) and compares; equal -> the outputs are zero, the counters stand, the history shifts: ~12
+    // instructions where the general word-at-once path (popcounts, state and history bookkeeping, output formulae,
+    // 64-bit counters, exec-mask handling) takes 80-110.  When every lane of the wave is clean the general path is skipped by
+    // a scalar branch.  A lane whose word is not clean re-creates the DetState the general path would hold (prbs = the top K
+    // bits of the newest feedback word, bit-reversed; err_sr = 0; reload_ctr = 0; bit_in) and goes through det_core as before;
+    // it is clean again after the first word that leaves it locked with an empty history.
+    typedef DetLag<K> LGc;
+    constexpr uint32_t MASKc = (uint32_t)((1ull << K) - 1ull);
+    bool clean = false;
+    uint32_t cbit = 0;                               // the bit_in register while `clean`
+    auto materialise = [&]() {
+        if constexpr (LGc::OK) {
+            s.prbs = __builtin_bitreverse32((uint32_t)(a.fh[LGc::NH - 1] >> 32)) & MASKc;
+            s.err_sr = 0; s.reload_ctr = 0; s.bit_in = cbit;
+        }
+    };
+    auto step = [&](u64 widx, u64 word, u64 &ew, u64 &rw) {
+        if constexpr (LGc::OK) {
+            const u64 V = (word << 1) | (u64)cbit;
+            const u64 Fp = det_hist_window<64 * LGc::NH - LGc::LAGK, LGc::NH>(a.fh) ^ det_hist_window<64 * LGc::NH - LGc::LAGT, LGc::NH>(a.fh);
+            // ... and the `err` output after the word's LAST clock is this word's last input bit against the NEXT feedback bit,
+            // x[t+64] = V[64-K] ^ V[64-TAP] on a clean word: an input error in bit 63 shows there and nowhere in V
+            const uint32_t vh = (uint32_t)(V >> 32);
+            const uint32_t last = (uint32_t)(word >> 32) ^ (vh << (K - 1)) ^ (vh << (det_tap_of(K) - 1));      // bit 31 = err after clock 63
+            const bool ok = clean && V == Fp && (int32_t)last >= 0;
+            if (ok) {
+#pragma unroll
+                for (int i = 0; i + 1 < LGc::NH; i++) a.fh[i] = a.fh[i + 1];
+                a.fh[LGc::NH - 1] = V;
+                cbit = (uint32_t)(word >> 63);
+                ew = 0; rw = 0;
+            }
+            if (__all(ok)) return;                   // (wave uniform: the whole wave is on a clean stretch)
+            if (!ok) {
+                if (clean) materialise();
+                clean = false;
+                det_core<K, EMIT, true>(s, a, widx, word, nbits, ew, rw, cnt);
+                cbit = s.bit_in;
+                clean = s.reload_ctr == 0 && s.err_sr == 0 && a.n >= LGc::NH;
+            }
+        } else {
+            det_core<K, EMIT, true>(s, a, widx, word, nbits, ew, rw, cnt);
+        }
+    };
     auto sync = [] { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
     // the tile written back the same way: 64 whole lines per 8 store instructions
     auto store_tile = [&](u64 *__restrict out, u64 off) {
@@ -259,14 +317,15 @@ __device__ __forceinline__ void det_span_tiled(DetState &s, const u64 *__restric
 #pragma unroll
         for (int p = 0; p < 8; p++) in[p] = tile[lane][p];
         sync();                                    // every lane has its row: the tile can take the outputs
-        u64x2 eo[8], ro[8];
+        u64x2 eo[OUT ? 8 : 1], ro[OUT ? 8 : 1];
 #pragma unroll
         for (int p = 0; p < 8; p++) {
             u64 e0, r0, e1, r1;
-            det_core<K, EMIT, true>(s, a, my_first + off + 2 * p, in[p].x, nbits, e0, r0, cnt);
-            det_core<K, EMIT, true>(s, a, my_first + off + 2 * p + 1, in[p].y, nbits, e1, r1, cnt);
-            eo[p].x = e0; eo[p].y = e1; ro[p].x = r0; ro[p].y = r1;
+            step(my_first + off + 2 * p, in[p].x, e0, r0);
+            step(my_first + off + 2 * p + 1, in[p].y, e1, r1);
+            if constexpr (OUT) { eo[p].x = e0; eo[p].y = e1; ro[p].x = r0; ro[p].y = r1; }
         }
+        if constexpr (!OUT) continue;
         if (EMIT && err) {
 #pragma unroll
             for (int p = 0; p < 8; p++) tile[lane][p] = eo[p];
@@ -278,11 +337,244 @@ __device__ __forceinline__ void det_span_tiled(DetState &s, const u64 *__restric
             store_tile(reload, off);
         }
     }
+    if (clean) materialise();
+}
+
+// ---------------------------------------------------------------------------------------------
+// The SPARSE form of the chunk pass (round 4).  The clean-word test above reads nothing but input words: with V_n = the input
+// delayed by one bit (word n shifted left, the top bit of word n - 1 below it), a locked detector with an empty error history
+// whose last NH feedback words were the inputs themselves finds word n clean exactly when
+//     V_n == R(V_{n-1}, ..., V_{n-NH})   and   bit 63 of word n == V_n[64-K] ^ V_n[64-TAP]
+// -- a STATELESS predicate of words n - NH - 1 ... n.  So the stream is classified first, by a streaming kernel that reads
+// it once at memory speed and leaves one flag per word (det_classify_kernel: 1/64 of the stream's size), and the serial
+// machine then runs only where it has to: a lane in the clean state with NH clean words behind it looks up the next unset
+// flag of its chunk and JUMPS there, re-creating its history from the NH + 1 input words in front of the target; everything
+// else -- reloads, words with errors, the NH words after one (whose true feedback words differ from the inputs) -- goes
+// through the same per-word code as before.  At 1e-3 errors per word a 512-word chunk is ~10 words of work and five cache
+// lines instead of 528 words: the call becomes the classification pass.  Outputs, when asked for, are zeroed first and
+// written for the words the machine visited.  K = 20 (ten history words) keeps the dense pass.
+// ---------------------------------------------------------------------------------------------
+// Flags: two 64-bit masks per block of 128 words, flags[2 b] = the EVEN words of the block (bit i = word 128 b + 2 i),
+// flags[2 b + 1] = the odd ones -- the shape in which two ballots of a wave that holds 16 bytes per lane deliver them.
+template <int K>
+__global__ void __launch_bounds__(256)
+det_classify_kernel(const u64 *__restrict src, u64 nbits, u64 nwords, u64 *__restrict flags) {
+    typedef DetLag<K> LG;
+    constexpr int NH = LG::NH, TAP = det_tap_of(K);
+    const unsigned lane = threadIdx.x & 63;
+    const u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
+    const u64 nfull = nbits / 64;                    // words with all 64 bits inside the stream
+    auto load2 = [&](const u64 i) -> u64x2 {         // words i, i + 1, read once: non-temporal (the stream's last word may stand alone)
+        if (i + 1 < nwords) return __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(src + i));
+        return (u64x2){i < nwords ? src[i] : 0ull, 0ull};
+    };
+    // lane t holds words base + 2t, base + 2t + 1 (one 16-byte load: 1 KiB per wave) and the same 128 words further; the four
+    // words in front of the block sit in lanes 62, 63 of `h`.  The next block's loads are in flight while this one is judged.
+    u64 base = ((((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6)) * 256;
+    u64x2 n0 = {0, 0}, n1 = {0, 0}, nh = {0, 0};
+    if (base < nwords) {
+        n0 = load2(base + 2 * lane); n1 = load2(base + 128 + 2 * lane);
+        if (lane >= 62 && base >= 128) nh = load2(base - 128 + 2 * lane);
+    }
+    for (; base < nwords; base += nwaves * 256) {
+        const u64x2 a0 = n0, a1 = n1, h = nh;
+        const u64 nb = base + nwaves * 256;
+        if (nb < nwords) {
+            n0 = load2(nb + 2 * lane); n1 = load2(nb + 128 + 2 * lane);
+            if (lane >= 62) nh = load2(nb - 128 + 2 * lane);
+        }
+        auto pair_flags = [&](const u64x2 cur, const u64x2 lower, const u64 first, bool &fe, bool &fo) {
+            // first = index of cur.x.  w[j] = word n0 + 1 - j, j = 0 .. NH + 2, from this lane and the two below it
+            const int l1 = (int)((lane - 1u) & 63u), l2 = (int)((lane - 2u) & 63u);
+            const u64 c1x = __shfl(cur.x, l1, 64), c1y = __shfl(cur.y, l1, 64), b1x = __shfl(lower.x, l1, 64), b1y = __shfl(lower.y, l1, 64);
+            const u64 c2x = __shfl(cur.x, l2, 64), c2y = __shfl(cur.y, l2, 64), b2x = __shfl(lower.x, l2, 64), b2y = __shfl(lower.y, l2, 64);
+            u64 w[6];
+            w[0] = cur.y; w[1] = cur.x;
+            w[2] = lane >= 1 ? c1y : b1y; w[3] = lane >= 1 ? c1x : b1x;
+            w[4] = lane >= 2 ? c2y : b2y; w[5] = lane >= 2 ? c2x : b2x;
+            auto one = [&](const int o, const u64 n) -> bool {          // the word w[o], index n
+                u64 fh[3] = {0, 0, 0};
+#pragma unroll
+                for (int q = 0; q < NH; q++) fh[q] = (w[o + NH - q] << 1) | (w[o + NH - q + 1] >> 63);       // fh[NH-1] = V_{n-1}
+                const u64 V = (w[o] << 1) | (w[o + 1] >> 63);
+                const u64 Fp = det_hist_window<64 * NH - LG::LAGK, NH>(fh) ^ det_hist_window<64 * NH - LG::LAGT, NH>(fh);
+                const uint32_t vh = (uint32_t)(V >> 32);
+                const uint32_t last = (uint32_t)(w[o] >> 32) ^ (vh << (K - 1)) ^ (vh << (TAP - 1));
+                return V == Fp && (int32_t)last >= 0 && n >= (u64)(NH + 1) && n < nfull;
+            };
+            static_assert(NH + 2 <= 5, "the two lanes below hold the words a flag needs");
+            fo = one(0, first + 1);
+            fe = one(1, first);
+        };
+        bool e0, o0, e1, o1;
+        pair_flags(a0, h, base + 2 * lane, e0, o0);
+        pair_flags(a1, a0, base + 128 + 2 * lane, e1, o1);
+        const u64 me0 = __ballot(e0), mo0 = __ballot(o0), me1 = __ballot(e1), mo1 = __ballot(o1);
+        if (lane == 0) {
+            *reinterpret_cast<u64x2 *>(flags + (base >> 6)) = (u64x2){me0, mo0};
+            if (base + 128 < nwords) *reinterpret_cast<u64x2 *>(flags + (base >> 6) + 2) = (u64x2){me1, mo1};
+        }
+    }
+}
+
+// A lane's view of the flags: the blocks of its chunk (and the one in front of it) fetched together into registers when the
+// lane starts -- one round trip instead of one per jump -- and memory for anything outside that window.
+struct DetFlags {
+    static constexpr int kWin = 6;
+    const u64 *mem;
+    u64 b0;
+    int n;
+    u64x2 f[kWin];
+    __device__ __forceinline__ void fetch(const u64 *flags, u64 first_block, u64 last_block) {
+        mem = flags; b0 = first_block;
+        n = last_block - first_block + 1 > (u64)kWin ? kWin : (int)(last_block - first_block + 1);
+#pragma unroll
+        for (int i = 0; i < kWin; i++) f[i] = i < n ? *reinterpret_cast<const u64x2 *>(flags + 2 * (first_block + (u64)i)) : (u64x2){0, 0};
+    }
+    __device__ __forceinline__ u64x2 block(u64 b) const {
+        if (b - b0 < (u64)n) {
+            u64x2 r = f[0];
+#pragma unroll
+            for (int i = 1; i < kWin; i++) r = (b - b0 == (u64)i) ? f[i] : r;
+            return r;
+        }
+        return *reinterpret_cast<const u64x2 *>(mem + 2 * b);
+    }
+};
+
+// the first word at or after w, below w1, whose flag is not set (w1 if there is none)
+__device__ __forceinline__ u64 det_next_unflagged(const DetFlags &fl, u64 w, u64 w1) {
+    for (u64 b = w >> 7; b <= (w1 - 1) >> 7; b++) {
+        const u64x2 f = fl.block(b);
+        u64 de = ~f.x, dn = ~f.y;                    // unset among the even / the odd words of block b
+        if (b == (w >> 7)) {
+            const unsigned r = (unsigned)(w & 127);
+            const unsigned se = (r + 1) >> 1, so = r >> 1;       // even word 2 i >= r <=> i >= ceil(r / 2); odd 2 i + 1 >= r <=> i >= floor(r / 2)
+            de = se >= 64 ? 0ull : de & (~0ull << se);
+            dn &= ~0ull << so;
+        }
+        const u64 ce = de ? 2ull * (u64)__builtin_ctzll(de) : 1000ull, co = dn ? 2ull * (u64)__builtin_ctzll(dn) + 1 : 1000ull;
+        const u64 c = ce < co ? ce : co;
+        if (c < 1000ull) {
+            const u64 cand = b * 128 + c;
+            return cand < w1 ? cand : w1;
+        }
+    }
+    return w1;
+}
+
+// what a lane carries from word to word in the sparse pass
+struct DetCtx { DetAux a; bool clean; uint32_t cbit; int vrun; };     // vrun: clean words in a row just passed (saturates at NH)
+
+// words [w0, w1) from state s: jumps over flagged stretches, the per-word machine elsewhere
+template <int K, bool EMIT>
+__device__ __forceinline__ void det_span_sparse(DetState &s, DetCtx &x, const u64 *__restrict src, const DetFlags &flags, u64 w0,
+                                                u64 w1, u64 nbits, u64 *__restrict err, u64 *__restrict reload, DetCount &cnt) {
+    typedef DetLag<K> LG;
+    constexpr int NH = LG::NH, TAP = det_tap_of(K);
+    constexpr uint32_t MASK = (uint32_t)((1ull << K) - 1ull);
+    const u64 nfull = nbits / 64;
+    u64 w = w0;
+    while (w < w1) {
+        if (x.clean && x.vrun >= NH) {
+            const u64 j = det_next_unflagged(flags, w, w1);
+            if (j > w) {
+                // every word of [w, j) is clean for a machine in this state: go to j with the history those words leave
+                // (a flagged word has index >= NH + 1: the loads stay inside the stream)
+                u64 ww[NH + 1];
+#pragma unroll
+                for (int q = 0; q <= NH; q++) ww[q] = src[j - 1 - (u64)NH + (u64)q];
+#pragma unroll
+                for (int q = 0; q < NH; q++) x.a.fh[q] = (ww[q + 1] << 1) | (ww[q] >> 63);
+                x.a.n = NH;
+                x.cbit = (uint32_t)(ww[NH] >> 63);
+                w = j;
+                continue;
+            }
+        }
+        const u64 word = src[w];
+        u64 ew = 0, rw = 0;
+        bool ok = false;
+        if (x.clean && w < nfull) {
+            const u64 V = (word << 1) | (u64)x.cbit;
+            const u64 Fp = det_hist_window<64 * NH - LG::LAGK, NH>(x.a.fh) ^ det_hist_window<64 * NH - LG::LAGT, NH>(x.a.fh);
+            const uint32_t vh = (uint32_t)(V >> 32);
+            const uint32_t last = (uint32_t)(word >> 32) ^ (vh << (K - 1)) ^ (vh << (TAP - 1));
+            ok = V == Fp && (int32_t)last >= 0;
+            if (ok) {
+#pragma unroll
+                for (int i = 0; i + 1 < NH; i++) x.a.fh[i] = x.a.fh[i + 1];
+                x.a.fh[NH - 1] = V;
+                x.cbit = (uint32_t)(word >> 63);
+                x.vrun = x.vrun < NH ? x.vrun + 1 : NH;
+            }
+        }
+        if (!ok) {
+            if (x.clean) {
+                s.prbs = __builtin_bitreverse32((uint32_t)(x.a.fh[NH - 1] >> 32)) & MASK;
+                s.err_sr = 0; s.reload_ctr = 0; s.bit_in = x.cbit;
+            }
+            det_core<K, EMIT>(s, x.a, w, word, nbits, ew, rw, cnt);
+            x.cbit = s.bit_in;
+            x.clean = s.reload_ctr == 0 && s.err_sr == 0 && x.a.n >= NH;
+            x.vrun = 0;
+        }
+        if (EMIT) {                                  // (a clean word's outputs are zero: the arrays were zeroed)
+            if (err && ew) err[w] = ew;
+            if (reload && rw) reload[w] = rw;
+        }
+        w++;
+    }
+    if (x.clean) {
+        s.prbs = __builtin_bitreverse32((uint32_t)(x.a.fh[NH - 1] >> 32)) & MASK;
+        s.err_sr = 0; s.reload_ctr = 0; s.bit_in = x.cbit;
+    }
+}
+
+// the speculative run of every chunk (det_chunk_kernel's mode 0) in the sparse form: one lane per chunk
+template <int K>
+__global__ void __launch_bounds__(256)
+det_sparse_kernel(const u64 *__restrict src, const u64 *__restrict flags, u64 nbits, u64 nwords, u64 chunk_words, u64 warm_words,
+                  u64 nchunks, DetState *__restrict spec, DetState *__restrict endst, DetCount *__restrict counts, u64 *__restrict err,
+                  u64 *__restrict reload) {
+    const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchunks) return;
+    const u64 w0 = c * chunk_words;
+    const u64 w1 = w0 + chunk_words < nwords ? w0 + chunk_words : nwords;
+    DetState s = det_reset(K);
+    DetCtx x;
+    x.a.n = 0; x.clean = false; x.cbit = 0; x.vrun = 0;
+    DetCount cnt = {0, 0, 0, 0}, dummy = {0, 0, 0, 0};
+    const u64 ws = w0 > warm_words ? w0 - warm_words : 0;     // ws == 0: the whole prefix is run, the start is exact
+    typedef DetLag<K> LGs;
+    constexpr int NHs = LGs::NH;
+    DetFlags fl;
+    fl.fetch(flags, (w0 >= (u64)NHs ? w0 - NHs : 0) >> 7, (w1 - 1) >> 7);
+    // The speculative start.  When the NH words in front of the chunk are flagged, a machine that was locked on them
+    // arrives in the clean state those words define: take that state without running anything (the verification against
+    // the predecessor's true end decides, as for every speculation).  Otherwise: the reset state `warm` bits earlier.
+    if (ws > 0 && w0 >= (u64)(2 * NHs + 2) && det_next_unflagged(fl, w0 - NHs, w0) == w0) {
+        u64 ww[NHs + 1];
+#pragma unroll
+        for (int q = 0; q <= NHs; q++) ww[q] = src[w0 - 1 - (u64)NHs + (u64)q];
+#pragma unroll
+        for (int q = 0; q < NHs; q++) x.a.fh[q] = (ww[q + 1] << 1) | (ww[q] >> 63);
+        x.a.n = NHs; x.clean = true; x.vrun = NHs;
+        x.cbit = (uint32_t)(ww[NHs] >> 63);
+        s.prbs = __builtin_bitreverse32((uint32_t)(x.a.fh[NHs - 1] >> 32)) & (uint32_t)((1ull << K) - 1ull);
+        s.err_sr = 0; s.reload_ctr = 0; s.bit_in = x.cbit;
+    } else {
+        det_span_sparse<K, false>(s, x, src, fl, ws, w0, nbits, nullptr, nullptr, dummy);
+    }
+    spec[c] = s;
+    det_span_sparse<K, true>(s, x, src, fl, w0, w1, nbits, err, reload, cnt);
+    endst[c] = s;
+    counts[c] = cnt;
 }
 
 // mode 0: speculative run of every chunk.  mode 1: re-run of the chunks in `list` from end[c-1].
-template <int K>
-__global__ void __launch_bounds__(256)
+template <int K, bool OUT>
+__global__ void __launch_bounds__(256, OUT ? 2 : 4)      // totals only: <= 128 registers, four waves per SIMD
 det_chunk_kernel(int mode, const u64 *__restrict src, u64 nbits, u64 nwords, u64 chunk_words, u64 warm_words,
                  u64 nchunks, const unsigned *__restrict list, unsigned nlist, DetState *__restrict spec,
                  DetState *__restrict endst, DetCount *__restrict counts, u64 *__restrict err, u64 *__restrict reload,
@@ -299,10 +591,10 @@ det_chunk_kernel(int mode, const u64 *__restrict src, u64 nbits, u64 nwords, u64
             DetState s = det_reset(K);
             DetCount cnt = {0, 0, 0, 0}, dummy = {0, 0, 0, 0};
             u64x2 (*tile)[9] = tiles[threadIdx.x >> 6];
-            det_span_tiled<K, false>(s, src, c0 * chunk_words - warm_words, chunk_words, warm_words, w0 - warm_words, nbits, nullptr,
+            det_span_tiled<K, false, false>(s, src, c0 * chunk_words - warm_words, chunk_words, warm_words, w0 - warm_words, nbits, nullptr,
                                      nullptr, dummy, tile, lane);
             spec[c] = s;
-            det_span_tiled<K, true>(s, src, c0 * chunk_words, chunk_words, chunk_words, w0, nbits, err, reload, cnt, tile, lane);
+            det_span_tiled<K, true, OUT>(s, src, c0 * chunk_words, chunk_words, chunk_words, w0, nbits, err, reload, cnt, tile, lane);
             endst[c] = s;
             counts[c] = cnt;
             return;
@@ -470,9 +762,10 @@ static int detector_stream_k(const u64 *src, u64 nbits, u64 *err, u64 *reload, b
     const u64 nchunks = (nwords + chunk_words - 1) / chunk_words;
     if (nchunks > 0x7fffffffull) return fail(BBB_EINVAL, "too many chunks; raise chunk_bits");
     // one stream-ordered allocation: spec | endst | counts | list | nlist + totals
+    constexpr bool kSparse = DetLag<K>::OK;             // (K = 20: ten history words -- the dense pass)
     const size_t o_spec = 0, o_end = o_spec + nchunks * sizeof(DetState), o_cnt = o_end + nchunks * sizeof(DetState),
                  o_list = o_cnt + nchunks * sizeof(DetCount), o_tail = (o_list + 2 * nchunks * sizeof(unsigned) + 7) & ~(size_t)7,
-                 total = o_tail + 16 * sizeof(u64);
+                 o_flags = (o_tail + 16 * sizeof(u64) + 15) & ~(size_t)15, total = o_flags + (kSparse ? ((nwords + 255) / 256) * 4 * sizeof(u64) : 0);
     int ws_slot = -1;
     int rc_ws = det_ws_acquire(total, &ws_slot);
     if (rc_ws) return rc_ws;
@@ -493,8 +786,24 @@ static int detector_stream_k(const u64 *src, u64 nbits, u64 *err, u64 *reload, b
     const unsigned rgrid = grid < 512 ? grid : 512;
     // cooperative 128-byte loads need chunks and warm-up in whole 16-word rows on 16-byte aligned data
     const int tiles_ok = chunk_words % 16 == 0 && warm_words % 16 == 0 && warm_words > 0 && ((uintptr_t)src & 15) == 0;
-    hipLaunchKernelGGL(det_chunk_kernel<K>, dim3(grid), dim3(256), 0, st, 0, src, nbits, nwords, chunk_words, warm_words,
-                       nchunks, (const unsigned *)nullptr, 0u, spec, endst, counts, err, reload, tiles_ok, (const unsigned *)nullptr);
+    static const bool dense = env_knob("BBB_DET_DENSE", 0) != 0;          // (A/B timing of the two forms; -DBBB_EXPERIMENTS only)
+    if (kSparse && !dense && ((uintptr_t)src & 15) == 0) {
+        if constexpr (kSparse) {
+            u64 *flags = (u64 *)(ws + o_flags);
+            if (err) (void)hipMemsetAsync(err, 0, nwords * sizeof(u64), st);
+            if (reload) (void)hipMemsetAsync(reload, 0, nwords * sizeof(u64), st);
+            const u64 nblk = (nwords + 255) / 256;                        // one wave per 256 words, four waves per block
+            const unsigned cgrid = (unsigned)((nblk + 3) / 4 < 8192 ? (nblk + 3) / 4 : 8192);
+            hipLaunchKernelGGL(det_classify_kernel<K>, dim3(cgrid), dim3(256), 0, st, src, nbits, nwords, flags);
+            hipLaunchKernelGGL(det_sparse_kernel<K>, dim3(grid), dim3(256), 0, st, src, (const u64 *)flags, nbits, nwords, chunk_words,
+                               warm_words, nchunks, spec, endst, counts, err, reload);
+        }
+    } else if (err || reload)
+        hipLaunchKernelGGL((det_chunk_kernel<K, true>), dim3(grid), dim3(256), 0, st, 0, src, nbits, nwords, chunk_words, warm_words,
+                           nchunks, (const unsigned *)nullptr, 0u, spec, endst, counts, err, reload, tiles_ok, (const unsigned *)nullptr);
+    else
+        hipLaunchKernelGGL((det_chunk_kernel<K, false>), dim3(grid), dim3(256), 0, st, 0, src, nbits, nwords, chunk_words, warm_words,
+                           nchunks, (const unsigned *)nullptr, 0u, spec, endst, counts, err, reload, tiles_ok, (const unsigned *)nullptr);
     u64 rerun = 0, passes = 0;
     bool serial = false;
     u64 h[5] = {0, 0, 0, 0, 0};
@@ -508,7 +817,7 @@ static int detector_stream_k(const u64 *src, u64 nbits, u64 *err, u64 *reload, b
         (void)hipMemsetAsync(tail, 0, 16 * sizeof(u64), st);
         hipLaunchKernelGGL(det_reduce_kernel, dim3(rgrid), dim3(256), 0, st, nchunks, counts, tail, (const DetState *)spec,
                            (const DetState *)endst, list, nlist, (const unsigned *)nullptr);
-        hipLaunchKernelGGL(det_chunk_kernel<K>, dim3(kSpec / 256), dim3(256), 0, st, 1, src, nbits, nwords, chunk_words, warm_words,
+        hipLaunchKernelGGL((det_chunk_kernel<K, true>), dim3(kSpec / 256), dim3(256), 0, st, 1, src, nbits, nwords, chunk_words, warm_words,
                            nchunks, (const unsigned *)list, kSpec, spec, endst, counts, err, reload, 0, (const unsigned *)nlist);
         hipLaunchKernelGGL(det_reduce_kernel, dim3(rgrid), dim3(256), 0, st, nchunks, counts, tail2, (const DetState *)spec,
                            (const DetState *)endst, list2, nlist2, (const unsigned *)nlist);
@@ -559,7 +868,7 @@ static int detector_stream_k(const u64 *src, u64 nbits, u64 *err, u64 *reload, b
             continue;
         }
         rerun += nbad;
-        hipLaunchKernelGGL(det_chunk_kernel<K>, dim3((nbad + 255) / 256), dim3(256), 0, st, 1, src, nbits, nwords, chunk_words,
+        hipLaunchKernelGGL((det_chunk_kernel<K, true>), dim3((nbad + 255) / 256), dim3(256), 0, st, 1, src, nbits, nwords, chunk_words,
                            warm_words, nchunks, (const unsigned *)list, nbad, spec, endst, counts, err, reload, 0, (const unsigned *)nullptr);
     }
     cleanup();
