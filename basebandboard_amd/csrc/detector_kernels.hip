@@ -356,60 +356,71 @@ __device__ __forceinline__ void det_span_tiled(DetState &s, const u64 *__restric
 // ---------------------------------------------------------------------------------------------
 // Flags: two 64-bit masks per block of 128 words, flags[2 b] = the EVEN words of the block (bit i = word 128 b + 2 i),
 // flags[2 b + 1] = the odd ones -- the shape in which two ballots of a wave that holds 16 bytes per lane deliver them.
+// the flags of 256 words held by a wave as 16 bytes per lane: a0 = words base + 2t, base + 2t + 1, a1 = the same 128 words
+// further, h = the four words in front of the block in lanes 62, 63
+template <int K>
+__device__ __forceinline__ void det_classify_256(const u64x2 a0, const u64x2 a1, const u64x2 h, const u64 base, const u64 nfull,
+                                                 const unsigned lane, u64 &me0, u64 &mo0, u64 &me1, u64 &mo1) {
+    typedef DetLag<K> LG;
+    constexpr int NH = LG::NH, TAP = det_tap_of(K);
+    auto pair_flags = [&](const u64x2 cur, const u64x2 lower, const u64 first, bool &fe, bool &fo) {
+        // first = index of cur.x.  w[j] = word first + 1 - j, j = 0 .. NH + 2, from this lane and the two below it
+        const int l1 = (int)((lane - 1u) & 63u), l2 = (int)((lane - 2u) & 63u);
+        const u64 c1x = __shfl(cur.x, l1, 64), c1y = __shfl(cur.y, l1, 64), b1x = __shfl(lower.x, l1, 64), b1y = __shfl(lower.y, l1, 64);
+        const u64 c2x = __shfl(cur.x, l2, 64), c2y = __shfl(cur.y, l2, 64), b2x = __shfl(lower.x, l2, 64), b2y = __shfl(lower.y, l2, 64);
+        u64 w[6];
+        w[0] = cur.y; w[1] = cur.x;
+        w[2] = lane >= 1 ? c1y : b1y; w[3] = lane >= 1 ? c1x : b1x;
+        w[4] = lane >= 2 ? c2y : b2y; w[5] = lane >= 2 ? c2x : b2x;
+        auto one = [&](const int o, const u64 n) -> bool {          // the word w[o], index n
+            u64 fh[3] = {0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < NH; q++) fh[q] = (w[o + NH - q] << 1) | (w[o + NH - q + 1] >> 63);       // fh[NH-1] = V_{n-1}
+            const u64 V = (w[o] << 1) | (w[o + 1] >> 63);
+            const u64 Fp = det_hist_window<64 * NH - LG::LAGK, NH>(fh) ^ det_hist_window<64 * NH - LG::LAGT, NH>(fh);
+            const uint32_t vh = (uint32_t)(V >> 32);
+            const uint32_t last = (uint32_t)(w[o] >> 32) ^ (vh << (K - 1)) ^ (vh << (TAP - 1));
+            return V == Fp && (int32_t)last >= 0 && n >= (u64)(NH + 1) && n < nfull;
+        };
+        static_assert(NH + 2 <= 5, "the two lanes below hold the words a flag needs");
+        fo = one(0, first + 1);
+        fe = one(1, first);
+    };
+    bool e0, o0, e1, o1;
+    pair_flags(a0, h, base + 2 * lane, e0, o0);
+    pair_flags(a1, a0, base + 128 + 2 * lane, e1, o1);
+    me0 = __ballot(e0); mo0 = __ballot(o0); me1 = __ballot(e1); mo1 = __ballot(o1);
+}
+
+// words i, i + 1 of a stream that is read once: non-temporal (the stream's last word may stand alone)
+__device__ __forceinline__ u64x2 det_load2(const u64 *__restrict src, const u64 i, const u64 nwords) {
+    if (i + 1 < nwords) return __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(src + i));
+    return (u64x2){i < nwords ? src[i] : 0ull, 0ull};
+}
+
 template <int K>
 __global__ void __launch_bounds__(256)
 det_classify_kernel(const u64 *__restrict src, u64 nbits, u64 nwords, u64 *__restrict flags) {
-    typedef DetLag<K> LG;
-    constexpr int NH = LG::NH, TAP = det_tap_of(K);
     const unsigned lane = threadIdx.x & 63;
     const u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
     const u64 nfull = nbits / 64;                    // words with all 64 bits inside the stream
-    auto load2 = [&](const u64 i) -> u64x2 {         // words i, i + 1, read once: non-temporal (the stream's last word may stand alone)
-        if (i + 1 < nwords) return __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(src + i));
-        return (u64x2){i < nwords ? src[i] : 0ull, 0ull};
-    };
     // lane t holds words base + 2t, base + 2t + 1 (one 16-byte load: 1 KiB per wave) and the same 128 words further; the four
     // words in front of the block sit in lanes 62, 63 of `h`.  The next block's loads are in flight while this one is judged.
     u64 base = ((((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6)) * 256;
     u64x2 n0 = {0, 0}, n1 = {0, 0}, nh = {0, 0};
     if (base < nwords) {
-        n0 = load2(base + 2 * lane); n1 = load2(base + 128 + 2 * lane);
-        if (lane >= 62 && base >= 128) nh = load2(base - 128 + 2 * lane);
+        n0 = det_load2(src, base + 2 * lane, nwords); n1 = det_load2(src, base + 128 + 2 * lane, nwords);
+        if (lane >= 62 && base >= 128) nh = det_load2(src, base - 128 + 2 * lane, nwords);
     }
     for (; base < nwords; base += nwaves * 256) {
         const u64x2 a0 = n0, a1 = n1, h = nh;
         const u64 nb = base + nwaves * 256;
         if (nb < nwords) {
-            n0 = load2(nb + 2 * lane); n1 = load2(nb + 128 + 2 * lane);
-            if (lane >= 62) nh = load2(nb - 128 + 2 * lane);
+            n0 = det_load2(src, nb + 2 * lane, nwords); n1 = det_load2(src, nb + 128 + 2 * lane, nwords);
+            if (lane >= 62) nh = det_load2(src, nb - 128 + 2 * lane, nwords);
         }
-        auto pair_flags = [&](const u64x2 cur, const u64x2 lower, const u64 first, bool &fe, bool &fo) {
-            // first = index of cur.x.  w[j] = word n0 + 1 - j, j = 0 .. NH + 2, from this lane and the two below it
-            const int l1 = (int)((lane - 1u) & 63u), l2 = (int)((lane - 2u) & 63u);
-            const u64 c1x = __shfl(cur.x, l1, 64), c1y = __shfl(cur.y, l1, 64), b1x = __shfl(lower.x, l1, 64), b1y = __shfl(lower.y, l1, 64);
-            const u64 c2x = __shfl(cur.x, l2, 64), c2y = __shfl(cur.y, l2, 64), b2x = __shfl(lower.x, l2, 64), b2y = __shfl(lower.y, l2, 64);
-            u64 w[6];
-            w[0] = cur.y; w[1] = cur.x;
-            w[2] = lane >= 1 ? c1y : b1y; w[3] = lane >= 1 ? c1x : b1x;
-            w[4] = lane >= 2 ? c2y : b2y; w[5] = lane >= 2 ? c2x : b2x;
-            auto one = [&](const int o, const u64 n) -> bool {          // the word w[o], index n
-                u64 fh[3] = {0, 0, 0};
-#pragma unroll
-                for (int q = 0; q < NH; q++) fh[q] = (w[o + NH - q] << 1) | (w[o + NH - q + 1] >> 63);       // fh[NH-1] = V_{n-1}
-                const u64 V = (w[o] << 1) | (w[o + 1] >> 63);
-                const u64 Fp = det_hist_window<64 * NH - LG::LAGK, NH>(fh) ^ det_hist_window<64 * NH - LG::LAGT, NH>(fh);
-                const uint32_t vh = (uint32_t)(V >> 32);
-                const uint32_t last = (uint32_t)(w[o] >> 32) ^ (vh << (K - 1)) ^ (vh << (TAP - 1));
-                return V == Fp && (int32_t)last >= 0 && n >= (u64)(NH + 1) && n < nfull;
-            };
-            static_assert(NH + 2 <= 5, "the two lanes below hold the words a flag needs");
-            fo = one(0, first + 1);
-            fe = one(1, first);
-        };
-        bool e0, o0, e1, o1;
-        pair_flags(a0, h, base + 2 * lane, e0, o0);
-        pair_flags(a1, a0, base + 128 + 2 * lane, e1, o1);
-        const u64 me0 = __ballot(e0), mo0 = __ballot(o0), me1 = __ballot(e1), mo1 = __ballot(o1);
+        u64 me0, mo0, me1, mo1;
+        det_classify_256<K>(a0, a1, h, base, nfull, lane, me0, mo0, me1, mo1);
         if (lane == 0) {
             *reinterpret_cast<u64x2 *>(flags + (base >> 6)) = (u64x2){me0, mo0};
             if (base + 128 < nwords) *reinterpret_cast<u64x2 *>(flags + (base >> 6) + 2) = (u64x2){me1, mo1};
@@ -417,35 +428,10 @@ det_classify_kernel(const u64 *__restrict src, u64 nbits, u64 nwords, u64 *__res
     }
 }
 
-// A lane's view of the flags: the blocks of its chunk (and the one in front of it) fetched together into registers when the
-// lane starts -- one round trip instead of one per jump -- and memory for anything outside that window.
-struct DetFlags {
-    static constexpr int kWin = 6;
-    const u64 *mem;
-    u64 b0;
-    int n;
-    u64x2 f[kWin];
-    __device__ __forceinline__ void fetch(const u64 *flags, u64 first_block, u64 last_block) {
-        mem = flags; b0 = first_block;
-        n = last_block - first_block + 1 > (u64)kWin ? kWin : (int)(last_block - first_block + 1);
-#pragma unroll
-        for (int i = 0; i < kWin; i++) f[i] = i < n ? *reinterpret_cast<const u64x2 *>(flags + 2 * (first_block + (u64)i)) : (u64x2){0, 0};
-    }
-    __device__ __forceinline__ u64x2 block(u64 b) const {
-        if (b - b0 < (u64)n) {
-            u64x2 r = f[0];
-#pragma unroll
-            for (int i = 1; i < kWin; i++) r = (b - b0 == (u64)i) ? f[i] : r;
-            return r;
-        }
-        return *reinterpret_cast<const u64x2 *>(mem + 2 * b);
-    }
-};
-
 // the first word at or after w, below w1, whose flag is not set (w1 if there is none)
-__device__ __forceinline__ u64 det_next_unflagged(const DetFlags &fl, u64 w, u64 w1) {
+__device__ __forceinline__ u64 det_next_unflagged(const u64 *__restrict flags, u64 w, u64 w1) {
     for (u64 b = w >> 7; b <= (w1 - 1) >> 7; b++) {
-        const u64x2 f = fl.block(b);
+        const u64x2 f = *reinterpret_cast<const u64x2 *>(flags + 2 * b);      // (a chunk's flags are one or two cache lines: the first read fetches them)
         u64 de = ~f.x, dn = ~f.y;                    // unset among the even / the odd words of block b
         if (b == (w >> 7)) {
             const unsigned r = (unsigned)(w & 127);
@@ -468,13 +454,16 @@ struct DetCtx { DetAux a; bool clean; uint32_t cbit; int vrun; };     // vrun: c
 
 // words [w0, w1) from state s: jumps over flagged stretches, the per-word machine elsewhere
 template <int K, bool EMIT>
-__device__ __forceinline__ void det_span_sparse(DetState &s, DetCtx &x, const u64 *__restrict src, const DetFlags &flags, u64 w0,
+__device__ __forceinline__ void det_span_sparse(DetState &s, DetCtx &x, const u64 *__restrict src, const u64 *__restrict flags, u64 w0,
                                                 u64 w1, u64 nbits, u64 *__restrict err, u64 *__restrict reload, DetCount &cnt) {
     typedef DetLag<K> LG;
     constexpr int NH = LG::NH, TAP = det_tap_of(K);
     constexpr uint32_t MASK = (uint32_t)((1ull << K) - 1ull);
-    const u64 nfull = nbits / 64;
+    const u64 nfull = nbits / 64, nwords = (nbits + 63) / 64;
     u64 w = w0;
+    // the words a jump lands on, fetched WITH the history in front of them (one round trip to memory per jump instead of one
+    // per word: a lane's time is the latency of its dependent loads): the unflagged word j and the NH behind it
+    u64 pre[NH + 1], pre0 = 1ull << 63;       // (w - pre0 is then huge for every real w)
     while (w < w1) {
         if (x.clean && x.vrun >= NH) {
             const u64 j = det_next_unflagged(flags, w, w1);
@@ -485,6 +474,9 @@ __device__ __forceinline__ void det_span_sparse(DetState &s, DetCtx &x, const u6
 #pragma unroll
                 for (int q = 0; q <= NH; q++) ww[q] = src[j - 1 - (u64)NH + (u64)q];
 #pragma unroll
+                for (int q = 0; q <= NH; q++) pre[q] = src[j + (u64)q < nwords ? j + (u64)q : nwords - 1];
+                pre0 = j;
+#pragma unroll
                 for (int q = 0; q < NH; q++) x.a.fh[q] = (ww[q + 1] << 1) | (ww[q] >> 63);
                 x.a.n = NH;
                 x.cbit = (uint32_t)(ww[NH] >> 63);
@@ -492,7 +484,14 @@ __device__ __forceinline__ void det_span_sparse(DetState &s, DetCtx &x, const u6
                 continue;
             }
         }
-        const u64 word = src[w];
+        u64 word;
+        if (w - pre0 <= (u64)NH) {
+            word = pre[0];
+#pragma unroll
+            for (int q = 1; q <= NH; q++) word = (w - pre0 == (u64)q) ? pre[q] : word;
+        } else {
+            word = src[w];
+        }
         u64 ew = 0, rw = 0;
         bool ok = false;
         if (x.clean && w < nfull) {
@@ -548,15 +547,13 @@ det_sparse_kernel(const u64 *__restrict src, const u64 *__restrict flags, u64 nb
     const u64 ws = w0 > warm_words ? w0 - warm_words : 0;     // ws == 0: the whole prefix is run, the start is exact
     typedef DetLag<K> LGs;
     constexpr int NHs = LGs::NH;
-    DetFlags fl;
-    fl.fetch(flags, (w0 >= (u64)NHs ? w0 - NHs : 0) >> 7, (w1 - 1) >> 7);
     // The speculative start.  When the NH words in front of the chunk are flagged, a machine that was locked on them
     // arrives in the clean state those words define: take that state without running anything (the verification against
     // the predecessor's true end decides, as for every speculation).  Otherwise: the reset state `warm` bits earlier.
-    if (ws > 0 && w0 >= (u64)(2 * NHs + 2) && det_next_unflagged(fl, w0 - NHs, w0) == w0) {
-        u64 ww[NHs + 1];
+    u64 ww[NHs + 1];                                 // (fetched beside the flags, whatever they will say)
 #pragma unroll
-        for (int q = 0; q <= NHs; q++) ww[q] = src[w0 - 1 - (u64)NHs + (u64)q];
+    for (int q = 0; q <= NHs; q++) ww[q] = w0 >= (u64)(NHs + 1) ? src[w0 - 1 - (u64)NHs + (u64)q] : 0ull;
+    if (ws > 0 && w0 >= (u64)(2 * NHs + 2) && det_next_unflagged(flags, w0 - NHs, w0) == w0) {
 #pragma unroll
         for (int q = 0; q < NHs; q++) x.a.fh[q] = (ww[q + 1] << 1) | (ww[q] >> 63);
         x.a.n = NHs; x.clean = true; x.vrun = NHs;
@@ -564,10 +561,90 @@ det_sparse_kernel(const u64 *__restrict src, const u64 *__restrict flags, u64 nb
         s.prbs = __builtin_bitreverse32((uint32_t)(x.a.fh[NHs - 1] >> 32)) & (uint32_t)((1ull << K) - 1ull);
         s.err_sr = 0; s.reload_ctr = 0; s.bit_in = x.cbit;
     } else {
-        det_span_sparse<K, false>(s, x, src, fl, ws, w0, nbits, nullptr, nullptr, dummy);
+        det_span_sparse<K, false>(s, x, src, flags, ws, w0, nbits, nullptr, nullptr, dummy);
     }
     spec[c] = s;
-    det_span_sparse<K, true>(s, x, src, fl, w0, w1, nbits, err, reload, cnt);
+    det_span_sparse<K, true>(s, x, src, flags, w0, w1, nbits, err, reload, cnt);
+    endst[c] = s;
+    counts[c] = cnt;
+}
+
+// Both passes in ONE kernel (the form a default call takes): a wave classifies the words of ITS 64 chunks (and the block in
+// front of them) into LDS -- 64 chunks of 4 KiB are a contiguous 256 KiB stretch, streamed 2 KiB per step -- and its lanes
+// then run their chunks from those flags.  The classification of one wave overlaps the serial part of the others on the same
+// CU (latency-bound lanes beside a memory-bound stream), the flags never travel through memory, and the few words a lane
+// goes back to were read by its own wave microseconds earlier.  Needs chunks of whole 128-word flag blocks and a warm-up of
+// at most one; other geometries take the two kernels above.
+constexpr int kDetFusedMaxChunkWords = 512;
+template <int K>
+__global__ void __launch_bounds__(256)
+det_fused_kernel(const u64 *__restrict src, u64 nbits, u64 nwords, u64 chunk_words, u64 warm_words, u64 nchunks,
+                 DetState *__restrict spec, DetState *__restrict endst, DetCount *__restrict counts, u64 *__restrict err,
+                 u64 *__restrict reload) {
+    __shared__ __attribute__((aligned(16))) u64 lflags[4][kDetFusedMaxChunkWords + 8];      // 2 words per 128-word block of the region, + slack
+    const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const u64 c0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x - lane);                    // the wave's first chunk
+    if (c0 >= nchunks) return;
+    const u64 nfull = nbits / 64;
+    const u64 r0 = c0 ? c0 * chunk_words - 128 : 0;                                        // region: one block in front of the first chunk ...
+    const u64 r1e = (c0 + 64) * chunk_words;
+    const u64 r1 = r1e < nwords ? r1e : nwords;                                            // ... to the end of the last
+    u64 *const lf = lflags[wv];
+    {
+        // two steps (4 KiB per wave) of loads in flight beyond the one being judged
+        u64 base = r0;
+        auto fetch = [&](const u64 b, u64x2 &x0, u64x2 &x1, u64x2 &xh) {
+            x0 = (u64x2){0, 0}; x1 = x0; xh = x0;
+            if (b < r1) {
+                x0 = det_load2(src, b + 2 * lane, nwords); x1 = det_load2(src, b + 128 + 2 * lane, nwords);
+                if (lane >= 62 && b >= 128) xh = det_load2(src, b - 128 + 2 * lane, nwords);
+            }
+        };
+        u64x2 p0, p1, ph, q0, q1, qh;
+        fetch(base, p0, p1, ph);
+        fetch(base + 256, q0, q1, qh);
+        for (; base < r1; base += 256) {
+            const u64x2 a0 = p0, a1 = p1, h = ph;
+            p0 = q0; p1 = q1; ph = qh;
+            fetch(base + 512, q0, q1, qh);
+            u64 me0, mo0, me1, mo1;
+            det_classify_256<K>(a0, a1, h, base, nfull, lane, me0, mo0, me1, mo1);
+            if (lane == 0) {
+                const u64 i = (base - r0) >> 6;
+                *reinterpret_cast<u64x2 *>(lf + i) = (u64x2){me0, mo0};
+                *reinterpret_cast<u64x2 *>(lf + i + 2) = (u64x2){me1, mo1};
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const u64 *const flags = lf - 2 * (r0 >> 7);     // flags + 2 b = block b of the stream
+    const u64 c = c0 + lane;
+    if (c >= nchunks) return;
+    const u64 w0 = c * chunk_words;
+    const u64 w1 = w0 + chunk_words < nwords ? w0 + chunk_words : nwords;
+    DetState s = det_reset(K);
+    DetCtx x;
+    x.a.n = 0; x.clean = false; x.cbit = 0; x.vrun = 0;
+    DetCount cnt = {0, 0, 0, 0}, dummy = {0, 0, 0, 0};
+    const u64 ws = w0 > warm_words ? w0 - warm_words : 0;
+    typedef DetLag<K> LGs;
+    constexpr int NHs = LGs::NH;
+    u64 ww[NHs + 1];
+#pragma unroll
+    for (int q = 0; q <= NHs; q++) ww[q] = w0 >= (u64)(NHs + 1) ? src[w0 - 1 - (u64)NHs + (u64)q] : 0ull;
+    if (ws > 0 && w0 >= (u64)(2 * NHs + 2) && det_next_unflagged(flags, w0 - NHs, w0) == w0) {
+#pragma unroll
+        for (int q = 0; q < NHs; q++) x.a.fh[q] = (ww[q + 1] << 1) | (ww[q] >> 63);
+        x.a.n = NHs; x.clean = true; x.vrun = NHs;
+        x.cbit = (uint32_t)(ww[NHs] >> 63);
+        s.prbs = __builtin_bitreverse32((uint32_t)(x.a.fh[NHs - 1] >> 32)) & (uint32_t)((1ull << K) - 1ull);
+        s.err_sr = 0; s.reload_ctr = 0; s.bit_in = x.cbit;
+    } else {
+        det_span_sparse<K, false>(s, x, src, flags, ws, w0, nbits, nullptr, nullptr, dummy);
+    }
+    spec[c] = s;
+    det_span_sparse<K, true>(s, x, src, flags, w0, w1, nbits, err, reload, cnt);
     endst[c] = s;
     counts[c] = cnt;
 }
@@ -787,16 +864,23 @@ static int detector_stream_k(const u64 *src, u64 nbits, u64 *err, u64 *reload, b
     // cooperative 128-byte loads need chunks and warm-up in whole 16-word rows on 16-byte aligned data
     const int tiles_ok = chunk_words % 16 == 0 && warm_words % 16 == 0 && warm_words > 0 && ((uintptr_t)src & 15) == 0;
     static const bool dense = env_knob("BBB_DET_DENSE", 0) != 0;          // (A/B timing of the two forms; -DBBB_EXPERIMENTS only)
-    if (kSparse && !dense && ((uintptr_t)src & 15) == 0) {
+    const bool sparse = kSparse && !dense && ((uintptr_t)src & 15) == 0;
+    if (sparse) {
         if constexpr (kSparse) {
             u64 *flags = (u64 *)(ws + o_flags);
             if (err) (void)hipMemsetAsync(err, 0, nwords * sizeof(u64), st);
             if (reload) (void)hipMemsetAsync(reload, 0, nwords * sizeof(u64), st);
             const u64 nblk = (nwords + 255) / 256;                        // one wave per 256 words, four waves per block
             const unsigned cgrid = (unsigned)((nblk + 3) / 4 < 8192 ? (nblk + 3) / 4 : 8192);
-            hipLaunchKernelGGL(det_classify_kernel<K>, dim3(cgrid), dim3(256), 0, st, src, nbits, nwords, flags);
-            hipLaunchKernelGGL(det_sparse_kernel<K>, dim3(grid), dim3(256), 0, st, src, (const u64 *)flags, nbits, nwords, chunk_words,
-                               warm_words, nchunks, spec, endst, counts, err, reload);
+            static const bool two_kernels = env_knob("BBB_DET_TWO_KERNELS", 0) != 0;      // (A/B timing; -DBBB_EXPERIMENTS only)
+            if (chunk_words % 128 == 0 && chunk_words <= (u64)kDetFusedMaxChunkWords && warm_words <= 128 && !two_kernels) {
+                hipLaunchKernelGGL(det_fused_kernel<K>, dim3(grid), dim3(256), 0, st, src, nbits, nwords, chunk_words, warm_words, nchunks,
+                                   spec, endst, counts, err, reload);
+            } else {
+                hipLaunchKernelGGL(det_classify_kernel<K>, dim3(cgrid), dim3(256), 0, st, src, nbits, nwords, flags);
+                hipLaunchKernelGGL(det_sparse_kernel<K>, dim3(grid), dim3(256), 0, st, src, (const u64 *)flags, nbits, nwords, chunk_words,
+                                   warm_words, nchunks, spec, endst, counts, err, reload);
+            }
         }
     } else if (err || reload)
         hipLaunchKernelGGL((det_chunk_kernel<K, true>), dim3(grid), dim3(256), 0, st, 0, src, nbits, nwords, chunk_words, warm_words,
@@ -817,17 +901,36 @@ static int detector_stream_k(const u64 *src, u64 nbits, u64 *err, u64 *reload, b
         (void)hipMemsetAsync(tail, 0, 16 * sizeof(u64), st);
         hipLaunchKernelGGL(det_reduce_kernel, dim3(rgrid), dim3(256), 0, st, nchunks, counts, tail, (const DetState *)spec,
                            (const DetState *)endst, list, nlist, (const unsigned *)nullptr);
-        hipLaunchKernelGGL((det_chunk_kernel<K, true>), dim3(kSpec / 256), dim3(256), 0, st, 1, src, nbits, nwords, chunk_words, warm_words,
-                           nchunks, (const unsigned *)list, kSpec, spec, endst, counts, err, reload, 0, (const unsigned *)nlist);
-        hipLaunchKernelGGL(det_reduce_kernel, dim3(rgrid), dim3(256), 0, st, nchunks, counts, tail2, (const DetState *)spec,
-                           (const DetState *)endst, list2, nlist2, (const unsigned *)nlist);
+        // The repair stages are queued blind only for the dense pass, whose reset-state speculation leaves a few dozen
+        // inconsistent chunks on every noisy stream.  The sparse pass starts a chunk from the clean state its flags imply and
+        // is consistent as speculated unless an error or a reload sits right on a chunk boundary: there the two idle launches
+        // (10 us of a 0.3 ms call) cost more than the second round trip they save, so the host looks first.
+        if (!sparse) {
+            hipLaunchKernelGGL((det_chunk_kernel<K, true>), dim3(kSpec / 256), dim3(256), 0, st, 1, src, nbits, nwords, chunk_words, warm_words,
+                               nchunks, (const unsigned *)list, kSpec, spec, endst, counts, err, reload, 0, (const unsigned *)nlist);
+            hipLaunchKernelGGL(det_reduce_kernel, dim3(rgrid), dim3(256), 0, st, nchunks, counts, tail2, (const DetState *)spec,
+                               (const DetState *)endst, list2, nlist2, (const unsigned *)nlist);
+        }
         hipError_t e = hipMemcpyAsync(hh, tail, 16 * sizeof(u64), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) { cleanup(); BBB_HIP(e); }
         const unsigned nbad1 = (unsigned)(hh[4] & 0xffffffffull), nbad2 = (unsigned)(hh[12] & 0xffffffffull);
         bool settled = false;
         if (!nbad1) { for (int i = 0; i < 5; i++) h[i] = hh[i]; settled = true; }
-        else {
+        else if (sparse) {
+            // second trip: the listed chunks again from their predecessors' ends, verify + totals, look again
+            const unsigned nb = nbad1 < kSpec ? nbad1 : kSpec;
+            hipLaunchKernelGGL((det_chunk_kernel<K, true>), dim3((nb + 255) / 256), dim3(256), 0, st, 1, src, nbits, nwords, chunk_words,
+                               warm_words, nchunks, (const unsigned *)list, nb, spec, endst, counts, err, reload, 0, (const unsigned *)nullptr);
+            hipLaunchKernelGGL(det_reduce_kernel, dim3(rgrid), dim3(256), 0, st, nchunks, counts, tail2, (const DetState *)spec,
+                               (const DetState *)endst, list2, nlist2, (const unsigned *)nullptr);
+            e = hipMemcpyAsync(hh, tail, 16 * sizeof(u64), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) { cleanup(); BBB_HIP(e); }
+            rerun += nb;
+            passes = 1;
+            if (nbad1 <= kSpec && !(unsigned)(hh[12] & 0xffffffffull)) { for (int i = 0; i < 5; i++) h[i] = hh[8 + i]; settled = true; }
+        } else {
             rerun += nbad1 < kSpec ? nbad1 : kSpec;
             passes = 1;
             if (nbad1 <= kSpec && !nbad2) { for (int i = 0; i < 5; i++) h[i] = hh[8 + i]; settled = true; }

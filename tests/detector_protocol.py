@@ -22,15 +22,17 @@ clock i.
 import numpy as np
 
 
-def make_case(k, prbs_bits_fn, seed):
-    """Returns (wire, tx_errors): the 0/1 input wire per clock and the injected error flags."""
+def make_case(k, prbs_bits_fn, seed, literal=False):
+    """Returns (wire, tx_errors): the 0/1 input wire per clock and the injected error flags.
+    literal: the reference's own windows (prbs.py:133-138: 2k clean bits first, 2k after the burst) instead of 4k."""
     rng = np.random.default_rng(seed)
     nbits = min((1 << k) - 1, 512)
     tx_errors = rng.binomial(1, 0.02, nbits).astype(np.uint8)
-    tx_errors[: 4 * k] = 0
+    quiet = 2 * k if literal else 4 * k
+    tx_errors[:quiet] = 0
     mid = nbits // 2
     tx_errors[mid: mid + 3 * k] = 1
-    tx_errors[mid + 3 * k: mid + 7 * k] = 0
+    tx_errors[mid + 3 * k: mid + 3 * k + quiet] = 0
     tx = np.asarray(prbs_bits_fn(k, nbits), dtype=np.uint8)
     wire = np.concatenate([[0], (tx ^ tx_errors)[:-1]]).astype(np.uint8)
     return wire, tx_errors
@@ -46,3 +48,15 @@ def check_case(tx_errors, rx_errors, reload):
     # and must have seen (and flagged) the burst
     assert valid.sum() >= len(tx_errors) // 4
     assert (1 - valid.astype(int)).sum() > 0
+
+
+def errors_inside_reload(k, tx_errors, reload):
+    """Injected errors outside the burst that reach the detector while `reload` is high (error i is on the wire during
+    clock i + 1).  Such an error is shifted INTO the LFSR: the detector comes out of the reload locked to a wrong state and
+    reports errors that were never injected -- the reference's own assertion (prbs.py:158-163) fails on such a draw, which
+    with its unseeded RNG and 2k windows happens now and then (an error right behind the 2k preamble meets the tail of the
+    start-up reloads; an error behind the 2k post-burst window meets the resynchronisation)."""
+    n = len(tx_errors)
+    mid = n // 2
+    r = np.asarray(reload)
+    return [i for i in range(n - 1) if tx_errors[i] and not (mid <= i < mid + 3 * k) and r[i + 1]]

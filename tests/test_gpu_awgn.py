@@ -234,9 +234,22 @@ def test_baseline_configs_2_and_4_at_full_size(gpu, oracle):
     u = gpu.LUTOPT.shipped(256)
     got = gpu.CLTGRNG(u).generate(n, first_step=16).cpu().numpy()
     m = oracle.Lutopt(path=oracle.data_path(256))
-    exp = m.awgn(1, 16, n, fast=True)
+    exp3 = m.awgn(1, 16, 3 * n, fast=True)          # ONE sequential oracle pass over three reads' worth (~75 s of one host core)
+    exp = exp3[:n]
     assert got.shape == exp.shape and np.array_equal(got, exp)
     del got
+    # The TIMED path of bench.py, at its size: bbb_awgn_stream_next on a fresh handle -- the two-kernel form, two reads per
+    # sample kernel (the stream's own choice of level), every next read announced -- 1e9 samples per read, three reads (a
+    # kernel's first and second half and the next kernel's first), every byte against that one oracle pass.
+    us = gpu.LUTOPT.shipped(256)
+    buf = torch.empty(n, dtype=torch.int8, device="cuda")
+    with gpu.CLTGRNG(us).stream(n, first_step=16) as st:
+        for r in range(3):
+            st.next(out=buf)
+            part = buf.cpu().numpy()
+            assert np.array_equal(part, exp3[r * n:(r + 1) * n]), r
+        assert st.tell() == 16 + 3 * n
+    del buf, part, exp3
     # sigma^2 = 2^(log2 n - 2) = 64 (software/clt-grng/clt-grng-evaluate.py:18-21), mean 0
     x = exp[: 50_000_000].astype(np.float64)
     assert abs(x.mean()) < 0.01 and abs(x.var() - 64.0) < 0.1

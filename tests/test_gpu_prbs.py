@@ -105,6 +105,23 @@ def test_prbs_detector_reference_protocol(gpu, oracle, k, seed):
     check_case(tx_errors, e[0].cpu().numpy(), r[0].cpu().numpy())
 
 
+@pytest.mark.parametrize("k", KS)
+def test_prbs_detector_reference_protocol_literal_windows(gpu, oracle, k):
+    """The same with the reference's own 2k / 3k / 2k windows (prbs.py:133-138), twelve seeded draws per k run as twelve
+    parallel streams: the device's outputs equal the oracle's on every draw, and the reference's assertion holds on every
+    draw in which no injected error meets a reload window (tests/test_oracle.py has the count and the k = 7 case)."""
+    from detector_protocol import make_case, check_case, errors_inside_reload
+    cases = [make_case(k, lambda kk, n: oracle.prbs_bits(kk, n)[0], seed, literal=True) for seed in range(12)]
+    wires = np.stack([c[0] for c in cases])
+    e, r = gpu.PRBSErrorDetector(k).run(torch.from_numpy(wires).cuda())
+    e, r = e.cpu().numpy(), r.cpu().numpy()
+    for i, (wire, tx_errors) in enumerate(cases):
+        eo, ro = oracle.prbs_detector_run(k, wire)
+        assert np.array_equal(e[i], eo) and np.array_equal(r[i], ro)
+        if not errors_inside_reload(k, tx_errors, r[i]):
+            check_case(tx_errors, e[i], r[i])
+
+
 def test_prbs31_beyond_2_pow_35_bits(gpu, oracle):
     """4 GiB of packed PRBS-31 in one call: loopback is clean, far words match the oracle."""
     nbits = (1 << 35) + 77

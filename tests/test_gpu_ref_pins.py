@@ -104,3 +104,21 @@ def test_word_stream_needs_whole_words(gpu):
     u = gpu.LUTOPT.shipped(16)
     with pytest.raises(ValueError):
         u.generate_words(4)
+
+
+@pytest.mark.parametrize("k", (7, 9, 11, 15, 20, 23, 31))
+def test_prbs_prefix_and_state_of_survey_appendix_b(gpu, k):
+    """SURVEY.md Appendix B's PRBS(k) lines (reference model prbs.py:112-113) on the device: bbb_prbs_fill's first 64 bits and
+    bbb_prbs_state_at(64); for k = 31 also as the head of the 1e10-bit fill of BASELINE configs[2] (the same kernel at the
+    size the metric is quoted on: bit t at word t / 64, bit t % 64)."""
+    import json
+    import pathlib
+    bits, s = json.load(open(pathlib.Path(__file__).parent / "golden" / "survey_appendix_b_prbs.json"))["vectors"][str(k)]
+    p = gpu.PRBS(k)
+    w = int(p.generate(64).cpu().numpy().view(np.uint64)[0])
+    assert "".join(str((w >> t) & 1) for t in range(64)) == bits
+    assert p.state_at(64) == int(s, 16)
+    if k == 31:
+        big = p.generate(10_000_000_000)
+        assert int(big[:1].cpu().numpy().view(np.uint64)[0]) == w
+        del big

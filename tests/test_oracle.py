@@ -141,6 +141,31 @@ def test_detector_reference_protocol(oracle, k, seed):
 
 
 @pytest.mark.parametrize("k", KS)
+def test_detector_reference_protocol_literal_windows(oracle, k):
+    """The reference's protocol with its OWN windows (2k clean, 3k burst, 2k clean: prbs.py:133-138) over twelve seeded
+    draws per k: its assertion holds on every draw in which no injected error meets a reload window, and fails on the
+    others -- which is why the other protocol tests widen the windows to 4k (detector_protocol.py)."""
+    from detector_protocol import make_case, check_case, errors_inside_reload
+    clean_draws = 0
+    for seed in range(12):
+        wire, tx_errors = make_case(k, lambda kk, n: oracle.prbs_bits(kk, n)[0], seed, literal=True)
+        e, r = oracle.prbs_detector_run(k, wire)
+        if not errors_inside_reload(k, tx_errors, r):
+            check_case(tx_errors, e, r)
+            clean_draws += 1
+        else:
+            with pytest.raises(AssertionError):
+                check_case(tx_errors, e, r)
+    assert clean_draws >= 9
+    if k == 7:
+        # the reason for the 4k windows, in numbers: an error right behind the 2k = 14 bit preamble still finds `reload` high
+        wire, tx_errors = make_case(7, lambda kk, n: oracle.prbs_bits(kk, n)[0], 4, literal=True)
+        e, r = oracle.prbs_detector_run(7, wire)
+        hit = errors_inside_reload(7, tx_errors, r)
+        assert hit and 14 <= hit[0] < 21
+
+
+@pytest.mark.parametrize("k", KS)
 def test_detector_structure(oracle, k):
     """Facts that follow from prbs.py:80,91-97: the all-ones reset of err_sr arms a reload on the
     very first clock; a clean stream is in lock (err == 0, reload == 0) from some clock on."""

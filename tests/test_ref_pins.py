@@ -117,3 +117,14 @@ def test_lfsr_strings_of_the_reference_script():
     want = ((1 | 1 << 11 | 1 << 13 | 1 << 14 | 1 << 16, 16), (1 | 1 << 1 | 1 << 61 | 1 << 62 | 1 << 64, 64))
     for s, w in zip(lines, want):
         assert gf2poly.berlekamp_massey([int(c) for c in s]) == w
+
+
+@pytest.mark.parametrize("k", (7, 9, 11, 15, 20, 23, 31))
+def test_prbs_prefix_and_state_of_survey_appendix_b(oracle, k):
+    """The survey's known-answer lines for PRBS(k) from reset state 1 (from the reference's model
+    prbs.py:112-113): the first 64 emitted bits and the LFSR state after them -- the one literal this repository holds
+    for PRBS-31, whose 2^31 - 1 period no reference file spells out."""
+    bits, s = json.load(open(GOLDEN / "survey_appendix_b_prbs.json"))["vectors"][str(k)]
+    got, state = oracle.prbs_bits(k, 64)
+    assert "".join(str(int(b)) for b in got) == bits
+    assert state == int(s, 16)
