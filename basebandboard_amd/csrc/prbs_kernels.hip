@@ -84,6 +84,118 @@ int prbs_state_at_host(int k, uint64_t init_state, uint64_t nbits, uint64_t *sta
 }
 
 // ---------------------------------------------------------------------------------------------
+// Region seeds (round 4).  Every wave of the generator and of the checker used to open with the same private bootstrap: jump
+// the LFSR state to its region (up to 64 dependent mat-vecs over four fetches of the power table), form K words bit by bit,
+// then grow them to K rows -- 15-20 us in which the kernel moves no data, twice per loopback (7 % of it).  The first two steps
+// depend on nothing but (k, init, first_bit, the partition): seed r = the K words that start K rows in front of region r.
+// They are computed ONCE by prbs_seed_kernel and kept (a small per-device cache keyed on those parameters, like an FFT
+// plan); the generator's wave r starts from seed r, and the reverse checker's wave r from seed r + 1 -- the K rows in front
+// of region r + 1 ARE the last K rows of region r, the first window the descending pass needs.  What is left per wave is the
+// growth in LDS (~3 us).
+// ---------------------------------------------------------------------------------------------
+template <int K>
+__device__ __forceinline__ uint32_t lfsr_matvec(const uint32_t *__restrict rows, uint32_t s);      // (below)
+
+template <int K>
+__global__ void __launch_bounds__(64)
+prbs_seed_kernel(int ki, u64 init_state, u64 first_bit, u64 nseeds, u64 rows_per_wave, u64 *__restrict seeds) {
+    constexpr int TAP = tap_of(K);
+    constexpr int RW = 64;
+    constexpr uint32_t SMASK = (uint32_t)((1ull << K) - 1ull);
+    const int lane = threadIdx.x;
+    const u64 r = blockIdx.x;
+    if (r >= nseeds) return;
+    const PrbsPowTable &pw = d_prbs_pow[ki];
+    constexpr u64 PERIOD = (1ull << K) - 1ull;
+    constexpr u64 BACK = (u64)K * RW * 64;                       // bits in K rows
+    constexpr u64 WRAP = ((BACK + PERIOD - 1) / PERIOD) * PERIOD;  // multiple of the period >= BACK
+    const u64 word0 = r * rows_per_wave * RW;
+    const u64 t0 = (first_bit % PERIOD) + ((word0 % PERIOD) * 64) % PERIOD + (WRAP - BACK);
+    uint32_t s = (uint32_t)init_state;
+#pragma unroll 1
+    for (int i0 = 0; i0 < 64; i0 += 16) {
+        if (((t0 >> i0) & 0xffffull) == 0) continue;
+        uint32_t myrow[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) myrow[i] = pw.rows[i0 + i][lane & 31];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            if ((t0 >> (i0 + i)) & 1) s = (uint32_t)__ballot(lane < K && (__builtin_popcount(myrow[i] & s) & 1));
+        }
+    }
+    if (lane < K) {
+        uint32_t si = s;
+#pragma unroll
+        for (int m = 0; m < 5; m++) {
+            const uint32_t sj = lfsr_matvec<K>(pw.rows[6 + m], si);
+            si = ((lane >> m) & 1) ? sj : si;
+        }
+        u64 w = 0;
+        for (int j = 0; j < 64; j++) {
+            const uint32_t bit = ((si >> (K - 1)) ^ (si >> (TAP - 1))) & 1u;
+            si = ((si << 1) | bit) & SMASK;
+            w |= (u64)bit << j;
+        }
+        seeds[r * 32 + (u64)lane] = w;
+    }
+}
+
+struct PrbsSeedPlan {
+    int dev = -1, k = 0;
+    u64 init = 0, first_bit = 0, rpw = 0, nseeds = 0;
+    u64 *d = nullptr;
+    size_t cap = 0;
+    hipStream_t last = nullptr;
+    u64 stamp = 0;
+};
+static std::mutex g_seed_mu;
+static PrbsSeedPlan g_seed_plans[8];
+static u64 g_seed_clock = 0;
+
+// seeds[r * 32 + i], r < nseeds: ready on `st` when this returns (computed there if no plan matched)
+static int prbs_region_seeds(int k, int ki, u64 init_state, u64 first_bit, u64 rpw, u64 nseeds, hipStream_t st, const u64 **out) {
+    int dev = 0;
+    BBB_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> g(g_seed_mu);
+    PrbsSeedPlan *victim = &g_seed_plans[0];
+    for (PrbsSeedPlan &p : g_seed_plans) {
+        if (p.d && p.dev == dev && p.k == k && p.init == init_state && p.first_bit == first_bit && p.rpw == rpw && p.nseeds >= nseeds) {
+            // (a plan computed on another stream: that stream's work so far includes its seed kernel)
+            if (p.last != st) BBB_HIP(hipStreamSynchronize(p.last));
+            p.last = st;
+            p.stamp = ++g_seed_clock;
+            *out = p.d;
+            return BBB_OK;
+        }
+        if (p.stamp < victim->stamp) victim = &p;
+    }
+    PrbsSeedPlan &p = *victim;
+    if (p.d && p.dev == dev && p.last != st) BBB_HIP(hipStreamSynchronize(p.last));      // its last reader may still run
+    if (p.d && p.dev != dev) {                      // another device's buffer: release it there
+        int cur = dev;
+        (void)hipSetDevice(p.dev); (void)hipStreamSynchronize(p.last); (void)hipFree(p.d); (void)hipSetDevice(cur);
+        p.d = nullptr; p.cap = 0;
+    }
+    const size_t need = (size_t)nseeds * 32 * sizeof(u64);
+    if (p.cap < need) {
+        if (p.d) { BBB_HIP(hipStreamSynchronize(p.last)); BBB_HIP(hipFree(p.d)); }
+        p.d = nullptr; p.cap = 0;
+        BBB_HIP(hipMalloc((void **)&p.d, need));
+        p.cap = need;
+    }
+    p.dev = dev; p.k = k; p.init = init_state; p.first_bit = first_bit; p.rpw = rpw; p.nseeds = nseeds; p.last = st; p.stamp = ++g_seed_clock;
+#define BBB_PRBS_CASE(KK) case KK: hipLaunchKernelGGL(prbs_seed_kernel<KK>, dim3((unsigned)nseeds), dim3(64), 0, st, ki, init_state, first_bit, nseeds, rpw, p.d); break;
+    switch (k) {
+        BBB_PRBS_CASE(7) BBB_PRBS_CASE(9) BBB_PRBS_CASE(11) BBB_PRBS_CASE(15)
+        BBB_PRBS_CASE(20) BBB_PRBS_CASE(23) BBB_PRBS_CASE(31)
+    }
+#undef BBB_PRBS_CASE
+    BBB_HIP(hipGetLastError());
+    *out = p.d;
+    return BBB_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Streaming generator / checker.  One wave per block; block b owns rows [b*rpw, (b+1)*rpw).
 // A row is RW = 64*WPL words; lane l owns words WPL*l .. WPL*l+WPL-1 of every row (8- or 16-byte
 // accesses).  Row lag identity: row[q] = row[q-K] ^ row[q-TAP]  (bit lags K*RW*64, TAP*RW*64).
@@ -145,7 +257,7 @@ __device__ __forceinline__ void fill_store(T *p, const T &v) {
 template <int K, bool CHECK, int WPL, bool LW>
 __global__ void __launch_bounds__(64, 2)   // >= 2 waves per SIMD: at most 256 registers
 prbs_stream_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwords, u64 rows_per_wave,
-                   u64 *__restrict buf, u64 *__restrict nerr, int nt_stores) {
+                   u64 *__restrict buf, u64 *__restrict nerr, int nt_stores, const u64 *__restrict seeds) {
     typedef typename LaneWords<WPL>::type lw_t;
     constexpr int TAP = tap_of(K);
     constexpr int RW = 64 * WPL;                 // words per row
@@ -163,6 +275,10 @@ prbs_stream_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwords,
     //    sequence has period 2^K - 1 (maximal length), which extends it to negative positions.
     //    s = T^(t0) * init, lane r evaluating row r; the candidate rows of T^(2^i) are fetched 16 at
     //    a time (four memory round trips, not one per set bit).
+    if (seeds) {
+        // (steps 1 and 2 were done once for the whole partition: prbs_region_seeds)
+        if (lane < K) X[lane] = seeds[(u64)blockIdx.x * 32 + (u64)lane];
+    } else {
     constexpr u64 PERIOD = (1ull << K) - 1ull;
     constexpr u64 BACK = (u64)K * RW * 64;                       // bits in K rows
     constexpr u64 WRAP = ((BACK + PERIOD - 1) / PERIOD) * PERIOD;  // multiple of the period >= BACK
@@ -194,6 +310,7 @@ prbs_stream_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwords,
             w |= (u64)bit << j;
         }
         X[lane] = w;
+    }
     }
     __syncthreads();
     // 3. grow the known prefix K -> K*RW words: level j uses word lags K*2^j and TAP*2^j.
@@ -369,7 +486,7 @@ prbs_stream_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwords,
 template <int K>
 __global__ void __launch_bounds__(64, 2)
 prbs_check_rev_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwords, u64 rows_per_wave,
-                      const u64 *__restrict buf, u64 *__restrict nerr) {
+                      const u64 *__restrict buf, u64 *__restrict nerr, const u64 *__restrict seeds) {
     constexpr int TAP = tap_of(K);
     constexpr int RW = 64;
     constexpr int LEVELS = 6;
@@ -383,6 +500,12 @@ prbs_check_rev_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwor
     const u64 rows_total = (nwords - word0 + RW - 1) / RW;
     const long long nrows = (long long)(rows_total < rows_per_wave ? rows_total : rows_per_wave);
 
+    // A whole region with the partition's seeds at hand starts from seed r + 1: the K rows in FRONT of the next region are
+    // this region's last K rows -- the window after the first retreat, which is then skipped (prbs_region_seeds).
+    const bool seeded = seeds != nullptr && (u64)nrows == rows_per_wave;
+    if (seeded) {
+        if (lane < K) X[lane] = seeds[((u64)blockIdx.x + 1) * 32 + (u64)lane];
+    } else {
     // 1. LFSR state at the first bit of the K rows that FOLLOW this region
     constexpr u64 PERIOD = (1ull << K) - 1ull;
     const u64 wtop = word0 + (u64)nrows * RW;
@@ -415,6 +538,7 @@ prbs_check_rev_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwor
         }
         X[lane] = w;
     }
+    }
     __syncthreads();
     {
         int known = K;
@@ -442,10 +566,14 @@ prbs_check_rev_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwor
     u64 errs = 0;
     constexpr int DB = 16;
     constexpr int NB = (K + DB - 1) / DB;
+    bool first_pass = seeded;
     for (long long q0 = nrows - K; q0 > -(long long)K; q0 -= K) {       // the pass covers rows [q0, q0 + K)
-        // retreat the window: V[i] = row q0 + i
+        // retreat the window: V[i] = row q0 + i (a seeded wave's window starts there)
+        if (!first_pass) {
 #pragma unroll
-        for (int i = K - 1; i >= 0; i--) xor_inplace(V[i], V[(i - TAP + K) % K]);
+            for (int i = K - 1; i >= 0; i--) xor_inplace(V[i], V[(i - TAP + K) % K]);
+        }
+        first_pass = false;
         if (q0 >= 0 && word0 + (u64)(q0 + K) * RW <= last_word) {
             const u64 *rowp = buf + (word0 + (u64)q0 * RW);
             u32x2 D[2][DB];
@@ -525,10 +653,16 @@ static int launch_check_rev(int k, int ki, u64 init_state, u64 first_bit, u64 nb
     const u64 nblocks = (rows + rpw - 1) / rpw;
     if (nblocks > 0x7fffffffull) return fail(BBB_EINVAL, "nbits too large");
     dim3 grid((unsigned)nblocks), block(64);
+    const u64 *seeds = nullptr;
+    static const int use_seeds = env_knob("BBB_PRBS_SEEDS", 1);          // (A/B timing; -DBBB_EXPERIMENTS only)
+    if (use_seeds) {
+        const int rcs = prbs_region_seeds(k, ki, init_state, first_bit, rpw, nblocks + 1, st, &seeds);
+        if (rcs) return rcs;
+    }
 #define BBB_PRBS_CASE(KK)                                                                                          \
     case KK:                                                                                                       \
         hipLaunchKernelGGL((prbs_check_rev_kernel<KK>), grid, block, 0, st, ki, init_state, first_bit, nbits, nwords, \
-                           rpw, buf, nerr);                                                                        \
+                           rpw, buf, nerr, seeds);                                                                 \
         break;
     switch (k) {
         BBB_PRBS_CASE(7) BBB_PRBS_CASE(9) BBB_PRBS_CASE(11) BBB_PRBS_CASE(15)
@@ -585,10 +719,16 @@ static int launch_stream_w(int k, int ki, u64 init_state, u64 first_bit, u64 nbi
     const u64 nblocks = (rows + rpw - 1) / rpw;
     if (nblocks > 0x7fffffffull) return fail(BBB_EINVAL, "nbits too large");
     dim3 grid((unsigned)nblocks), block(64);
+    const u64 *seeds = nullptr;
+    static const int use_seeds = env_knob("BBB_PRBS_SEEDS", 1);          // (A/B timing; -DBBB_EXPERIMENTS only)
+    if (use_seeds && WPL == 1) {                    // (one more than the generator needs: the reverse checker of the same range shares the plan)
+        const int rcs = prbs_region_seeds(k, ki, init_state, first_bit, rpw, nblocks + 1, st, &seeds);
+        if (rcs) return rcs;
+    }
 #define BBB_PRBS_CASE(KK)                                                                                       \
     case KK:                                                                                                    \
         hipLaunchKernelGGL((prbs_stream_kernel<KK, CHECK, WPL, LW>), grid, block, 0, st, ki, init_state, first_bit, \
-                           nbits, nwords, rpw, buf, nerr, nt_stores);                                           \
+                           nbits, nwords, rpw, buf, nerr, nt_stores, seeds);                                    \
         break;
     switch (k) {
         BBB_PRBS_CASE(7) BBB_PRBS_CASE(9) BBB_PRBS_CASE(11) BBB_PRBS_CASE(15)
