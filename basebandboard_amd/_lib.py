@@ -18,7 +18,7 @@ SYMBOLS = [
     "bbb_lutopt_load_matrix_file", "bbb_lutopt_create", "bbb_lutopt_destroy", "bbb_lutopt_set_stream",
     "bbb_lutopt_is_specialised", "bbb_lutopt_set_staged", "bbb_lutopt_set_custom_fill", "bbb_lutopt_set_custom_ber", "bbb_lutopt_attach_custom_library", "bbb_lutopt_profile", "bbb_lutopt_profile_read", "bbb_lutopt_profile_read_mover", "bbb_lutopt_state_at", "bbb_lutopt_fill_words", "bbb_awgn_fill_i8", "bbb_awgn_fill_i16", "bbb_awgn_prefetch", "bbb_awgn_stream_open", "bbb_awgn_stream_next", "bbb_awgn_stream_read", "bbb_awgn_stream_seek", "bbb_awgn_stream_tell", "bbb_awgn_stream_close",
     "bbb_clt_tree_i16", "bbb_prbs_fill", "bbb_prbs_fill_hint", "bbb_prbs_check", "bbb_prbs_check_dev", "bbb_prbs_state_at",
-    "bbb_prbs_detector_run", "bbb_prbs_detector_stream", "bbb_ber_trials", "bbb_ber_trials_dev", "bbb_ber_run_open", "bbb_ber_run_next", "bbb_ber_run_next_dev", "bbb_ber_run_tell", "bbb_ber_run_close", "bbb_ber_sweep_multi", "bbb_sweep_shard", "bbb_multi_release", "bbb_shaper_fill_i16", "bbb_tx_fill_i16", "bbb_tx_stream_open", "bbb_tx_stream_next", "bbb_tx_stream_read", "bbb_tx_stream_seek", "bbb_tx_stream_tell", "bbb_tx_stream_close", "bbb_rx_slice", "bbb_rx_phase_search", "bbb_gf2_berlekamp_massey", "bbb_gf2_recur",
+    "bbb_prbs_detector_run", "bbb_prbs_detector_stream", "bbb_ber_trials", "bbb_ber_trials_dev", "bbb_ber_run_open", "bbb_ber_run_next", "bbb_ber_run_next_dev", "bbb_ber_run_tell", "bbb_ber_run_close", "bbb_ber_sweep_multi", "bbb_sweep_shard", "bbb_multi_last_info", "bbb_multi_release", "bbb_shaper_fill_i16", "bbb_tx_fill_i16", "bbb_tx_stream_open", "bbb_tx_stream_next", "bbb_tx_stream_read", "bbb_tx_stream_seek", "bbb_tx_stream_tell", "bbb_tx_stream_close", "bbb_rx_slice", "bbb_rx_phase_search", "bbb_gf2_berlekamp_massey", "bbb_gf2_recur",
     "bbb_gf2_dot", "bbb_gf2_poly_is_primitive", "bbb_gf2_poly_modexp", "bbb_lutopt_charpoly", "bbb_lutopt_is_full_period",
     "bbb_lutopt_save_matrix_file", "bbb_lutopt_search_candidate", "bbb_lutopt_search",
 ]
@@ -53,6 +53,12 @@ class DetectorStats(C.Structure):
 class SearchStats(C.Structure):
     """bbb_search_stats"""
     _fields_ = [(n, C.c_uint64) for n in ("tested", "full_degree", "order_divides", "primitive", "kernel_ns")]
+
+
+class MultiInfo(C.Structure):
+    """bbb_multi_info"""
+    _fields_ = [("n_devices", C.c_int32), ("n_ranks_seen", C.c_int32), ("rccl_reused", C.c_int32), ("reserved", C.c_int32),
+                ("rccl_path", C.c_char * 256)]
 
 
 class Ber(C.Structure):
@@ -125,6 +131,7 @@ def lib():
     l.bbb_prbs_detector_stream.argtypes = [i32, vp, u64, vp, vp, C.POINTER(DetectorStats), u64, u64, i32, vp]
     l.bbb_ber_trials.argtypes = [vp, C.POINTER(TrialCfg), i32, C.POINTER(Ber)]
     l.bbb_ber_trials_dev.argtypes = [vp, C.POINTER(TrialCfg), i32, vp]
+    l.bbb_multi_last_info.argtypes = [C.POINTER(MultiInfo)]
     l.bbb_ber_run_open.argtypes = [vp, C.POINTER(TrialCfg), i32, C.c_uint32, C.POINTER(vp)]
     l.bbb_ber_run_next.argtypes = [vp, C.POINTER(Ber)]
     l.bbb_ber_run_next_dev.argtypes = [vp, vp]

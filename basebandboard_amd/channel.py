@@ -190,6 +190,15 @@ def sweep_multi(urngs, trials, mode=_lib.SHARD_BITS):
     return [(o.bits, o.errors) for o in out]
 
 
+def multi_info():
+    """What the last sweep_multi of this process ran on (bbb_multi_last_info): devices, the communicator's rank count, the
+    RCCL file in use and whether it was the copy the process already held."""
+    m = _lib.MultiInfo()
+    _lib.check(_lib.lib().bbb_multi_last_info(C.byref(m)), "bbb_multi_last_info")
+    return {"n_devices": m.n_devices, "n_ranks_seen": m.n_ranks_seen, "rccl_reused": bool(m.rccl_reused),
+            "rccl_path": m.rccl_path.decode(errors="replace")}
+
+
 # ---- sharding a sweep over ranks (one process per GPU) -----------------------------------------
 
 def shard(ntrials, rank, world):

@@ -53,6 +53,7 @@ int use_device(int device) {
 // device copy of the doubling matrices for one segment length L
 struct JumpPlan {
     GF2Mat B;                     // the per-generator jump itself (host copy, for the first 16 states)
+    GF2Mat Bt;                    // its transpose: y = B x as the XOR of the rows of Bt that x selects (GF2Mat::matvec_t)
     uint32_t *d_cols = nullptr;   // [levels][15][k/4 * 16 * W32] nibble tables of M^(j*16^e)
     int levels = 0;
 };
@@ -227,6 +228,7 @@ int build_plan(const GF2Mat &M, int levels, JumpPlan *plan) {
     BBB_HIP(hipMemcpy(plan->d_cols, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     plan->levels = levels;
     plan->B = M;
+    plan->Bt = M.transpose();
     return BBB_OK;
 }
 
@@ -237,7 +239,7 @@ void first16(const JumpPlan &plan, const uint64_t *s0, uint32_t *out) {
     std::memcpy(x, s0, sizeof(uint64_t) * (size_t)W);
     std::memset(out, 0, sizeof(uint32_t) * 256);
     for (int i = 0; i < 16; i++) {
-        if (i) plan.B.matvec(x, x);
+        if (i) plan.Bt.matvec_t(x, x);
         for (int w = 0; w < 2 * W && w < 16; w++) out[i * 16 + w] = (uint32_t)(x[w >> 1] >> (32 * (w & 1)));
     }
 }
@@ -662,26 +664,28 @@ int ber_run(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, unsigned long lo
         if (L >= (1ull << 27)) return fail(BBB_EINVAL, "nbits too large for one trial (about 2^47): split it with first_bit");
         for (int j = 0; j < n; j++) { td[(size_t)(i + j)].L = (uint32_t)L; td[(size_t)(i + j)].G = G; td[(size_t)(i + j)].nbits = c.nbits; }
         int rc;
+        // The generator's start states first: their chain of launches is what the trial kernel waits for (an isolated call's
+        // wall time starts with the host work in front of the first launch).  The BER kernels take the state OF their first
+        // sample: one clock past the stream position.
+        for (hipEvent_t *e : {&h->ber_fork, &h->ber_join})
+            if (!*e) BBB_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        if (!h->side) BBB_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        BBB_HIP(hipEventRecord(h->ber_fork, h->cs));                  // (the previous trial's kernel may still read d_pplanes)
+        if ((rc = prepare_planes(h, c.warmup + c.first_bit + 1, L, G, nlanes))) return rc;
         // PRBS start states: the same doubling machinery with the k x k LFSR companion matrix.  Queued on the side stream,
-        // so that its chain of small launches runs beside the generator's (both are latency, not work)
+        // so that its launches run beside the generator's (both are latency, not work)
         JumpPlan *pp;
         if ((rc = get_prbs_plan(h, c.prbs_k, L, &pp))) return rc;
+        if ((rc = grow(&h->d_pstates, &h->pstates_cap, (size_t)G))) return rc;
         if ((rc = grow(&h->d_pplanes, &h->pplanes_cap, (size_t)32 * nlanes))) return rc;
         uint64_t ps0 = 0;
         if ((rc = prbs_state_at_host(c.prbs_k, c.prbs_state, c.first_bit, &ps0))) return rc;
         uint64_t ps64[8] = {ps0};
         uint32_t ps16[256];
         first16(*pp, ps64, ps16);
-        if (!h->side) BBB_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-        for (hipEvent_t *e : {&h->ber_fork, &h->ber_join})
-            if (!*e) BBB_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
-        BBB_HIP(hipEventRecord(h->ber_fork, h->cs));                  // (the previous trial's kernel may still read d_pplanes)
         BBB_HIP(hipStreamWaitEvent(h->side, h->ber_fork, 0));
-        if ((rc = grow(&h->d_pstates, &h->pstates_cap, (size_t)G))) return rc;
         if ((rc = prbs_seed_planes_launch(c.prbs_k, pp->d_cols, ps16, G, h->d_pstates, nlanes, h->d_pplanes, h->side))) return rc;
         BBB_HIP(hipEventRecord(h->ber_join, h->side));
-        // (the BER kernels take the state OF their first sample: one clock past the stream position)
-        if ((rc = prepare_planes(h, c.warmup + c.first_bit + 1, L, G, nlanes))) return rc;
         BBB_HIP(hipStreamWaitEvent(h->cs, h->ber_join, 0));
         if (h->specialised) {
             if ((rc = ber256_launch(h->d_planes, h->d_pplanes, &td[(size_t)i], n, nlanes, counters_dev + 2 * (size_t)i, h->cs))) return rc;
@@ -1806,6 +1810,18 @@ int get_comms(const std::vector<int> &devs, std::vector<ncclComm_t> *out) {
 
 }  // namespace
 
+namespace {
+std::mutex g_multi_info_mu;
+bbb_multi_info g_multi_info{};         // what the last bbb_ber_sweep_multi of this process saw
+}  // namespace
+
+int bbb_multi_last_info(bbb_multi_info *out) {
+    if (!out) return fail(BBB_EINVAL, "null argument");
+    std::lock_guard<std::mutex> g(g_multi_info_mu);
+    *out = g_multi_info;
+    return BBB_OK;
+}
+
 int bbb_multi_release(void) {
     std::lock_guard<std::mutex> g(g_comm_mu);
     const Rccl &r = rccl();
@@ -1886,6 +1902,20 @@ int bbb_ber_sweep_multi(bbb_lutopt *const *handles, int ndev, const bbb_trial_cf
         const ncclResult_t e2 = nccl.GroupEnd();
         if (e == ncclSuccess) e = e2;
         if (e != ncclSuccess) return fail(BBB_EHIP, std::string("ncclAllReduce: ") + nccl.GetErrorString(e));
+        // what the communicator itself says (the first multi-device run checks itself with this: bbb_multi_last_info)
+        int seen = 0;
+        if (nccl.CommCount(comms[0], &seen) != ncclSuccess) seen = -1;
+        std::lock_guard<std::mutex> gi(g_multi_info_mu);
+        g_multi_info = bbb_multi_info{};
+        g_multi_info.n_devices = ndev;
+        g_multi_info.n_ranks_seen = seen;
+        g_multi_info.rccl_reused = nccl.reused ? 1 : 0;
+        std::snprintf(g_multi_info.rccl_path, sizeof g_multi_info.rccl_path, "%s", nccl.path.c_str());
+    } else {
+        std::lock_guard<std::mutex> gi(g_multi_info_mu);
+        g_multi_info = bbb_multi_info{};
+        g_multi_info.n_devices = ndev;
+        g_multi_info.n_ranks_seen = 0;         // rehearsal: no communicator
     }
     for (int r = 0; r < ndev; r++) {
         BBB_HIP(hipSetDevice(handles[r]->device));

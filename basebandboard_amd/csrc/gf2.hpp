@@ -45,6 +45,24 @@ struct GF2Mat {
         std::memcpy(y, out, sizeof(uint64_t) * (size_t)W);
     }
 
+    // y = M^T x, i.e. the XOR of the rows of this matrix selected by the bits of x: for y = B x keep B's TRANSPOSE and call
+    // this -- about n/2 row XORs instead of n dot products (4x fewer word operations at n = 256; the per-call host work in
+    // front of a seeding is fifteen of these)
+    void matvec_t(const uint64_t *x, uint64_t *y) const {
+        uint64_t out[8] = {0};
+        for (int w = 0; w < W; w++) {
+            uint64_t bits = x[w];
+            while (bits) {
+                const int c = (w << 6) + __builtin_ctzll(bits);
+                bits &= bits - 1;
+                if (c >= n) break;
+                const uint64_t *b = row(c);
+                for (int q = 0; q < W; q++) out[q] ^= b[q];
+            }
+        }
+        std::memcpy(y, out, sizeof(uint64_t) * (size_t)W);
+    }
+
     // C = this * B : row r of C is the XOR of the rows c of B for which this[r][c] = 1
     GF2Mat mul(const GF2Mat &B) const {
         GF2Mat C(n);

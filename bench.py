@@ -171,6 +171,68 @@ def launch_ranks(n):
     return rc
 
 
+def gather_ranks(dt, dt_own, steps, world, dist, device):
+    """The launch contract's reduction: MAX of the ranks' timed regions (barrier to barrier) -- plus what a first multi-GPU
+    run needs to check itself: how many ranks the process group really holds and every rank's OWN time (its K steps up to
+    its own synchronisation, before the closing barrier: a slow rank shows).  Returns (dt_max, info)."""
+    import torch
+    if world <= 1:
+        return dt, {"n_ranks_seen": 1, "per_rank_ms_per_step": [round(dt_own / steps * 1e3, 4)]}
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    own = torch.tensor([dt_own], dtype=torch.float64, device=device)
+    every = [torch.zeros_like(own) for _ in range(world)]
+    dist.all_gather(every, own)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    per = [float(x.item()) for x in every]
+    return float(t.item()), {"n_ranks_seen": dist.get_world_size(), "per_rank_ms_per_step": [round(x / steps * 1e3, 4) for x in per]}
+
+
+def dry_run(args, emit, rank, world):
+    """BENCH_DRY_RUN=1: everything of a multi-rank run that is NOT GPU work -- the launch (launch_ranks or a launcher), the
+    rendezvous, barriers, the MAX-reduce of the timed region, the counter all-reduces of the sweep and the shape of the JSON
+    line -- on the CPU with gloo, the step replaced by a sleep and the trial runner by a stub with known counters.  For
+    tests/test_bench_launch.py: the first real N > 1 run should meet no surprise outside the kernels.  The line says
+    "dry_run": true and carries no measurement."""
+    import torch
+    import torch.distributed as dist
+    from basebandboard_amd import channel
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (rank + 1))              # (rank r is r + 1 times slower: the MAX must pick the last rank)
+    dt_own = time.perf_counter() - t0
+    barrier()
+    dt = time.perf_counter() - t0
+    dt, info = gather_ranks(dt, dt_own, args.steps, world, dist, "cpu")
+    # the sweep's collectives with a stub runner: trial i on "seed" r counts (1000, 10 i + r)
+    trials = [channel.Trial(nbits=1000, amp=channel.amp_for_ebn0(db, 8), noise_var=8) for db in range(11)]
+    stub = lambda ts, n: torch.tensor([[t.nbits, 10 * i + rank] for i, t in enumerate(ts)], dtype=torch.int64)
+    seeds_total = channel.sweep_seeds(trials, stub, world=world).tolist()
+    bits_total = channel.sweep_bits(trials, lambda ts, n: torch.tensor([[t.nbits, 1] for t in ts], dtype=torch.int64), rank=rank, world=world).tolist()
+    if rank == 0:
+        emit({"metric": "awgn_clt_gsamples_per_s", "value": None, "unit": "Gsample/s", "n_gpus": world, "steps": args.steps,
+              "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+              "vs_baseline": None, "dtype": "u32 bit-sliced GF(2) / int8 out", "data": "synthetic", "dry_run": True,
+              "config": {"workload": "DRY RUN: no GPU work, steps are sleeps of (rank + 1) ms", "samples_per_step_per_gpu": NSAMP},
+              **info,
+              "extra": {"ber_sweep": {"seeds": world, "counters": seeds_total,
+                                      "reduce": "torch.distributed.all_reduce(int64[11,2], SUM), gloo" if world > 1 else "single rank"},
+                        "ber_sweep_bits_sharded": {"counters": bits_total}}})
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -216,6 +278,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         return
+    if os.environ.get("BENCH_DRY_RUN"):
+        return dry_run(args, emit, rank, world)
     # BENCH_BACKEND=gloo + BENCH_SHARE_GPU=1 rehearse the multi-rank code path on a one-GPU box
     backend = os.environ.get("BENCH_BACKEND", "nccl")
     if os.environ.get("BENCH_SHARE_GPU"):
@@ -299,6 +363,8 @@ def main():
     t0 = time.perf_counter()
     for s in range(args.steps):
         one_step()
+    torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0               # this rank's own K steps (for the record; the metric is barrier to barrier)
     barrier()
     dt = time.perf_counter() - t0
     seed_ms, kern_ms, calls = u.profile_read(reset=True)
@@ -307,10 +373,7 @@ def main():
     if st is not None:
         st.close()
     look_ahead = level if level >= 2 else (2 if (staged and not level) else 0)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, rank_info = gather_ranks(dt, dt_own, args.steps, world, dist, f"cuda:{local_rank}" if backend == "nccl" else "cpu")
     verified = None
     if rank == 0:
         import numpy as np
@@ -577,17 +640,77 @@ def main():
             "labels": "ebn0_db = amp^2 / (2 (8 nv)^2), ignores that the sample is an integer; ebn0_db_effective / q_lattice account for "
                       "the integer decision threshold (channel.ber_lattice) and are the ones comparable with Q(sqrt(2 Eb/N0))",
             "reduce": "torch.distributed.all_reduce(int64[11,2], SUM) over RCCL, one seed per rank" if world > 1 else "single rank"}
+        # The same sweep CONTINUED over many calls (bbb_ber_run_*: one seeding of the generators per block of 8 calls, the
+        # kernel leaves its states for the next call): what a Monte-Carlo run that keeps adding bits until it has seen enough
+        # errors pays per 11 x 1e9 bits.  16 calls timed, the blocks' seedings inside; every rank on its own seed, ONE
+        # all-reduce of the totals at the end.
+        cont_calls, cont_block = 16, 8
+        with channel.ContinuedTrials(us, trials, cont_block) as run:
+            cacc = torch.zeros((len(trials), 2), dtype=torch.int64, device=dev)
+            for _ in range(cont_block):
+                run.next_into(cacc)                 # (jump plans of the block's segment length; clocks)
+            cacc.zero_()
+            torch.cuda.synchronize(); barrier()
+            tc0 = time.perf_counter()
+            for _ in range(cont_calls):
+                run.next_into(cacc)
+            torch.cuda.synchronize(); barrier()
+            tcont = time.perf_counter() - tc0
+        if world > 1:
+            if backend == "nccl":
+                dist.all_reduce(cacc, op=dist.ReduceOp.SUM)
+            else:                                    # (gloo rehearsal: through the host)
+                hc = cacc.cpu()
+                dist.all_reduce(hc, op=dist.ReduceOp.SUM)
+                cacc.copy_(hc)
+        ctot = cacc.cpu().tolist()
+        cont_ms = tcont / cont_calls * 1e3
+        extra["ber_sweep_continued"] = {
+            "calls": cont_calls, "calls_per_seeding": cont_block, "bits_per_point_and_call": 1_000_000_000,
+            "ms_per_call": round(cont_ms, 4), "gbit_s": round(world * cont_calls * 11e9 / tcont / 1e9, 2),
+            "bits_per_point": ctot[0][0], "errors": [e_ for _, e_ in ctot],
+            "what": "bbb_ber_run_next_dev: 11 settings x 1e9 bits per call on one pass of the noise stream, a block of 8 calls shares one seeding "
+                    "(the (bit, sample) pairs of a block are those of one bbb_ber_trials call over its 8e9 bits: tests/test_gpu_ber.py)"}
+        # roofline record of the trial kernel: integer VALU issue, like the sample kernel (counts from this round's SQ pass)
+        try:
+            bp = json.load(open(ROOT / "profiles" / "r04_ber_pmc.json"))
+            vps = bp["fused"]["valu_insts_per_step_and_wave"]
+            kms = bp["fused"].get("kernel_ms_avg")
+        except Exception:
+            vps, kms = 1203.0, None
+        t_k = (kms or cont_ms) * 1e-3
+        ber_issued_t = vps / 32.0 * 1e9 / t_k / 1e12
+        other.append({"kernel": "ber256_fused_kernel<fast, 11> (one pass of the noise stream for 11 channel settings)", "bound": "valu",
+                      "achieved": round(ber_issued_t, 2), "peak": 78.64, "unit": "T lane-op/s", "frac": round(ber_issued_t / 78.64, 3),
+                      "valu_frac_issued": round(ber_issued_t / 78.64, 3), "valu_frac_issued_of_1wave_ceiling": round(ber_issued_t / 39.32, 3),
+                      "valu_issued_per_step_and_wave": vps, "kernel_ms_avg": round(t_k * 1e3, 4),
+                      "kernel_ms_source": "profiles/r04_ber_pmc.json (rocprofv3 kernel trace)" if kms else "bbb_ber_run_next_dev per call (includes the state write-back)",
+                      "algorithmic_bytes_per_launch": 0,
+                      "what": "no sample stream is written: 1061-instruction generator step + 16 more AGPR moves + 8 + 11 x 10 comparator instructions per 32 bits and "
+                              "lane; one wave per SIMD, power limited (2.15-2.2 GHz alone: profiles/README.md)"})
+        if world > 1:
+            # BASELINE configs[4] the other way: every rank runs all points over ITS slice of the bit range, ONE all-reduce; the totals
+            # must equal the undivided trials on one device exactly (rank 0 runs those too)
+            tb1 = time.perf_counter()
+            btot = channel.sweep_bits(trials, channel.gpu_runner(u), rank=rank, world=world)
+            torch.cuda.synchronize(); barrier()
+            tb1 = time.perf_counter() - tb1
+            single = channel.run_trials(u, trials) if rank == 0 else None
+            extra["ber_sweep_bits_sharded"] = {"n_ranks": world, "gbit_s": round(11e9 / tb1 / 1e9, 2),
+                                               "equals_single_device_counters": (btot.cpu().tolist() == [list(x) for x in single]) if rank == 0 else None,
+                                               "reduce": "torch.distributed.all_reduce(int64[11,2], SUM) over RCCL, one bit slice per rank"}
         if world == 1:
             # the same sweep through the C ABI's own multi-device entry (host thread per device + ONE ncclAllReduce),
             # here over this one device
-            from basebandboard_amd.channel import sweep_multi
+            from basebandboard_amd.channel import sweep_multi, multi_info
             sweep_multi([u], warm)
             tm = time.perf_counter()
             got = sweep_multi([u], trials)
             tm = time.perf_counter() - tm
             extra["ber_sweep_multi_c_abi"] = {"n_devices": 1, "equals_single_device_counters": [list(x) for x in got] == tot,
                                               "gbit_s": round(sum(b_ for b_, _ in got) / tm / 1e9, 2),
-                                              "reduce": "ncclAllReduce(ncclUint64, ncclSum) of uint64[22] inside bbb_ber_sweep_multi"}
+                                              "reduce": "ncclAllReduce(ncclUint64, ncclSum) of uint64[22] inside bbb_ber_sweep_multi",
+                                              **multi_info()}
 
     if rank == 0:
         # issued VALU instructions per step and wave: from the SQ pass of this round (SQ_INSTS_VALU), else the ISA count
@@ -612,6 +735,8 @@ def main():
             "metric": "awgn_clt_gsamples_per_s", "value": round(value, 3), "unit": "Gsample/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            # (a multi-rank run checks itself: ranks in the process group, every rank's own time -- ms_per_step is their MAX)
+            "n_ranks_seen": rank_info["n_ranks_seen"], "per_rank_ms_per_step": rank_info["per_rank_ms_per_step"],
             "vs_baseline": None, "dtype": "u32 bit-sliced GF(2) / int8 out", "data": "synthetic",
             "config": {"workload": "CLT AWGN (LUTOPT-256 -> CLTGRNG adder tree), 1e9 int8 samples/step/GPU, init=1, "
                                    "warm-up 16, sequential reference stream (BASELINE configs[1]; reference-faithful "

@@ -294,6 +294,8 @@ int main(int argc, char **argv) {
     std::vector<bbb_ber> out(cfg.size()), part(cfg.size());
     double ms = 0;
     const char *reduce = "single device";
+    bbb_multi_info minfo{};
+    int equals_single = -1;              // -1: not compared (single device, or one seed per device)
     if (gpus > 1 || multi) {
         // one handle per device; seeds mode gives device d seed d
         std::vector<bbb_lutopt *> hs((size_t)gpus, nullptr);
@@ -306,6 +308,16 @@ int main(int argc, char **argv) {
         const double t0 = now_s();
         CHECK(bbb_ber_sweep_multi(hs.data(), gpus, cfg.data(), (int)cfg.size(), mode, out.data()));
         ms = (now_s() - t0) * 1e3;
+        // a multi-device run checks itself: what the communicator says, which RCCL it was, and -- for the sharding modes whose
+        // totals do not depend on the device count -- the same trials on device 0 alone
+        CHECK(bbb_multi_last_info(&minfo));
+        if (mode != BBB_SHARD_SEEDS) {
+            std::vector<bbb_ber> single(cfg.size());
+            CHECK(bbb_ber_trials(hs[0], cfg.data(), (int)cfg.size(), single.data()));
+            equals_single = 1;
+            for (size_t i = 0; i < cfg.size(); i++)
+                if (single[i].bits != out[i].bits || single[i].errors != out[i].errors) equals_single = 0;
+        }
         for (auto *h : hs) CHECK(bbb_lutopt_destroy(h));
         CHECK(bbb_multi_release());
         reduce = "ncclAllReduce(uint64[2 x points], sum) over the devices of this process";
@@ -351,8 +363,11 @@ int main(int argc, char **argv) {
     if (json)
         std::printf("{\"mode\": \"ber_sweep\", \"prbs_k\": %d, \"points\": %zu, \"n_gpus\": %d, \"shard\": \"%s\", \"seeds\": %d, \"total_bits\": %llu, "
                     "\"ms\": %.3f, \"gbit_trials_s\": %.2f, \"hbm_bytes_per_bit\": 0, \"hbm_roofline_frac\": null, "
-                    "\"bound\": \"integer VALU (no sample stream is written)\", \"reduce\": \"%s\"}\n",
-                    k, cfg.size(), gpus, shard.c_str(), seeds, total_bits, ms, ms > 0 ? (double)total_bits / (ms * 1e-3) / 1e9 : 0.0, reduce);
+                    "\"bound\": \"integer VALU (no sample stream is written)\", \"reduce\": \"%s\", \"n_ranks_seen\": %d, "
+                    "\"rccl_path\": \"%s\", \"rccl_reused\": %s, \"equals_single_device_counters\": %s}\n",
+                    k, cfg.size(), gpus, shard.c_str(), seeds, total_bits, ms, ms > 0 ? (double)total_bits / (ms * 1e-3) / 1e9 : 0.0, reduce,
+                    minfo.n_ranks_seen, minfo.rccl_path, minfo.rccl_reused ? "true" : "false",
+                    equals_single < 0 ? "null" : (equals_single ? "true" : "false"));
     if (loopback > 0) {
         const uint64_t nb = (uint64_t)loopback;
         uint64_t *buf = nullptr;

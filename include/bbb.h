@@ -320,6 +320,18 @@ int bbb_ber_sweep_multi(bbb_lutopt *const *handles, int ndev, const bbb_trial_cf
                         bbb_ber *out);
 /* The share of `rank` among `ndev`: mine[i] is trial i as that rank runs it (nbits = 0: not at all). */
 int bbb_sweep_shard(const bbb_trial_cfg *cfgs, int ncfg, int ndev, int rank, int mode, bbb_trial_cfg *mine);
+/* What the last bbb_ber_sweep_multi of this process ran on, for a caller (or a first multi-GPU run) that wants to check
+ * itself: the number of handles it was given, the rank count the RCCL communicator reports (ncclCommCount), the file the
+ * RCCL entry points were resolved from and whether that library was already mapped in the process (a PyTorch process holds
+ * its own copy: it is reused, not loaded a second time). */
+typedef struct {
+    int32_t n_devices;      /* handles of the call */
+    int32_t n_ranks_seen;   /* ncclCommCount of its communicator (0: no call yet) */
+    int32_t rccl_reused;    /* 1: found with RTLD_NOLOAD */
+    int32_t reserved;
+    char    rccl_path[256];
+} bbb_multi_info;
+int bbb_multi_last_info(bbb_multi_info *out);
 /* Destroy the cached RCCL communicators (optional; before unloading the library or resetting devices). */
 int bbb_multi_release(void);
 
