@@ -439,7 +439,12 @@ int produce_planes(bbb_lutopt *h, uint64_t L, unsigned nlanes, bbb_lutopt::ProfE
     }
     // (the skip holds only while no LATER mover was queued on the slot: a prefetch stays valid across fills that do not
     // match it, and those may have put new movers on this very slot since its seeding waited)
+    // (BBB_SCHED_MODEL_REVERT_STALE_SKIP: without the generation check -- the round-2 advisor's case; tests/test_sched_model.py only)
+#ifndef BBB_SCHED_MODEL_REVERT_STALE_SKIP
     const bool seeding_saw_last_mover = planes_seeded_after_mover && h->pf_waited_slot == slot && h->pf_waited_gen == h->stage_gen[slot];
+#else
+    const bool seeding_saw_last_mover = planes_seeded_after_mover && h->pf_waited_slot == slot;
+#endif
     if (planes_seeded_after_mover) h->pf_waited_slot = -1;          // consumed
     if (h->stage_busy[slot] && !seeding_saw_last_mover)
         BBB_HIP(hipStreamWaitEvent(h->cs, h->stage_free[slot], 0));   // its last mover has read it
@@ -833,6 +838,9 @@ int bbb_lutopt_destroy(bbb_lutopt *h) {
     for (hipEvent_t e : {h->pf.seeded, h->pf.last_read, h->cur_last_read, h->handover, h->stage_free[0], h->stage_free[1],
                          h->stage_arith[0], h->stage_arith[1], h->ev_user, h->fbits_read[0], h->fbits_read[1], h->fbits_ready, h->ber_fork, h->ber_join})
         if (e) (void)hipEventDestroy(e);
+    // (profiling events of calls whose times were never read: found by the scheduler model's leak check, tests/sched_model)
+    for (auto &pr : h->prof_mover_pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto &ev : h->prof_pending) { (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); (void)hipEventDestroy(ev.e2); }
     for (hipStream_t st : {h->side, h->xs2[0], h->xs2[1], h->ys})
         if (st) (void)hipStreamDestroy(st);
     (void)hipFree(h->d_stage[0]);
@@ -1014,8 +1022,14 @@ static int awgn_prefetch(bbb_lutopt *h, uint64_t nsamples, uint64_t first_step, 
     // An announcement that was never taken leaves its seeding behind -- queued on the arithmetic stream of the fill it expected,
     // which need not be the one this seeding goes to: without this wait the two would write the same buffers side by side
     // (the soak test's case: a hint whose fill came with another partition, then the next hint).
+    // (BBB_SCHED_MODEL_REVERT_UNTAKEN_HINT: the scheduler as it stood BEFORE this wait existed -- defined only by
+    // tests/test_sched_model.py, which must see the model of tests/sched_model/ find that race)
+#ifndef BBB_SCHED_MODEL_REVERT_UNTAKEN_HINT
     if (pf.seeded) BBB_HIP(hipStreamWaitEvent(side, pf.seeded, 0));
     else BBB_HIP(hipEventCreateWithFlags(&pf.seeded, hipEventDisableTiming));
+#else
+    if (!pf.seeded) BBB_HIP(hipEventCreateWithFlags(&pf.seeded, hipEventDisableTiming));
+#endif
     // the buffers may still be read by the sample kernel that used them last (main stream)
     if (pf.read_pending) BBB_HIP(hipStreamWaitEvent(side, pf.last_read, 0));
     if (pf.states_cap < (size_t)G * h->W32 || pf.planes_cap < (size_t)2 * h->k * nlanes) {
