@@ -107,7 +107,10 @@ ber256_fused_kernel(BerMasks mk, uint32_t *__restrict planes, uint32_t *__restri
     typedef const uint32_t __attribute__((address_space(4))) *kptr_t;
     typedef uint32_t s8_t __attribute__((ext_vector_type(8)));
     const kptr_t mp = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();       // the table is the FIRST kernel argument: offset 0
-    constexpr int kRes = MODE == kBerFast ? (NC < 7 ? NC : 7) : 0;
+    #ifndef BBB_BER_KRES
+#define BBB_BER_KRES 7
+#endif
+    constexpr int kRes = MODE == kBerFast ? (NC < BBB_BER_KRES ? NC : BBB_BER_KRES) : 0;
     uint32_t eqm[MODE == kBerFast ? NC : 1], tmr[kRes ? kRes : 1][8];
     if constexpr (MODE == kBerFast) {
 #pragma unroll

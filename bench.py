@@ -409,7 +409,7 @@ def main():
     # committed summary of this round's passes and says which file it came from (stale if the kernels changed since)
     traffic = traffic_src = traffic_step = None
     pmc_rec = {}
-    for name in ("r03_awgn_pmc.json",):
+    for name in ("r04_awgn_pmc.json", "r03_awgn_pmc.json"):
         pmc = ROOT / "profiles" / name
         if pmc.exists() and staged:
             try:
@@ -476,8 +476,8 @@ def main():
         check = lambda first, n: _lib.check(L.bbb_prbs_check_dev(31, 1, first, n, C.c_void_p(pbuf.data_ptr() + first // 8),
                                                                 C.c_void_p(cnt.data_ptr()), local_rank, sp), "bbb_prbs_check_dev")
         fill_rb = lambda first, n: _lib.check(L.bbb_prbs_fill_hint(31, 1, first, n, C.c_void_p(pbuf.data_ptr() + first // 8), 1, local_rank, sp), "bbb_prbs_fill_hint")
-        for _ in range(2):
-            fill(0, nbits); check(0, nbits)
+        for _ in range(4):                      # (the buffer's pages, the region-seed plan, clocks)
+            fill_rb(0, nbits); check(0, nbits)
         torch.cuda.synchronize()
         reps = 5
         # the loopback as a loopback caller runs it: the fill told that a check follows (BBB_PRBS_WILL_READ_BACK)
@@ -525,17 +525,18 @@ def main():
         noise = torch.randint(0, 1000, (pbuf.numel(),), device=pbuf.device) == 0
         pbuf ^= noise.to(torch.int64) << 13
         del noise
-        det.run_stream(pbuf, nbits)
+        for _ in range(3):                      # (workspace, pinned read-back buffer, clocks: the first call takes 2 ms, the second 0.34)
+            det.run_stream(pbuf, nbits)
         torch.cuda.synchronize()
         td = time.perf_counter()
-        ds = det.run_stream(pbuf, nbits)
-        torch.cuda.synchronize()
-        td = time.perf_counter() - td
+        for _ in range(3):
+            ds = det.run_stream(pbuf, nbits)    # (every call synchronises: it returns the totals)
+        td = (time.perf_counter() - td) / 3
         extra["detector_stream"] = {"bits": nbits, "errors": ds["errors"], "resyncs": ds["resyncs"], "chunks": ds["chunks"],
                                     "chunks_rerun": ds["chunks_rerun"], "gbit_s": round(nbits / td / 1e9, 1),
-                                    "note": "bbb_prbs_detector_stream, totals only, includes its verify passes and host syncs"}
-        r = hbm("det_chunk_kernel<31> + verify passes (whole call, wall clock)", nbytes, td * 1e3, "1/8 B per bit read")
-        r["true_bound"] = "integer VALU issue (~80-110 instructions per 64-bit word on the locked path: 64-bit ops in halves, counters, exec-mask bookkeeping); the chunk pass is 0.44 of the call's 0.50 ms (verify, re-run of the inconsistent chunks, verify, one read-back: 0.04), not HBM"
+                                    "note": "bbb_prbs_detector_stream, totals only, wall time per call over three calls, includes its verify pass, read-back and host synchronisation"}
+        r = hbm("det_fused_kernel<31> + verify pass (whole call, wall clock)", nbytes, td * 1e3, "1/8 B per bit read")
+        r["true_bound"] = "HBM read of the classification pass (0.20-0.22 ms of the call's 0.29-0.31: 5.7-6.3 TB/s); the serial machine visits ~2 % of the words (DESIGN.md 3.7)"
         other.append(r)
         del pbuf
         # TX output stream: shaped PRBS-31 + scaled CLT noise, int16, 8 samples/bit
@@ -628,14 +629,26 @@ def main():
         tb0 = time.perf_counter()
         total = channel.sweep_seeds(trials, channel.gpu_runner(us), world=world)
         torch.cuda.synchronize(); barrier()
-        tber = time.perf_counter() - tb0
+        tber_isolated = time.perf_counter() - tb0
         tot = total.cpu().tolist()
+        # the same sweep three times back to back, every one at another stream position (every one seeds for itself): the
+        # host's work in front of a call's first launch (55 us) and the idle GPU's first-launch latency overlap the call before
+        nrep = 3
+        reps_t = [[channel.Trial(nbits=t.nbits, amp=t.amp, noise_var=nv, first_bit=(2 + i) << 21) for t in trials] for i in range(nrep)]
+        torch.cuda.synchronize(); barrier()
+        tb0 = time.perf_counter()
+        for i in range(nrep):
+            channel.sweep_seeds(reps_t[i], channel.gpu_runner(us), world=world)
+        torch.cuda.synchronize(); barrier()
+        tber = (time.perf_counter() - tb0) / nrep
         extra["ber_sweep"] = {
             "points": [{"ebn0_db": round(channel.ebn0_db(t.amp, nv), 3), "ebn0_db_effective": round(channel.ebn0_db_effective(t.amp, nv), 3),
                         "amp": t.amp, "noise_var": nv, "bits": b_, "errors": e_, "ber": e_ / b_ if b_ else None,
                         "q_theory": channel.ber_theory(channel.ebn0_db(t.amp, nv)), "q_lattice": channel.ber_lattice(t.amp, nv)}
                        for t, (b_, e_) in zip(trials, tot)],
-            "gbit_s": round(sum(b_ for b_, _ in tot) / tber / 1e9, 2), "seconds": round(tber, 4),
+            "gbit_s": round(sum(b_ for b_, _ in tot) / tber / 1e9, 2), "seconds": round(tber, 6),
+            "gbit_s_is": "per sweep over three sweeps back to back, each at its own stream position with its own seeding (counters below: the first, isolated one)",
+            "isolated_call_gbit_s": round(sum(b_ for b_, _ in tot) / tber_isolated / 1e9, 2), "isolated_call_seconds": round(tber_isolated, 6),
             "seeds": world, "seeding_in_timed_region": True,
             "labels": "ebn0_db = amp^2 / (2 (8 nv)^2), ignores that the sample is an integer; ebn0_db_effective / q_lattice account for "
                       "the integer decision threshold (channel.ber_lattice) and are the ones comparable with Q(sqrt(2 Eb/N0))",
