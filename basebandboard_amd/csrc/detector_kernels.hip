@@ -392,6 +392,59 @@ __device__ __forceinline__ void det_classify_256(const u64x2 a0, const u64x2 a1,
     me0 = __ballot(e0); mo0 = __ballot(o0); me1 = __ballot(e1); mo1 = __ballot(o1);
 }
 
+// The same for a half (128 words) in the INTERIOR of the stream, with what the half in front of it left behind: the cheap form
+// (the form above spends 35 instructions per word and lane, most of them cross-lane traffic through LDS and the recomputation
+// of every word's history; this one 25 and no LDS.  The kernel's time did not move -- 0.255-0.26 ms either way: it is bound by
+// the memory system's rate for 4768 waves streaming 4768 separate 256 KiB stretches, where the grid-strided classification
+// kernel of the two-kernel form reads at 5.7-6.3 TB/s -- but the instructions it no longer issues are energy.)
+// Every lane forms the delayed words V of its own two words ONCE; a neighbour's V comes by DPP (wave_shr:1: lane l reads lane
+// l - 1, lane 0 keeps the `old` operand, which is the previous half's lane 63 by V_READLANE): no LDS, no select.
+struct DetHalfV { u64 vx, vy; };
+__device__ __forceinline__ uint32_t det_shr1(const uint32_t cur, const uint32_t prev_half) {      // [l] = cur[l - 1]; [0] = prev_half[63]
+    const uint32_t fill = (uint32_t)__builtin_amdgcn_readlane((int)prev_half, 63);
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)cur, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t det_shr2(const uint32_t cur_shr1, const uint32_t prev_half) { // [l] = cur[l - 2]; [1] = prev_half[63]; [0] = prev_half[62]
+    const uint32_t fill = (uint32_t)__builtin_amdgcn_readlane((int)prev_half, 62);
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)cur_shr1, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ u64 det_u64(uint32_t lo, uint32_t hi) { return (u64)lo | ((u64)hi << 32); }
+// V of this lane's two words; prev_yhi = the top dword of the previous half's y word (this lane's: lane 63's is what counts)
+__device__ __forceinline__ DetHalfV det_half_v(const u64x2 cur, const uint32_t prev_yhi) {
+    const uint32_t yh = (uint32_t)(cur.y >> 32);
+    const uint32_t before_x = det_shr1(yh, prev_yhi);            // top dword of the word in front of cur.x
+    DetHalfV v;
+    v.vx = (cur.x << 1) | (u64)(before_x >> 31);
+    v.vy = (cur.y << 1) | (cur.x >> 63);
+    return v;
+}
+template <int K>
+__device__ __forceinline__ void det_half_flags(const u64x2 cur, const DetHalfV v, const DetHalfV pv, bool &fe, bool &fo) {
+    typedef DetLag<K> LG;
+    constexpr int NH = LG::NH, TAP = det_tap_of(K);
+    // the neighbours' V: lane l - 1 (and for three history words lane l - 2)
+    const uint32_t y1l = det_shr1((uint32_t)v.vy, (uint32_t)pv.vy), y1h = det_shr1((uint32_t)(v.vy >> 32), (uint32_t)(pv.vy >> 32));
+    const uint32_t x1l = det_shr1((uint32_t)v.vx, (uint32_t)pv.vx), x1h = det_shr1((uint32_t)(v.vx >> 32), (uint32_t)(pv.vx >> 32));
+    const u64 vy1 = det_u64(y1l, y1h), vx1 = det_u64(x1l, x1h);            // V_{n0-1}, V_{n0-2}
+    u64 he[3] = {0, 0, 0}, ho[3] = {0, 0, 0};                              // histories of the even (x) and the odd (y) word, oldest first
+    if constexpr (NH == 2) {
+        he[0] = vx1; he[1] = vy1;
+        ho[0] = vy1; ho[1] = v.vx;
+    } else {
+        const u64 vy2 = det_u64(det_shr2(y1l, (uint32_t)pv.vy), det_shr2(y1h, (uint32_t)(pv.vy >> 32)));      // V_{n0-3}
+        he[0] = vy2; he[1] = vx1; he[2] = vy1;
+        ho[0] = vx1; ho[1] = vy1; ho[2] = v.vx;
+    }
+    auto one = [&](const u64 (&fh)[3], const u64 V, const u64 w) -> bool {
+        const u64 Fp = det_hist_window<64 * NH - LG::LAGK, NH>(fh) ^ det_hist_window<64 * NH - LG::LAGT, NH>(fh);
+        const uint32_t vh = (uint32_t)(V >> 32);
+        const uint32_t last = (uint32_t)(w >> 32) ^ (vh << (K - 1)) ^ (vh << (TAP - 1));
+        return V == Fp && (int32_t)last >= 0;
+    };
+    fe = one(he, v.vx, cur.x);
+    fo = one(ho, v.vy, cur.y);
+}
+
 // words i, i + 1 of a stream that is read once: non-temporal (the stream's last word may stand alone)
 __device__ __forceinline__ u64x2 det_load2(const u64 *__restrict src, const u64 i, const u64 nwords) {
     if (i + 1 < nwords) return __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(src + i));
@@ -603,12 +656,28 @@ det_fused_kernel(const u64 *__restrict src, u64 nbits, u64 nwords, u64 chunk_wor
         u64x2 p0, p1, ph, q0, q1, qh;
         fetch(base, p0, p1, ph);
         fetch(base + 256, q0, q1, qh);
+        DetHalfV pv = {0, 0};                        // the V words of the half in front (valid from the second step on)
+        uint32_t pyh = 0;
         for (; base < r1; base += 256) {
             const u64x2 a0 = p0, a1 = p1, h = ph;
             p0 = q0; p1 = q1; ph = qh;
             fetch(base + 512, q0, q1, qh);
             u64 me0, mo0, me1, mo1;
-            det_classify_256<K>(a0, a1, h, base, nfull, lane, me0, mo0, me1, mo1);
+            // interior steps (every word has its NH + 1 predecessors, all 256 words are whole words of the stream, and the
+            // step in front left its V words): the cheap form; the region's first step and the stream's last: the general one
+            const bool interior = base > r0 && base >= 256 && base + 256 <= nfull;
+            DetHalfV v0 = det_half_v(a0, pyh);
+            DetHalfV v1 = det_half_v(a1, (uint32_t)(a0.y >> 32));
+            if (interior) {
+                bool e0, o0, e1, o1;
+                det_half_flags<K>(a0, v0, pv, e0, o0);
+                det_half_flags<K>(a1, v1, v0, e1, o1);
+                me0 = __ballot(e0); mo0 = __ballot(o0); me1 = __ballot(e1); mo1 = __ballot(o1);
+            } else {
+                det_classify_256<K>(a0, a1, h, base, nfull, lane, me0, mo0, me1, mo1);
+            }
+            pv = v1;
+            pyh = (uint32_t)(a1.y >> 32);
             if (lane == 0) {
                 const u64 i = (base - r0) >> 6;
                 *reinterpret_cast<u64x2 *>(lf + i) = (u64x2){me0, mo0};
