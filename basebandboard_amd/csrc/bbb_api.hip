@@ -154,6 +154,7 @@ struct bbb_lutopt {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_mover_pending;      // around every mover, on its stream
     double prof_mover_ms = 0; uint64_t prof_mover_calls = 0;
     std::vector<ProfEv> prof_pending;
+    hipEvent_t prof_prev_e2 = nullptr;    // completion of the last sample kernel bbb_lutopt_profile_read has accounted for
     double prof_seed_ms = 0, prof_main_ms = 0;
     uint64_t prof_calls = 0;
 };
@@ -517,8 +518,14 @@ int awgn_fill(bbb_lutopt *h, void *dst, int elem_size, uint64_t nsamples, uint64
     const bool staged = fast256 && h->staged_mode && nsamples >= (1ull << 24);
     // look-ahead: this very range was produced by the previous fill's sample kernel and waits in its staging slot
     if (staged && h->ahead.valid && h->ahead.kind == 0 && h->ahead.first == first_step && h->ahead.n == nsamples) {
-        int rc0 = begin_op(h, true);
-        if (rc0) return rc0;
+        // (no begin_op: a delivery queues nothing on an arithmetic stream -- its mover waits for the slot's sample kernel and the
+        // caller's stream by their own events.  Taking the NEXT slot's arithmetic stream here, as rounds 2-3 did, tied that
+        // stream to the running sample kernel with a handover event: the next sample kernel, whose announced start states make
+        // it independent of the running one, then started an event round trip (26-47 us) after it instead of into its tail)
+        if (env_knob("BBB_EXP_DELIVER_HANDOVER", 0)) {
+            int rc0 = begin_op(h, true);
+            if (rc0) return rc0;
+        }
         const bbb_lutopt::Ahead a = h->ahead;
         h->ahead.first += nsamples; h->ahead.step += nsamples;
         h->ahead.win_lo += nsamples;
@@ -841,6 +848,7 @@ int bbb_lutopt_destroy(bbb_lutopt *h) {
     // (profiling events of calls whose times were never read: found by the scheduler model's leak check, tests/sched_model)
     for (auto &pr : h->prof_mover_pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto &ev : h->prof_pending) { (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); (void)hipEventDestroy(ev.e2); }
+    if (h->prof_prev_e2) (void)hipEventDestroy(h->prof_prev_e2);
     for (hipStream_t st : {h->side, h->xs2[0], h->xs2[1], h->ys})
         if (st) (void)hipStreamDestroy(st);
     (void)hipFree(h->d_stage[0]);
@@ -915,8 +923,18 @@ int bbb_lutopt_profile_read(bbb_lutopt *h, double *seed_ms, double *kernel_ms, u
         float a = 0, b = 0;
         BBB_HIP(hipEventElapsedTime(&a, ev.e0, ev.e1));
         BBB_HIP(hipEventElapsedTime(&b, ev.e1, ev.e2));
+        // A sample kernel whose start states were announced is queued while the previous one still holds every SIMD (one
+        // 512-register wave each): between e1 and e2 it first WAITS for those waves to retire.  Its time on the machine is
+        // counted from the later of its own dispatch and the previous sample kernel's completion.
+        if (h->prof_prev_e2) {
+            float c = 0;
+            BBB_HIP(hipEventElapsedTime(&c, h->prof_prev_e2, ev.e2));
+            if (c > 0 && c < b) b = c;
+            (void)hipEventDestroy(h->prof_prev_e2);
+        }
+        h->prof_prev_e2 = ev.e2;
         h->prof_seed_ms += a; h->prof_main_ms += b; h->prof_calls++;
-        (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); (void)hipEventDestroy(ev.e2);
+        (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1);
     }
     h->prof_pending.clear();
     if (seed_ms) *seed_ms = h->prof_seed_ms;
@@ -1370,7 +1388,8 @@ int bbb_tx_fill_i16(bbb_lutopt *h, const bbb_tx_cfg *cfg, int16_t *out_dev, uint
             // who changes it mid-stream gets a fresh kernel, as before)
             if (h->ahead.valid && h->ahead.kind == 1 && h->ahead.first == first_sample && h->ahead.n == nsamples &&
                 tx_cfg_equal(h->ahead.cfg, *cfg)) {
-                if ((rc = begin_op(h, true))) return rc;
+                // (no begin_op: see awgn_fill's look-ahead delivery)
+                if (env_knob("BBB_EXP_DELIVER_HANDOVER", 0) && (rc = begin_op(h, true))) return rc;
                 const bbb_lutopt::Ahead a = h->ahead;
                 // its data bits sit in the slot's buffer, behind those of the windows before it
                 d_bits = h->d_mbits[a.slot]; words64 = a.bits_words64;

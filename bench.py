@@ -765,7 +765,10 @@ def main():
                        "verified_vs_oracle": verified},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "achieved_is": "sample kernel only: algorithmic bytes per launch / its mean duration (hipEvents on its stream)",
+                         "achieved_is": "sample kernel only: algorithmic bytes per launch / its mean duration (hipEvents on its stream; a launch "
+                                        "that is dispatched while the previous sample kernel still holds every SIMD is counted from that "
+                                        "kernel's completion -- its time on the machine, which is also the spacing of the kernels' END "
+                                        "timestamps in the rocprofv3 trace: tools/trace_spacing.py, profiles/README.md)",
                          # the whole step: sample kernel + mover + seeding, per 1e9 samples delivered
                          "traffic_step": traffic_step,
                          "kernel": "awgn256_planes_kernel" if staged else "awgn256_kernel<false>", "kernel_ms_avg": round(kern_avg_ms, 4),

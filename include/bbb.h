@@ -79,7 +79,9 @@ int bbb_lutopt_is_specialised(const bbb_lutopt *h);
 /* Device-side timing of the generator kernels with hipEvents recorded on the handle's stream
  * around every bbb_awgn_fill_i8 of a specialised handle: [start, seeding kernels, sample kernel].
  * bbb_lutopt_profile_read waits for the recorded events and returns the accumulated
- * milliseconds (seeding / sample kernel) and the number of calls; reset != 0 clears the sums. */
+ * milliseconds (seeding / sample kernel) and the number of calls; reset != 0 clears the sums.
+ * A sample kernel that is dispatched while the previous one still holds the machine (the staged form with announced
+ * start states) is counted from that kernel's completion, not from its own dispatch: time on the machine. */
 int bbb_lutopt_profile(bbb_lutopt *h, int enable);
 int bbb_lutopt_profile_read(bbb_lutopt *h, double *seed_ms, double *kernel_ms, uint64_t *calls, int reset);
 /* The same for the second kernel of the two-kernel form (the mover, on its internal stream): accumulated milliseconds
