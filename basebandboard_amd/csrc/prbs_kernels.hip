@@ -145,53 +145,87 @@ struct PrbsSeedPlan {
     u64 init = 0, first_bit = 0, rpw = 0, nseeds = 0;
     u64 *d = nullptr;
     size_t cap = 0;
-    hipStream_t last = nullptr;
+    // ready: behind the seed kernel; used: behind the last kernel that reads the seeds.  Events, not the streams they were
+    // recorded on: a caller's stream (a handle's internal one, a torch stream) may be destroyed while the plan lives on --
+    // synchronising with a remembered stream handle then is a use after free (the full GPU suite of round 4 crashed there).
+    hipEvent_t ready = nullptr, used = nullptr;
+    bool has_used = false;
     u64 stamp = 0;
 };
 static std::mutex g_seed_mu;
 static PrbsSeedPlan g_seed_plans[8];
 static u64 g_seed_clock = 0;
 
+// A plan handed to one caller: the cache stays locked until the caller has queued the kernel that reads the seeds and said so
+// (`queued`), so that no other thread re-targets or frees the buffer in between (bbb_ber_sweep_multi runs a host thread per device).
+struct PrbsSeedLease {
+    std::unique_lock<std::mutex> lock;
+    PrbsSeedPlan *plan = nullptr;
+    const u64 *seeds() const { return plan ? plan->d : nullptr; }
+    int queued(hipStream_t st) {
+        if (!plan) return BBB_OK;
+        PrbsSeedPlan *p = plan;
+        plan = nullptr;
+        // (`used` stands for ALL readers so far: an earlier one on another stream is chained in front of this record)
+        hipError_t e = p->has_used ? hipStreamWaitEvent(st, p->used, 0) : hipSuccess;
+        if (e == hipSuccess) e = hipEventRecord(p->used, st);
+        p->has_used = p->has_used || e == hipSuccess;
+        lock.unlock();
+        BBB_HIP(e);
+        return BBB_OK;
+    }
+};
+
 // seeds[r * 32 + i], r < nseeds: ready on `st` when this returns (computed there if no plan matched)
-static int prbs_region_seeds(int k, int ki, u64 init_state, u64 first_bit, u64 rpw, u64 nseeds, hipStream_t st, const u64 **out) {
+static int prbs_region_seeds(int k, int ki, u64 init_state, u64 first_bit, u64 rpw, u64 nseeds, hipStream_t st, PrbsSeedLease *lease) {
     int dev = 0;
     BBB_HIP(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> g(g_seed_mu);
+    lease->lock = std::unique_lock<std::mutex>(g_seed_mu);
+    lease->plan = nullptr;
     PrbsSeedPlan *victim = &g_seed_plans[0];
     for (PrbsSeedPlan &p : g_seed_plans) {
         if (p.d && p.dev == dev && p.k == k && p.init == init_state && p.first_bit == first_bit && p.rpw == rpw && p.nseeds >= nseeds) {
-            // (a plan computed on another stream: that stream's work so far includes its seed kernel)
-            if (p.last != st) BBB_HIP(hipStreamSynchronize(p.last));
-            p.last = st;
+            BBB_HIP(hipStreamWaitEvent(st, p.ready, 0));          // (a plan computed on another stream)
             p.stamp = ++g_seed_clock;
-            *out = p.d;
+            lease->plan = &p;
             return BBB_OK;
         }
         if (p.stamp < victim->stamp) victim = &p;
     }
     PrbsSeedPlan &p = *victim;
-    if (p.d && p.dev == dev && p.last != st) BBB_HIP(hipStreamSynchronize(p.last));      // its last reader may still run
-    if (p.d && p.dev != dev) {                      // another device's buffer: release it there
-        int cur = dev;
-        (void)hipSetDevice(p.dev); (void)hipStreamSynchronize(p.last); (void)hipFree(p.d); (void)hipSetDevice(cur);
-        p.d = nullptr; p.cap = 0;
+    if (p.d && p.dev != dev) {                      // another device's buffer: release it there (hipFree waits for its readers)
+        (void)hipSetDevice(p.dev);
+        if (p.has_used) (void)hipEventSynchronize(p.used);
+        (void)hipFree(p.d); (void)hipEventDestroy(p.ready); (void)hipEventDestroy(p.used);
+        (void)hipSetDevice(dev);
+        p = PrbsSeedPlan();
+    }
+    if (!p.ready) {
+        BBB_HIP(hipEventCreateWithFlags(&p.ready, hipEventDisableTiming));
+        BBB_HIP(hipEventCreateWithFlags(&p.used, hipEventDisableTiming));
     }
     const size_t need = (size_t)nseeds * 32 * sizeof(u64);
     if (p.cap < need) {
-        if (p.d) { BBB_HIP(hipStreamSynchronize(p.last)); BBB_HIP(hipFree(p.d)); }
-        p.d = nullptr; p.cap = 0;
+        if (p.d) {
+            if (p.has_used) BBB_HIP(hipEventSynchronize(p.used));
+            BBB_HIP(hipFree(p.d));
+        }
+        p.d = nullptr; p.cap = 0; p.has_used = false;
         BBB_HIP(hipMalloc((void **)&p.d, need));
         p.cap = need;
     }
-    p.dev = dev; p.k = k; p.init = init_state; p.first_bit = first_bit; p.rpw = rpw; p.nseeds = nseeds; p.last = st; p.stamp = ++g_seed_clock;
+    if (p.has_used) BBB_HIP(hipStreamWaitEvent(st, p.used, 0));          // the buffer's last reader may still run
+    p.dev = dev; p.k = k; p.init = init_state; p.first_bit = first_bit; p.rpw = rpw; p.nseeds = nseeds; p.stamp = ++g_seed_clock;
 #define BBB_PRBS_CASE(KK) case KK: hipLaunchKernelGGL(prbs_seed_kernel<KK>, dim3((unsigned)nseeds), dim3(64), 0, st, ki, init_state, first_bit, nseeds, rpw, p.d); break;
     switch (k) {
         BBB_PRBS_CASE(7) BBB_PRBS_CASE(9) BBB_PRBS_CASE(11) BBB_PRBS_CASE(15)
         BBB_PRBS_CASE(20) BBB_PRBS_CASE(23) BBB_PRBS_CASE(31)
     }
 #undef BBB_PRBS_CASE
-    BBB_HIP(hipGetLastError());
-    *out = p.d;
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipEventRecord(p.ready, st);
+    if (e != hipSuccess) { p.nseeds = 0; p.k = 0; BBB_HIP(e); }          // (never matched again)
+    lease->plan = &p;
     return BBB_OK;
 }
 
@@ -653,12 +687,13 @@ static int launch_check_rev(int k, int ki, u64 init_state, u64 first_bit, u64 nb
     const u64 nblocks = (rows + rpw - 1) / rpw;
     if (nblocks > 0x7fffffffull) return fail(BBB_EINVAL, "nbits too large");
     dim3 grid((unsigned)nblocks), block(64);
-    const u64 *seeds = nullptr;
+    PrbsSeedLease lease;
     static const int use_seeds = env_knob("BBB_PRBS_SEEDS", 1);          // (A/B timing; -DBBB_EXPERIMENTS only)
     if (use_seeds) {
-        const int rcs = prbs_region_seeds(k, ki, init_state, first_bit, rpw, nblocks + 1, st, &seeds);
+        const int rcs = prbs_region_seeds(k, ki, init_state, first_bit, rpw, nblocks + 1, st, &lease);
         if (rcs) return rcs;
     }
+    const u64 *const seeds = lease.seeds();
 #define BBB_PRBS_CASE(KK)                                                                                          \
     case KK:                                                                                                       \
         hipLaunchKernelGGL((prbs_check_rev_kernel<KK>), grid, block, 0, st, ki, init_state, first_bit, nbits, nwords, \
@@ -669,7 +704,12 @@ static int launch_check_rev(int k, int ki, u64 init_state, u64 first_bit, u64 nb
         BBB_PRBS_CASE(20) BBB_PRBS_CASE(23) BBB_PRBS_CASE(31)
     }
 #undef BBB_PRBS_CASE
-    BBB_HIP(hipGetLastError());
+    {
+        const hipError_t e = hipGetLastError();
+        const int rcq = lease.queued(st);
+        BBB_HIP(e);
+        if (rcq) return rcq;
+    }
     return BBB_OK;
 }
 
@@ -719,12 +759,13 @@ static int launch_stream_w(int k, int ki, u64 init_state, u64 first_bit, u64 nbi
     const u64 nblocks = (rows + rpw - 1) / rpw;
     if (nblocks > 0x7fffffffull) return fail(BBB_EINVAL, "nbits too large");
     dim3 grid((unsigned)nblocks), block(64);
-    const u64 *seeds = nullptr;
+    PrbsSeedLease lease;
     static const int use_seeds = env_knob("BBB_PRBS_SEEDS", 1);          // (A/B timing; -DBBB_EXPERIMENTS only)
     if (use_seeds && WPL == 1) {                    // (one more than the generator needs: the reverse checker of the same range shares the plan)
-        const int rcs = prbs_region_seeds(k, ki, init_state, first_bit, rpw, nblocks + 1, st, &seeds);
+        const int rcs = prbs_region_seeds(k, ki, init_state, first_bit, rpw, nblocks + 1, st, &lease);
         if (rcs) return rcs;
     }
+    const u64 *const seeds = lease.seeds();
 #define BBB_PRBS_CASE(KK)                                                                                       \
     case KK:                                                                                                    \
         hipLaunchKernelGGL((prbs_stream_kernel<KK, CHECK, WPL, LW>), grid, block, 0, st, ki, init_state, first_bit, \
@@ -735,7 +776,12 @@ static int launch_stream_w(int k, int ki, u64 init_state, u64 first_bit, u64 nbi
         BBB_PRBS_CASE(20) BBB_PRBS_CASE(23) BBB_PRBS_CASE(31)
     }
 #undef BBB_PRBS_CASE
-    BBB_HIP(hipGetLastError());
+    {
+        const hipError_t e = hipGetLastError();
+        const int rcq = lease.queued(st);
+        BBB_HIP(e);
+        if (rcq) return rcq;
+    }
     return BBB_OK;
 }
 

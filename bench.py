@@ -631,9 +631,10 @@ def main():
         torch.cuda.synchronize(); barrier()
         tber_isolated = time.perf_counter() - tb0
         tot = total.cpu().tolist()
-        # the same sweep three times back to back, every one at another stream position (every one seeds for itself): the
+        # the same sweep eight times back to back, every one at another stream position (every one seeds for itself): the
         # host's work in front of a call's first launch (55 us) and the idle GPU's first-launch latency overlap the call before
-        nrep = 3
+        # (the first of the eight still starts on an idle GPU)
+        nrep = 8
         reps_t = [[channel.Trial(nbits=t.nbits, amp=t.amp, noise_var=nv, first_bit=(2 + i) << 21) for t in trials] for i in range(nrep)]
         torch.cuda.synchronize(); barrier()
         tb0 = time.perf_counter()
@@ -647,7 +648,7 @@ def main():
                         "q_theory": channel.ber_theory(channel.ebn0_db(t.amp, nv)), "q_lattice": channel.ber_lattice(t.amp, nv)}
                        for t, (b_, e_) in zip(trials, tot)],
             "gbit_s": round(sum(b_ for b_, _ in tot) / tber / 1e9, 2), "seconds": round(tber, 6),
-            "gbit_s_is": "per sweep over three sweeps back to back, each at its own stream position with its own seeding (counters below: the first, isolated one)",
+            "gbit_s_is": "per sweep over eight sweeps back to back, each at its own stream position with its own seeding (counters below: the first, isolated one)",
             "isolated_call_gbit_s": round(sum(b_ for b_, _ in tot) / tber_isolated / 1e9, 2), "isolated_call_seconds": round(tber_isolated, 6),
             "seeds": world, "seeding_in_timed_region": True,
             "labels": "ebn0_db = amp^2 / (2 (8 nv)^2), ignores that the sample is an integer; ebn0_db_effective / q_lattice account for "

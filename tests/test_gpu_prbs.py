@@ -205,3 +205,31 @@ def test_read_back_hint_changes_no_bit(gpu, k):
     buf = torch.zeros(4, dtype=torch.int64, device="cuda")
     l = gpu._lib.lib()
     assert l.bbb_prbs_fill_hint(k, 1, 0, 100, C.c_void_p(buf.data_ptr()), 2, 0, None) == gpu._lib.BBB_EINVAL
+
+
+def test_seed_plans_outlive_the_stream_they_were_made_on(gpu, oracle):
+    """The region-seed plans of the PRBS kernels are process-wide; the stream a plan was computed on may be gone when the plan
+    is matched or re-targeted.  Round 4: the transmitter's data bits are generated on a handle's internal stream, which dies
+    with the handle -- the plan cache remembered the stream and synchronised with it later (a crash in the full GPU suite).
+    Here: such a plan is made, its handle destroyed, then more fills than the cache has entries re-target every plan."""
+    import gc
+    n = (1 << 24) + 4096
+    x = gpu.TX(31, 1, 0, 16, 1, 8)
+    with x.stream(n, first_sample=0) as st:
+        st.next()
+    torch.cuda.synchronize()
+    del st, x
+    gc.collect()
+    p = gpu.PRBS(31)
+    for i in range(12):
+        first = 1_000_003 * (i + 1)
+        got = p.generate(100_000, first_bit=first).cpu().numpy().view(np.uint64)
+        exp, _ = oracle.prbs_packed(31, 100_000, state=p.state_at(first), fast=True)
+        assert np.array_equal(got, exp), i
+    # and a plan shared between two live streams: the second user waits for the seed kernel by the plan's event
+    s2 = torch.cuda.Stream()
+    a = p.generate(3_000_000, first_bit=77)
+    with torch.cuda.stream(s2):
+        b = p.generate(3_000_000, first_bit=77)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
