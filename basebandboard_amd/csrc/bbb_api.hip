@@ -126,7 +126,7 @@ struct bbb_lutopt {
     // and the piece mover
     hipStream_t xs2[2] = {nullptr, nullptr}, ys = nullptr;
     uint32_t *d_stage[2] = {nullptr, nullptr}; size_t stage_cap[2] = {0, 0};
-    hipEvent_t stage_free[2] = {nullptr, nullptr};     // recorded on ys after the mover that read the buffer
+    hipEvent_t stage_free[2] = {nullptr, nullptr};     // recorded behind the mover that read the buffer (behind ALL its movers: queue_mover_with)
     bool stage_busy[2] = {false, false};
     int stage_slot = 0;
     hipEvent_t ev_user = nullptr;
@@ -286,19 +286,43 @@ void partition(const bbb_lutopt *h, uint64_t n, unsigned granule, uint64_t *L, u
     *nlanes = (unsigned)(waves * 64);
 }
 
-// Choose the stream this call's plane-touching work goes to.  When it differs from the previous call's (the staged
-// fills use an internal stream; the caller may also have re-bound the handle), the new one first waits for
-// everything the library queued on the old one.
+// The library's internal streams: ONE set per device, shared by every handle on it and kept for the life of the process.
+// The part maps HIP streams onto four hardware queues in creation order, and two streams on one queue run each other's kernels
+// in order: with streams per handle, the SECOND handle of a process found its arithmetic stream on the queue of the caller's
+// stream and lost 12 % (round 4: the transmitter's handle in bench.py next to the noise stream's).  With the caller's stream the
+// pool makes four.  Sharing a stream between handles only adds order -- every dependency the scheduler needs is an event --
+// and a pooled stream is never destroyed, so nothing can be left holding a dead handle's stream.
+struct DevStreams { hipStream_t xs[2] = {nullptr, nullptr}, side = nullptr; };
+static std::mutex g_streams_mu;
+static std::map<int, DevStreams> g_streams;
+
 int ensure_internal_streams(bbb_lutopt *h) {
     if (!h->xs2[0]) {
+        std::lock_guard<std::mutex> g(g_streams_mu);
+        DevStreams &d = g_streams[h->device];
         // (stream priorities -- arithmetic high, mover low -- made no measurable difference: profiles/README.md)
-        BBB_HIP(hipStreamCreateWithFlags(&h->xs2[0], hipStreamNonBlocking));
-        BBB_HIP(hipStreamCreateWithFlags(&h->xs2[1], hipStreamNonBlocking));
-        BBB_HIP(hipStreamCreateWithFlags(&h->ys, hipStreamNonBlocking));
+        for (hipStream_t *st : {&d.xs[0], &d.xs[1]})
+            if (!*st) BBB_HIP(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+        h->xs2[0] = d.xs[0]; h->xs2[1] = d.xs[1];
     }
     return BBB_OK;
 }
 
+// the side stream (PRBS start states of a BER trial, the transmitter's data bits in the one-kernel form, start states of an
+// announced fill on a handle that is not staged)
+int ensure_side_stream(bbb_lutopt *h) {
+    if (!h->side) {
+        std::lock_guard<std::mutex> g(g_streams_mu);
+        DevStreams &d = g_streams[h->device];
+        if (!d.side) BBB_HIP(hipStreamCreateWithFlags(&d.side, hipStreamNonBlocking));
+        h->side = d.side;
+    }
+    return BBB_OK;
+}
+
+// Choose the stream this call's plane-touching work goes to.  When it differs from the previous call's (the staged
+// fills use an internal stream; the caller may also have re-bound the handle), the new one first waits for
+// everything the library queued on the old one.
 int begin_op(bbb_lutopt *h, bool internal, bool independent_of_previous_internal = false) {
     if (internal) {
         const int rc = ensure_internal_streams(h);
@@ -377,40 +401,54 @@ int acquire_planes(bbb_lutopt *h, uint64_t first_step, uint64_t L, uint64_t G, u
 //             slot (no LDS, no plane -> byte work on the one wave per SIMD that owns the issue slots);
 //   deliver   unplane_kernel: a mover with LDS-DMA loads transposes a WINDOW of the staged stream into bytes at `dst` (or, as
 //             the shaping mover, into the transmitter's int16 samples).
-// Streams (four in all: a fifth would share a hardware queue with one of them):
+// Streams (three in all; the part maps streams onto four hardware queues, and a stream that shares one with another ties the
+// kernels of both together):
 //   arithmetic  xs2[slot]  start states (bbb_awgn_prefetch) and the sample kernel of the fill that takes staging slot `slot`;
 //                          ordered after the previous library work unless the start states were announced, NOT after the
 //                          caller's stream
-//   mover       ys         after the slot's sample kernel, and after everything the caller had queued before this call (it
-//                          may still be reading `dst`)
-//   caller's stream waits for the mover: whatever the caller queues next sees `dst` complete, as with one kernel.
+//   mover       the CALLER's stream, which first waits for the slot's sample kernel: the mover is then behind everything the
+//               caller had queued before this call (it may still be reading `dst`), whatever the caller queues next sees `dst`
+//               complete, as with one kernel, and consecutive movers follow each other on one queue.  (Rounds 2-4 had a
+//               fourth stream for it, tied to the caller's by an event each way: two cross-queue round trips, 40 us, between
+//               two movers -- 1 % of a 20-step region, whose last two movers run alone: experiments/mover_stream_ab.py.)
 // Since the next call's arithmetic does not wait for this call's mover, the mover (latency bound, 64 registers, its
 // instructions in the issue slots the sample kernel's wave cannot use) runs beside it.  Two staging slots alternate.
 
-// the mover of staging slot `slot`: behind the slot's sample kernel and behind everything the caller has queued so far;
-// the caller's stream then waits for it.  `launch_mover(staging buffer, stream)` queues the kernel
+// the mover of staging slot `slot`: on the caller's stream, behind the slot's sample kernel.  `launch_mover(staging buffer,
+// stream)` queues the kernel
 template <typename LaunchMover>
 int queue_mover_with(bbb_lutopt *h, int slot, LaunchMover launch_mover) {
-    for (hipEvent_t *e : {&h->stage_free[slot], &h->ev_user})
-        if (!*e) BBB_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
-    BBB_HIP(hipEventRecord(h->ev_user, h->stream));
-    BBB_HIP(hipStreamWaitEvent(h->ys, h->ev_user, 0));
-    BBB_HIP(hipStreamWaitEvent(h->ys, h->stage_arith[slot], 0));
+    if (!h->stage_free[slot]) BBB_HIP(hipEventCreateWithFlags(&h->stage_free[slot], hipEventDisableTiming));
+    hipStream_t ms = h->stream;
+    // (-DBBB_EXPERIMENTS, BBB_EXP_MOVER_OWN_STREAM=1: rounds 2-4's mover on a fourth internal stream tied to the caller's by an
+    // event each way, for the A/B of experiments/mover_stream_ab.py)
+    const bool own_stream = env_knob("BBB_EXP_MOVER_OWN_STREAM", 0) != 0;
+    if (own_stream) {
+        if (!h->ys) BBB_HIP(hipStreamCreateWithFlags(&h->ys, hipStreamNonBlocking));
+        if (!h->ev_user) BBB_HIP(hipEventCreateWithFlags(&h->ev_user, hipEventDisableTiming));
+        ms = h->ys;
+        BBB_HIP(hipEventRecord(h->ev_user, h->stream));
+        BBB_HIP(hipStreamWaitEvent(ms, h->ev_user, 0));
+    }
+    BBB_HIP(hipStreamWaitEvent(ms, h->stage_arith[slot], 0));
+    // stage_free[slot] stands for ALL movers that read the slot: the caller may have re-bound the handle to another stream since
+    // the slot's previous mover, so that one is chained in front of this call's record (same stream: already in its past)
+    if (h->stage_busy[slot]) BBB_HIP(hipStreamWaitEvent(ms, h->stage_free[slot], 0));
     hipEvent_t m0 = nullptr, m1 = nullptr;
     if (h->profiling) {
         BBB_HIP(hipEventCreate(&m0)); BBB_HIP(hipEventCreate(&m1));
-        BBB_HIP(hipEventRecord(m0, h->ys));
+        BBB_HIP(hipEventRecord(m0, ms));
     }
-    int rc = launch_mover((const void *)h->d_stage[slot], h->ys);
+    int rc = launch_mover((const void *)h->d_stage[slot], ms);
     if (rc) return rc;
     if (h->profiling) {
-        BBB_HIP(hipEventRecord(m1, h->ys));
+        BBB_HIP(hipEventRecord(m1, ms));
         h->prof_mover_pending.emplace_back(m0, m1);
     }
-    BBB_HIP(hipEventRecord(h->stage_free[slot], h->ys));
+    BBB_HIP(hipEventRecord(h->stage_free[slot], ms));
     h->stage_busy[slot] = true;
     h->stage_gen[slot]++;
-    BBB_HIP(hipStreamWaitEvent(h->stream, h->stage_free[slot], 0));
+    if (own_stream) BBB_HIP(hipStreamWaitEvent(h->stream, h->stage_free[slot], 0));
     return BBB_OK;
 }
 
@@ -681,7 +719,7 @@ int ber_run(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, unsigned long lo
         // sample: one clock past the stream position.
         for (hipEvent_t *e : {&h->ber_fork, &h->ber_join})
             if (!*e) BBB_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
-        if (!h->side) BBB_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        { const int rcs_ = ensure_side_stream(h); if (rcs_) return rcs_; }
         BBB_HIP(hipEventRecord(h->ber_fork, h->cs));                  // (the previous trial's kernel may still read d_pplanes)
         if ((rc = prepare_planes(h, c.warmup + c.first_bit + 1, L, G, nlanes))) return rc;
         // PRBS start states: the same doubling machinery with the k x k LFSR companion matrix.  Queued on the side stream,
@@ -849,8 +887,7 @@ int bbb_lutopt_destroy(bbb_lutopt *h) {
     for (auto &pr : h->prof_mover_pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto &ev : h->prof_pending) { (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); (void)hipEventDestroy(ev.e2); }
     if (h->prof_prev_e2) (void)hipEventDestroy(h->prof_prev_e2);
-    for (hipStream_t st : {h->side, h->xs2[0], h->xs2[1], h->ys})
-        if (st) (void)hipStreamDestroy(st);
+    if (h->ys) (void)hipStreamDestroy(h->ys);        // (the other internal streams are the device's pool: ensure_internal_streams)
     (void)hipFree(h->d_stage[0]);
     (void)hipFree(h->d_stage[1]);
     delete h;
@@ -1024,7 +1061,7 @@ static int awgn_prefetch(bbb_lutopt *h, uint64_t nsamples, uint64_t first_step, 
         if ((rc = ensure_internal_streams(h))) return rc;
         side = h->xs2[h->stage_slot ^ 1];
     } else {
-        if (!h->side) BBB_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        { const int rcs_ = ensure_side_stream(h); if (rcs_) return rcs_; }
         side = h->side;
     }
     // staged handles: the running sample kernel (fill s) shares its CUs with ONE guest kernel at a time: a SIMD's registers
@@ -1442,7 +1479,7 @@ int bbb_tx_fill_i16(bbb_lutopt *h, const bbb_tx_cfg *cfg, int16_t *out_dev, uint
         // bits m0 .. m0+nbits-1, slack for the windows of rounds past the end of the request
         const uint64_t words64 = 2 + (nbits + 63) / 64 + (L / 8 + 63) / 64 + 2;
         const int bs = h->fbits_slot ^= 1;
-        if (!h->side) BBB_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        { const int rcs_ = ensure_side_stream(h); if (rcs_) return rcs_; }
         for (hipEvent_t *e : {&h->fbits_read[bs], &h->fbits_ready})
             if (!*e) BBB_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
         if (h->fbits_cap[bs] < (size_t)words64 * 2) {
@@ -1737,7 +1774,7 @@ static int ber_run_step(bbb_ber_run *r, unsigned long long *counters_dev) {
         uint64_t ps64[8] = {ps0};
         uint32_t ps16[256];
         first16(*pp, ps64, ps16);
-        if (!h->side) BBB_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        { const int rcs_ = ensure_side_stream(h); if (rcs_) return rcs_; }
         for (hipEvent_t *e : {&r->fork, &r->join})
             if (!*e) BBB_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
         BBB_HIP(hipEventRecord(r->fork, h->cs));                      // (the previous block's last kernel still reads the buffers)
