@@ -84,7 +84,7 @@ int bbb_lutopt_is_specialised(const bbb_lutopt *h);
  * start states) is counted from that kernel's completion, not from its own dispatch: time on the machine. */
 int bbb_lutopt_profile(bbb_lutopt *h, int enable);
 int bbb_lutopt_profile_read(bbb_lutopt *h, double *seed_ms, double *kernel_ms, uint64_t *calls, int reset);
-/* The same for the second kernel of the two-kernel form (the mover, on its internal stream): accumulated milliseconds
+/* The same for the second kernel of the two-kernel form (the mover): accumulated milliseconds
  * and number of movers since the last reset. */
 int bbb_lutopt_profile_read_mover(bbb_lutopt *h, double *mover_ms, uint64_t *calls, int reset);
 
@@ -120,8 +120,9 @@ int bbb_awgn_prefetch(bbb_lutopt *h, uint64_t nsamples, uint64_t first_step);
  * bytes reach HBM.  The one-kernel form writes every generator's 16 new bytes straight to their place: 62.5 M
  * scattered pieces per 1e9 samples, one DRAM row activation each.  The staged form has the sample kernel leave its
  * pieces in an internal buffer as full lines and a second kernel move them with full-line reads and writes.  That
- * second kernel runs on an internal stream: the caller's stream waits for it (anything queued after the call sees the
- * output complete, as before), but the NEXT fill's arithmetic does not -- the mover (memory bound) and the next
+ * second kernel runs on the caller's stream, which first waits for the sample kernel (on an internal stream): anything
+ * queued after the call sees the output complete, as before; but the NEXT fill's arithmetic does not wait for it -- the
+ * mover (memory bound) and the next
  * arithmetic (integer-issue bound) share the machine.  Worth it for back-to-back fills; a single isolated fill
  * finishes later than in the one-kernel form.  Costs two staging buffers of the fill's size.
  * enable = m in 2..8 adds LOOK-AHEAD for bbb_awgn_fill_i8 (and for bbb_tx_fill_i16 with noise on this handle, while the
