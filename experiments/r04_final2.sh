@@ -18,3 +18,6 @@ for f in ("bench_profiled_noextra", "bench_default", "bench_driver_shape"):
     print(f, d["value"], d["ms_per_step"], d["roofline"]["kernel_ms_avg"], d["roofline"]["frac"],
           {k: (v.get("gbit_s") or v.get("gsample_s") or v.get("loopback_hbm_frac")) for k, v in e.items() if isinstance(v, dict)})
 PY
+python3 experiments/ber_rate.py > $O/ber_rate.log 2>&1; tail -2 $O/ber_rate.log
+python3 experiments/det_rate.py > $O/det_rate.log 2>&1; tail -2 $O/det_rate.log
+EXP= python3 experiments/prbs_loopback2.py > $O/prbs_loopback.log 2>&1; tail -3 $O/prbs_loopback.log
