@@ -79,8 +79,13 @@ struct bbb_lutopt {
     // workspace
     uint32_t *d_states = nullptr; size_t states_cap = 0;      // [W32][G] word-major
     uint32_t *d_planes = nullptr; size_t planes_cap = 0;      // [2][k][nlanes] (second half: generic kernel)
-    uint32_t *d_pstates = nullptr; size_t pstates_cap = 0;    // PRBS [G]
-    uint32_t *d_pplanes = nullptr; size_t pplanes_cap = 0;    // PRBS [32][nlanes]
+    // PRBS start states of a BER trial, two pairs taken in turn (ber_run): [G] and [32][nlanes]; pp_read[b]: behind the trial
+    // kernel that last read pair b
+    uint32_t *d_pstates[2] = {nullptr, nullptr}; size_t pstates_cap[2] = {0, 0};
+    uint32_t *d_pplanes[2] = {nullptr, nullptr}; size_t pplanes_cap[2] = {0, 0};
+    hipEvent_t pp_read[2] = {nullptr, nullptr};
+    bool pp_pending[2] = {false, false};
+    int pp_idx = 0;
     uint16_t *d_taps = nullptr;
     uint32_t *d_row_off = nullptr;
     unsigned long long *d_counters = nullptr; size_t counters_cap = 0;
@@ -92,7 +97,7 @@ struct bbb_lutopt {
     hipEvent_t fbits_read[2] = {nullptr, nullptr}, fbits_ready = nullptr;
     uint32_t *d_mbits[2] = {nullptr, nullptr}; size_t mbits_cap[2] = {0, 0};   // staged TX: a call's data bits, one buffer per staging slot (written on the
                                                                                // slot's arithmetic stream in front of the sample kernel, read by the slot's mover)
-    hipEvent_t ber_fork = nullptr, ber_join = nullptr;       // ber_run: PRBS seeding on the side stream beside the generator's
+    hipEvent_t ber_join = nullptr;       // ber_run: behind the PRBS seeding on the side stream
     bool fbits_pending[2] = {false, false};
     int fbits_slot = 0;
     // which stream position the planes in d_planes currently describe
@@ -158,6 +163,11 @@ struct bbb_lutopt {
     double prof_seed_ms = 0, prof_main_ms = 0;
     uint64_t prof_calls = 0;
 };
+
+// (defined among the extern "C" entry points below, next to bbb_awgn_prefetch)
+extern "C" {
+static int seed_announced(bbb_lutopt *h, uint64_t first_step, uint64_t L, uint64_t G, unsigned nlanes, hipStream_t side, int seed_variant);
+}
 
 namespace {
 
@@ -717,32 +727,51 @@ int ber_run(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, unsigned long lo
         // The generator's start states first: their chain of launches is what the trial kernel waits for (an isolated call's
         // wall time starts with the host work in front of the first launch).  The BER kernels take the state OF their first
         // sample: one clock past the stream position.
-        for (hipEvent_t *e : {&h->ber_fork, &h->ber_join})
-            if (!*e) BBB_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        // Neither set of start states is derived on the stream the trial kernel runs on: the generators' go to the handle's
+        // SECOND set of start-state buffers on an arithmetic stream (seed_announced, as for an announced fill) and are swapped in,
+        // the PRBS's to one of two buffer pairs on the side stream.  A caller that queues trials back to back
+        // (bbb_ber_trials_dev does not synchronise) thereby has trial s + 1 seeded BESIDE the kernel of trial s -- the seedings
+        // are latency, not work, and the trial kernel leaves 140 registers per SIMD -- and its kernel follows that of trial s
+        // directly: 1.29 -> 1.17 ms per 11 x 1e9-bit sweep in a sequence (round 4).  A single call is as before.
+        if (!h->ber_join) BBB_HIP(hipEventCreateWithFlags(&h->ber_join, hipEventDisableTiming));
         { const int rcs_ = ensure_side_stream(h); if (rcs_) return rcs_; }
-        BBB_HIP(hipEventRecord(h->ber_fork, h->cs));                  // (the previous trial's kernel may still read d_pplanes)
-        if ((rc = prepare_planes(h, c.warmup + c.first_bit + 1, L, G, nlanes))) return rc;
-        // PRBS start states: the same doubling machinery with the k x k LFSR companion matrix.  Queued on the side stream,
-        // so that its launches run beside the generator's (both are latency, not work)
+        const uint64_t gen_first = c.warmup + c.first_bit + 1;
+        if (!(h->planes_valid && h->planes_first == gen_first && h->planes_L == L && h->planes_G == G)) {
+            if ((rc = ensure_internal_streams(h))) return rc;
+            h->pf_waited_slot = -1;
+            if (!(h->pf.valid && h->pf.first == gen_first && h->pf.L == L && h->pf.G == G) &&
+                (rc = seed_announced(h, gen_first, L, G, nlanes, h->xs2[0], 2)))
+                return rc;
+            if ((rc = acquire_planes(h, gen_first, L, G, nlanes, true))) return rc;
+        }
+        // PRBS start states: the same doubling machinery with the k x k LFSR companion matrix
         JumpPlan *pp;
         if ((rc = get_prbs_plan(h, c.prbs_k, L, &pp))) return rc;
-        if ((rc = grow(&h->d_pstates, &h->pstates_cap, (size_t)G))) return rc;
-        if ((rc = grow(&h->d_pplanes, &h->pplanes_cap, (size_t)32 * nlanes))) return rc;
+        const int pb = h->pp_idx ^= 1;
+        if (!h->pp_read[pb]) BBB_HIP(hipEventCreateWithFlags(&h->pp_read[pb], hipEventDisableTiming));
+        if (h->pstates_cap[pb] < (size_t)G || h->pplanes_cap[pb] < (size_t)32 * nlanes) {
+            if (h->pp_pending[pb]) BBB_HIP(hipEventSynchronize(h->pp_read[pb]));          // growing frees the old buffers
+            h->pp_pending[pb] = false;
+            if ((rc = grow(&h->d_pstates[pb], &h->pstates_cap[pb], (size_t)G))) return rc;
+            if ((rc = grow(&h->d_pplanes[pb], &h->pplanes_cap[pb], (size_t)32 * nlanes))) return rc;
+        }
         uint64_t ps0 = 0;
         if ((rc = prbs_state_at_host(c.prbs_k, c.prbs_state, c.first_bit, &ps0))) return rc;
         uint64_t ps64[8] = {ps0};
         uint32_t ps16[256];
         first16(*pp, ps64, ps16);
-        BBB_HIP(hipStreamWaitEvent(h->side, h->ber_fork, 0));
-        if ((rc = prbs_seed_planes_launch(c.prbs_k, pp->d_cols, ps16, G, h->d_pstates, nlanes, h->d_pplanes, h->side))) return rc;
+        if (h->pp_pending[pb]) BBB_HIP(hipStreamWaitEvent(h->side, h->pp_read[pb], 0));    // the trial before last read this pair
+        if ((rc = prbs_seed_planes_launch(c.prbs_k, pp->d_cols, ps16, G, h->d_pstates[pb], nlanes, h->d_pplanes[pb], h->side))) return rc;
         BBB_HIP(hipEventRecord(h->ber_join, h->side));
         BBB_HIP(hipStreamWaitEvent(h->cs, h->ber_join, 0));
         if (h->specialised) {
-            if ((rc = ber256_launch(h->d_planes, h->d_pplanes, &td[(size_t)i], n, nlanes, counters_dev + 2 * (size_t)i, h->cs))) return rc;
+            if ((rc = ber256_launch(h->d_planes, h->d_pplanes[pb], &td[(size_t)i], n, nlanes, counters_dev + 2 * (size_t)i, h->cs))) return rc;
         } else {
-            const int e = h->custom_ber(h->d_planes, h->d_pplanes, &td[(size_t)i], n, nlanes, (uint64_t *)(counters_dev + 2 * (size_t)i), (void *)h->cs);
+            const int e = h->custom_ber(h->d_planes, h->d_pplanes[pb], &td[(size_t)i], n, nlanes, (uint64_t *)(counters_dev + 2 * (size_t)i), (void *)h->cs);
             if (e) return fail(e < 0 ? e : BBB_EHIP, "custom BER kernel failed");
         }
+        BBB_HIP(hipEventRecord(h->pp_read[pb], h->cs));
+        h->pp_pending[pb] = true;
         if ((rc = mark_planes_read(h))) return rc;
         i += n;
     }
@@ -876,12 +905,12 @@ int bbb_lutopt_destroy(bbb_lutopt *h) {
     (void)hipDeviceSynchronize();
     for (auto &p : h->plans) (void)hipFree(p.second.d_cols);
     for (auto &p : h->prbs_plans) (void)hipFree(p.second.d_cols);
-    for (void *p : {(void *)h->d_states, (void *)h->d_planes, (void *)h->d_pstates, (void *)h->d_pplanes,
+    for (void *p : {(void *)h->d_states, (void *)h->d_planes, (void *)h->d_pstates[0], (void *)h->d_pplanes[0], (void *)h->d_pstates[1], (void *)h->d_pplanes[1],
                     (void *)h->d_taps, (void *)h->d_row_off, (void *)h->d_counters, (void *)h->d_txnoise,
                     (void *)h->d_txbits, (void *)h->d_fbits[0], (void *)h->d_fbits[1], (void *)h->d_mbits[0], (void *)h->d_mbits[1], (void *)h->pf.d_states, (void *)h->pf.d_planes})
         (void)hipFree(p);
     for (hipEvent_t e : {h->pf.seeded, h->pf.last_read, h->cur_last_read, h->handover, h->stage_free[0], h->stage_free[1],
-                         h->stage_arith[0], h->stage_arith[1], h->ev_user, h->fbits_read[0], h->fbits_read[1], h->fbits_ready, h->ber_fork, h->ber_join})
+                         h->stage_arith[0], h->stage_arith[1], h->ev_user, h->fbits_read[0], h->fbits_read[1], h->fbits_ready, h->ber_join, h->pp_read[0], h->pp_read[1]})
         if (e) (void)hipEventDestroy(e);
     // (profiling events of calls whose times were never read: found by the scheduler model's leak check, tests/sched_model)
     for (auto &pr : h->prof_mover_pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -1003,6 +1032,45 @@ int bbb_lutopt_state_at(bbb_lutopt *h, uint64_t nsteps, uint64_t *state_words) {
     return BBB_OK;
 }
 
+// Start states of (first_step, L, G, nlanes) into the handle's SECOND set of start-state buffers (h->pf), on `side`, beside
+// whatever reads the first set: an announced fill's (bbb_awgn_prefetch) or, just in time, a BER trial's (ber_run).
+// acquire_planes swaps the sets.
+static int seed_announced(bbb_lutopt *h, uint64_t first_step, uint64_t L, uint64_t G, unsigned nlanes, hipStream_t side, int seed_variant) {
+    JumpPlan *plan;
+    int rc = get_plan(h, L, &plan);
+    if (rc) return rc;
+    bbb_lutopt::Prefetch &pf = h->pf;
+    pf.valid = false;
+    // An announcement that was never taken leaves its seeding behind -- queued on the arithmetic stream of the fill it expected,
+    // which need not be the one this seeding goes to: without this wait the two would write the same buffers side by side
+    // (the soak test's case: a hint whose fill came with another partition, then the next hint).
+    // (BBB_SCHED_MODEL_REVERT_UNTAKEN_HINT: the scheduler as it stood BEFORE this wait existed -- defined only by
+    // tests/test_sched_model.py, which must see the model of tests/sched_model/ find that race)
+#ifndef BBB_SCHED_MODEL_REVERT_UNTAKEN_HINT
+    if (pf.seeded) BBB_HIP(hipStreamWaitEvent(side, pf.seeded, 0));
+    else BBB_HIP(hipEventCreateWithFlags(&pf.seeded, hipEventDisableTiming));
+#else
+    if (!pf.seeded) BBB_HIP(hipEventCreateWithFlags(&pf.seeded, hipEventDisableTiming));
+#endif
+    // the buffers may still be read by the sample kernel that used them last (main stream)
+    if (pf.read_pending) BBB_HIP(hipStreamWaitEvent(side, pf.last_read, 0));
+    if (pf.states_cap < (size_t)G * h->W32 || pf.planes_cap < (size_t)2 * h->k * nlanes) {
+        if (pf.read_pending) BBB_HIP(hipEventSynchronize(pf.last_read));     // growing frees the old buffers
+        if ((rc = grow(&pf.d_states, &pf.states_cap, (size_t)G * h->W32))) return rc;
+        if ((rc = grow(&pf.d_planes, &pf.planes_cap, (size_t)2 * h->k * nlanes))) return rc;
+    }
+    pf.read_pending = false;
+    uint64_t s0[8] = {0};
+    h->pw->apply(first_step, h->init, s0);
+    uint32_t s16[256];
+    first16(*plan, s0, s16);
+    if ((rc = awgn_seed_launch(h->k, plan->d_cols, s16, G, pf.d_states, G, nlanes, pf.d_planes, side, h->fast512 ? 1 : 0, seed_variant))) return rc;
+    BBB_HIP(hipEventRecord(pf.seeded, side));
+    pf.valid = true;
+    pf.first = first_step; pf.L = L; pf.G = G; pf.nlanes = nlanes;
+    return BBB_OK;
+}
+
 // for_tx: the announced fill will run the SMALL form of the sample kernel (the transmitter's, and the noise stream's at one read
 // per kernel), which takes the state OF its first sample
 static int awgn_prefetch(bbb_lutopt *h, uint64_t nsamples, uint64_t first_step, bool for_tx);
@@ -1046,63 +1114,32 @@ static int awgn_prefetch(bbb_lutopt *h, uint64_t nsamples, uint64_t first_step, 
     }
     if (L > 0xffffff00ull) return BBB_OK;                         // the matching fill will refuse; nothing to prepare
     if (h->pf.valid && h->pf.first == first_step && h->pf.L == L && h->pf.G == G) return BBB_OK;      // already under way
-    JumpPlan *plan;
-    int rc = get_plan(h, L, &plan);
-    if (rc) return rc;
-    bbb_lutopt::Prefetch &pf = h->pf;
-    pf.valid = false;
     // Which stream seeds.  A staged k = 256 handle: the ARITHMETIC stream of the staging slot the announced fill will take --
-    // the sample kernel then follows its start states on one stream, with no event between them, and the library keeps to
-    // four streams (the caller's, two arithmetic, the mover's).  A fifth shares a hardware queue with one of the others
-    // on this part and ties the kernels of both together: with the seeding on a stream of its own beside two arithmetic
-    // streams the mover and the seeding ran BETWEEN the sample kernels instead of beside them (1.05 -> 1.69 ms per step).
+    // the sample kernel then follows its start states on one stream, with no event between them.  (With the seeding on a
+    // stream of its own beside two arithmetic streams the mover and the seeding ran BETWEEN the sample kernels instead of
+    // beside them: a stream more than the part has hardware queues for.)
     hipStream_t side = nullptr;
+    int rc;
     if (h->staged_mode && h->specialised) {
         if ((rc = ensure_internal_streams(h))) return rc;
         side = h->xs2[h->stage_slot ^ 1];
     } else {
-        { const int rcs_ = ensure_side_stream(h); if (rcs_) return rcs_; }
+        if ((rc = ensure_side_stream(h))) return rc;
         side = h->side;
     }
     // staged handles: the running sample kernel (fill s) shares its CUs with ONE guest kernel at a time: a SIMD's registers
     // hold the sample kernel's wave and one guest wave.  The guests of fill s are the piece mover of fill s-1 and this seeding
     // (for fill s+1): the seeding waits for that mover.  (The mover of fill s itself starts when fill s has finished.)
     h->pf_waited_slot = -1;
+    h->pf.valid = false;
     // (Beside the small form of the sample kernel -- the transmitter's -- there is room for both guests at once.)
     if (h->staged_mode && h->stage_busy[h->stage_slot ^ 1] && !h->last_staged_small) {
         BBB_HIP(hipStreamWaitEvent(side, h->stage_free[h->stage_slot ^ 1], 0));
         h->pf_waited_slot = h->stage_slot ^ 1;
         h->pf_waited_gen = h->stage_gen[h->stage_slot ^ 1];
     }
-    // An announcement that was never taken leaves its seeding behind -- queued on the arithmetic stream of the fill it expected,
-    // which need not be the one this seeding goes to: without this wait the two would write the same buffers side by side
-    // (the soak test's case: a hint whose fill came with another partition, then the next hint).
-    // (BBB_SCHED_MODEL_REVERT_UNTAKEN_HINT: the scheduler as it stood BEFORE this wait existed -- defined only by
-    // tests/test_sched_model.py, which must see the model of tests/sched_model/ find that race)
-#ifndef BBB_SCHED_MODEL_REVERT_UNTAKEN_HINT
-    if (pf.seeded) BBB_HIP(hipStreamWaitEvent(side, pf.seeded, 0));
-    else BBB_HIP(hipEventCreateWithFlags(&pf.seeded, hipEventDisableTiming));
-#else
-    if (!pf.seeded) BBB_HIP(hipEventCreateWithFlags(&pf.seeded, hipEventDisableTiming));
-#endif
-    // the buffers may still be read by the sample kernel that used them last (main stream)
-    if (pf.read_pending) BBB_HIP(hipStreamWaitEvent(side, pf.last_read, 0));
-    if (pf.states_cap < (size_t)G * h->W32 || pf.planes_cap < (size_t)2 * h->k * nlanes) {
-        if (pf.read_pending) BBB_HIP(hipEventSynchronize(pf.last_read));     // growing frees the old buffers
-        if ((rc = grow(&pf.d_states, &pf.states_cap, (size_t)G * h->W32))) return rc;
-        if ((rc = grow(&pf.d_planes, &pf.planes_cap, (size_t)2 * h->k * nlanes))) return rc;
-    }
-    pf.read_pending = false;
-    uint64_t s0[8] = {0};
-    h->pw->apply(first_step, h->init, s0);
-    uint32_t s16[256];
-    first16(*plan, s0, s16);
     // (this seeding runs beside the kernel of the fill before: the transmitter variant leaves LDS for 8 KiB pieces only)
-    if ((rc = awgn_seed_launch(h->k, plan->d_cols, s16, G, pf.d_states, G, nlanes, pf.d_planes, side, h->fast512 ? 1 : 0, h->last_fill_tx ? 4 : 2))) return rc;
-    BBB_HIP(hipEventRecord(pf.seeded, side));
-    pf.valid = true;
-    pf.first = first_step; pf.L = L; pf.G = G; pf.nlanes = nlanes;
-    return BBB_OK;
+    return seed_announced(h, first_step, L, G, nlanes, side, h->last_fill_tx ? 4 : 2);
 }
 
 int bbb_awgn_fill_i8(bbb_lutopt *h, int8_t *dst_dev, uint64_t nsamples, uint64_t first_step) {

@@ -276,7 +276,9 @@ typedef struct { uint64_t bits, errors; } bbb_ber;
 /* Run ncfg trials on the handle's generator; out[i] (host) receives trial i's counters. */
 int bbb_ber_trials(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, bbb_ber *out);
 /* Same, adding into device counters counters_dev[2*i] (bits), [2*i+1] (errors) without
- * synchronising -- the buffer a multi-GPU host hands to one RCCL all-reduce (ncclUint64, sum). */
+ * synchronising -- the buffer a multi-GPU host hands to one RCCL all-reduce (ncclUint64, sum).
+ * Calls queued back to back overlap: the start states of a trial (generators and PRBS) are derived on internal streams into
+ * a second set of buffers while the kernel of the trial before runs on the handle's stream, and its kernel follows directly. */
 int bbb_ber_trials_dev(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, uint64_t *counters_dev);
 
 /* A trial group CONTINUED over several calls (round 4).  One bbb_ber_trials call spends 0.16 ms in front of its kernel on

@@ -350,3 +350,33 @@ def test_continued_trials_reject_mixed_groups(gpu):
         gpu.ContinuedTrials(u, [gpu.Trial(nbits=1000, amp=1900, noise_var=15), gpu.Trial(nbits=1000, amp=10, noise_var=1)], 2)
     with gpu.ContinuedTrials(u, [gpu.Trial(nbits=1000, amp=1900, noise_var=15)], 2) as run:      # alone it runs (general kernel)
         assert run.next()[0][0] > 0
+
+
+def test_trials_queued_back_to_back_equal_trials_run_one_by_one(gpu, oracle):
+    """bbb_ber_trials_dev does not synchronise: a caller that queues trials back to back has the start states of trial s + 1
+    derived (on internal streams, into the second set of buffers) while the kernel of trial s runs.  Seven trials of different
+    positions, lengths and PRBS in one go, then each alone with a synchronisation in between, then the oracle; with a fill and
+    a staged stream read in between, which use the same second set of start-state buffers."""
+    u = gpu.LUTOPT.shipped(256)
+    g = gpu.CLTGRNG(u)
+    ts = [gpu.Trial(nbits=3_000_000 + 777 * i, amp=60 + 9 * i, noise_var=8, first_bit=(i * 37) % 5 * 1_000_003, prbs_k=(31, 23, 9)[i % 3],
+                    warmup=16 + i) for i in range(7)]
+    c = torch.zeros((len(ts), 2), dtype=torch.int64, device="cuda")
+    for i, t in enumerate(ts):
+        gpu.run_trials_into(u, [t], c[i:i + 1])
+        if i == 2:
+            g.generate(200_000, first_step=5)
+        if i == 4:
+            with g.stream((1 << 24) + 4096, first_step=99) as st:
+                st.next()
+    torch.cuda.synchronize()
+    got = [tuple(x) for x in c.cpu().tolist()]
+    v = gpu.LUTOPT.shipped(256)
+    alone = []
+    for t in ts:
+        alone.append(gpu.run_trials(v, [t])[0])
+        torch.cuda.synchronize()
+    assert got == [tuple(x) for x in alone]
+    m_or = oracle.Lutopt(path=oracle.data_path(256))
+    t = ts[3]
+    assert got[3] == m_or.ber_trial(1, t.prbs_k, 1, t.amp, t.noise_var, t.warmup, t.first_bit, t.nbits)
