@@ -266,8 +266,16 @@ def sweep_seeds(trials, runner, world=1, group=None):
 
 
 def gpu_runner(urng):
-    """The `runner` for `sweep` on a GPU rank."""
+    """The `runner` for `sweep` on a GPU rank.  The counters of consecutive calls are slices of one zeroed block (32 calls'
+    worth at a time): a zeroing kernel per call would sit on the stream between two trial kernels that otherwise follow each
+    other directly."""
+    pool = {"buf": None, "next": 0}
+
     def run(local_trials, n):
-        c = torch.zeros((n, 2), dtype=torch.int64, device=torch.device("cuda", urng.device))
+        if pool["buf"] is None or pool["buf"].shape[1] != n or pool["next"] == pool["buf"].shape[0]:
+            pool["buf"] = torch.zeros((32, n, 2), dtype=torch.int64, device=torch.device("cuda", urng.device))
+            pool["next"] = 0
+        c = pool["buf"][pool["next"]]
+        pool["next"] += 1
         return run_trials_into(urng, local_trials, c)
     return run

@@ -643,8 +643,9 @@ def main():
         reps_t = [[channel.Trial(nbits=t.nbits, amp=t.amp, noise_var=nv, first_bit=(2 + i) << 21) for t in trials] for i in range(nrep)]
         torch.cuda.synchronize(); barrier()
         tb0 = time.perf_counter()
+        runner = channel.gpu_runner(us)
         for i in range(nrep):
-            channel.sweep_seeds(reps_t[i], channel.gpu_runner(us), world=world)
+            channel.sweep_seeds(reps_t[i], runner, world=world)
         torch.cuda.synchronize(); barrier()
         tber = (time.perf_counter() - tb0) / nrep
         extra["ber_sweep"] = {
