@@ -443,7 +443,11 @@ int queue_mover_with(bbb_lutopt *h, int slot, LaunchMover launch_mover) {
     BBB_HIP(hipStreamWaitEvent(ms, h->stage_arith[slot], 0));
     // stage_free[slot] stands for ALL movers that read the slot: the caller may have re-bound the handle to another stream since
     // the slot's previous mover, so that one is chained in front of this call's record (same stream: already in its past)
+    // (BBB_SCHED_MODEL_REVERT_MOVER_CHAIN: without it -- defined only by tests/test_sched_model.py, whose model must then find a
+    // sample kernel overwriting a slot that a mover on the caller's OTHER stream still reads)
+#ifndef BBB_SCHED_MODEL_REVERT_MOVER_CHAIN
     if (h->stage_busy[slot]) BBB_HIP(hipStreamWaitEvent(ms, h->stage_free[slot], 0));
+#endif
     hipEvent_t m0 = nullptr, m1 = nullptr;
     if (h->profiling) {
         BBB_HIP(hipEventCreate(&m0)); BBB_HIP(hipEventCreate(&m1));

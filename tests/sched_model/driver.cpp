@@ -63,11 +63,18 @@ int main(int argc, char **argv) {
     hipEventCreate(&uev);
     // caller-side buffers (address space only)
     const uint64_t kMax = 3ull << 24;
-    void *dst8 = nullptr, *dst16 = nullptr, *counters = nullptr, *words = nullptr;
-    hipMalloc(&dst8, kMax + 64); model::tag(dst8, "caller: int8 samples");
-    hipMalloc(&dst16, 2 * (kMax + 64)); model::tag(dst16, "caller: int16 samples");
-    hipMalloc(&counters, 2 * 8 * 12); model::tag(counters, "caller: BER counters");
-    hipMalloc(&words, 1 << 20); model::tag(words, "caller: state words");
+    // two sets, one per caller stream: a caller that re-binds the handle WITHOUT ordering its two streams (allowed: nothing of
+    // its own is shared between them) uses other buffers on the other stream
+    void *sets[2][4] = {};
+    for (int i = 0; i < 2; i++) {
+        const std::string sfx = i ? " (stream 1)" : " (stream 0)";
+        hipMalloc(&sets[i][0], kMax + 64); model::tag(sets[i][0], "caller: int8 samples" + sfx);
+        hipMalloc(&sets[i][1], 2 * (kMax + 64)); model::tag(sets[i][1], "caller: int16 samples" + sfx);
+        hipMalloc(&sets[i][2], 2 * 8 * 12); model::tag(sets[i][2], "caller: BER counters" + sfx);
+        hipMalloc(&sets[i][3], 1 << 20); model::tag(sets[i][3], "caller: state words" + sfx);
+    }
+    void *dst8 = sets[0][0], *dst16 = sets[0][1], *counters = sets[0][2], *words = sets[0][3];
+    auto use_set = [&](int i) { dst8 = sets[i][0]; dst16 = sets[i][1]; counters = sets[i][2]; words = sets[i][3]; };
 
     const uint64_t sizes[4] = {1ull << 24, (1ull << 24) + 4096, 1ull << 25, 3ull << 24};
     bbb_tx_cfg tx{};
@@ -81,6 +88,7 @@ int main(int argc, char **argv) {
         if (h) CK(bbb_lutopt_destroy(h));
         CK(bbb_lutopt_create(&h, k, taps.data(), off.data(), init, 0));
         cur = 0;
+        use_set(0);
         CK(bbb_lutopt_set_stream(h, (void *)user[0]));
     };
     fresh_handle();
@@ -209,11 +217,15 @@ int main(int argc, char **argv) {
             }
             case 11: {                 // the caller re-binds the handle to its other stream
                 if (ns || ts || run) break;
-                // (the caller orders its OWN streams: what it queued on the old one is in front of what it queues on the new one)
-                hipEventRecord(uev, user[cur]);
+                // Half of the time the caller orders its streams (what it queued on the old one is in front of what it queues on
+                // the new one); otherwise it does not -- it works on another set of buffers there, and whatever of the LIBRARY's
+                // the two streams share (staging slots a mover still reads, start states) is the library's to order
+                const bool ordered = rng.chance(50);
+                if (ordered) hipEventRecord(uev, user[cur]);
                 cur ^= 1;
-                hipStreamWaitEvent(user[cur], uev, 0);
-                model::host_note("bbb_lutopt_set_stream -> user stream " + std::to_string(cur));
+                if (ordered) hipStreamWaitEvent(user[cur], uev, 0);
+                use_set(cur);
+                model::host_note(std::string("bbb_lutopt_set_stream -> user stream ") + std::to_string(cur) + (ordered ? " (ordered)" : " (NOT ordered)"));
                 CK(bbb_lutopt_set_stream(h, (void *)user[cur]));
                 break;
             }
@@ -245,7 +257,7 @@ int main(int argc, char **argv) {
     }
     if (h) CK(bbb_lutopt_destroy(h));
     hipEventDestroy(uev);
-    for (void *p : {dst8, dst16, counters, words}) hipFree(p);
+    for (auto &st : sets) for (void *p : st) hipFree(p);
     std::printf("{\"sequences\": %ld, \"calls\": %llu, \"operations_checked\": %llu, \"sequences_with_unordered_access\": %ld}\n", nseq,
                 (unsigned long long)calls, (unsigned long long)model::ops_checked(), bad_sequences);
     return bad_sequences ? 1 : 0;

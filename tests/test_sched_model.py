@@ -6,7 +6,8 @@ vector clocks and reports every access that the streams, events and host synchro
 of a buffer's last reader, a read in front of its writer.  That is the hazard the GPU cannot be sanitised for and that
 round 3's soak test met on seed 3 of 3.
 
-Two builds prove that the model sees what it has to: with -DBBB_SCHED_MODEL_REVERT_UNTAKEN_HINT the scheduler is the one of
+Three builds prove that the model sees what it has to (the third: -DBBB_SCHED_MODEL_REVERT_MOVER_CHAIN, round 4's rule that a
+slot's "free" event stands for ALL movers that read it, also one on the caller's other stream): with -DBBB_SCHED_MODEL_REVERT_UNTAKEN_HINT the scheduler is the one of
 commit f1ee557 in that respect (round 3's race: an announcement that was never taken leaves its seeding on one arithmetic
 stream, the next seeding goes to the other) and with -DBBB_SCHED_MODEL_REVERT_STALE_SKIP the one before the round-2
 advisor's fix (a prefetch's "the seeding waited for this slot's mover" outliving later movers on the slot) -- both must be
@@ -28,12 +29,13 @@ BUILDS = {
     "tsan": ["-fsanitize=thread"],
     "BBB_SCHED_MODEL_REVERT_UNTAKEN_HINT": ["-DBBB_SCHED_MODEL_REVERT_UNTAKEN_HINT"],
     "BBB_SCHED_MODEL_REVERT_STALE_SKIP": ["-DBBB_SCHED_MODEL_REVERT_STALE_SKIP"],
+    "BBB_SCHED_MODEL_REVERT_MOVER_CHAIN": ["-DBBB_SCHED_MODEL_REVERT_MOVER_CHAIN"],
 }
 
 
 @pytest.fixture(scope="module")
 def exes(tmp_path_factory):
-    """the four builds, compiled side by side"""
+    """the five builds, compiled side by side"""
     d = tmp_path_factory.mktemp("sched_model")
     procs = {}
     for name, flags in BUILDS.items():
@@ -74,11 +76,13 @@ def test_scheduler_under_thread_sanitizer(exes):
     ("BBB_SCHED_MODEL_REVERT_UNTAKEN_HINT", "all", "seeding"),
     ("BBB_SCHED_MODEL_REVERT_UNTAKEN_HINT", "hints", "seeding"),
     ("BBB_SCHED_MODEL_REVERT_STALE_SKIP", "hints", "awgn256_planes_kernel"),
+    ("BBB_SCHED_MODEL_REVERT_MOVER_CHAIN", "all", "awgn256_planes_kernel"),
 ])
 def test_the_model_finds_the_races_of_rounds_two_and_three(exes, macro, mode, what):
-    """The scheduler with one of the two historical fixes taken out: the model must report unordered accesses, and of the
-    kind the fix was about (two seedings writing the same start-state buffers from different streams; a sample kernel
-    overwriting a staging slot its mover still reads)."""
-    r, out = run(exes[macro], 3000, 1, mode, max_bad=3)
+    """The scheduler with one of its ordering rules taken out: the model must report unordered accesses, and of the kind the
+    rule is about (two seedings writing the same start-state buffers from different streams; a sample kernel overwriting a
+    staging slot its mover still reads -- rounds 2 and 3; round 4, the mover on the caller's stream: a sample kernel
+    overwriting a slot that a mover on the caller's OTHER stream still reads after a re-bind the caller did not order)."""
+    r, out = run(exes[macro], 6000 if "MOVER_CHAIN" in macro else 3000, 1, mode, max_bad=3)
     assert r.returncode == 1 and out["sequences_with_unordered_access"] > 0
     assert "UNORDERED ACCESS" in r.stderr and what in r.stderr
