@@ -7,6 +7,7 @@ if os.environ.get("EXP"): bbb._lib.select_build("experiments")
 N = 1_000_000_000
 buf16 = torch.empty(N, dtype=torch.int16, device="cuda")
 x = bbb.TX(31, 1, 0, 16, 1, 8)
+if os.environ.get("LEVEL"): x.urng.set_staged(True, look_ahead=int(os.environ["LEVEL"]))
 with x.stream(N, first_sample=0) as st:
     for _ in range(30): st.next(buf16)
     torch.cuda.synchronize(); t0 = time.perf_counter()
