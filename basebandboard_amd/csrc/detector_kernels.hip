@@ -861,7 +861,9 @@ det_reduce_kernel(u64 nchunks, const DetCount *__restrict counts, u64 *__restric
 // device).  With a stream-ordered allocation per call the pool gave the 22 MB of a 1e10-bit call back to the driver at every
 // synchronisation and fetched them again at the next call, and the totals came back through a pageable bounce buffer: 0.26 ms
 // of host time around 0.49 ms of kernels.
-struct DetWorkspace { int dev; char *d; size_t cap; u64 *h; bool busy; };
+// zeroed_at / ev_zero: the 16 tail words at that offset of d are zero once ev_zero has happened -- a call that ends the plain way
+// zeroes them for the next one BEHIND its read-back instead of the next call doing so in front of its first kernel
+struct DetWorkspace { int dev; char *d; size_t cap; u64 *h; bool busy; hipEvent_t ev_copy, ev_zero; size_t zeroed_at; bool zeroed; };
 static std::mutex g_det_ws_mu;
 static std::vector<DetWorkspace> g_det_ws;
 
@@ -873,15 +875,17 @@ static int det_ws_acquire(size_t need, int *slot) {
     for (size_t i = 0; i < g_det_ws.size(); i++)
         if (!g_det_ws[i].busy && g_det_ws[i].dev == dev) { found = (int)i; break; }
     if (found < 0) {
-        DetWorkspace w{dev, nullptr, 0, nullptr, false};
+        DetWorkspace w{dev, nullptr, 0, nullptr, false, nullptr, nullptr, 0, false};
         BBB_HIP(hipHostMalloc((void **)&w.h, 16 * sizeof(u64), hipHostMallocDefault));
+        BBB_HIP(hipEventCreateWithFlags(&w.ev_copy, hipEventDisableTiming));
+        BBB_HIP(hipEventCreateWithFlags(&w.ev_zero, hipEventDisableTiming));
         g_det_ws.push_back(w);
         found = (int)g_det_ws.size() - 1;
     }
     DetWorkspace &w = g_det_ws[found];
     if (w.cap < need) {
         if (w.d) (void)hipFree(w.d);
-        w.d = nullptr; w.cap = 0;
+        w.d = nullptr; w.cap = 0; w.zeroed = false;
         BBB_HIP(hipMalloc((void **)&w.d, need));
         w.cap = need;
     }
@@ -895,7 +899,7 @@ static void det_ws_release(int slot) {
     DetWorkspace &w = g_det_ws[slot];
     if (w.cap > (size_t)256 << 20) {        // (a very long stream's workspace is not kept: 256 MiB = 1.2e11 bits at the default chunking)
         (void)hipFree(w.d);
-        w.d = nullptr; w.cap = 0;
+        w.d = nullptr; w.cap = 0; w.zeroed = false;
     }
     w.busy = false;
 }
@@ -917,9 +921,14 @@ static int detector_stream_k(const u64 *src, u64 nbits, u64 *err, u64 *reload, b
     if (rc_ws) return rc_ws;
     char *ws;
     u64 *hpin;
+    hipEvent_t ev_copy, ev_zero;
+    bool tail_zeroed;
     {
         std::lock_guard<std::mutex> g(g_det_ws_mu);
-        ws = g_det_ws[ws_slot].d; hpin = g_det_ws[ws_slot].h;
+        DetWorkspace &w = g_det_ws[ws_slot];
+        ws = w.d; hpin = w.h; ev_copy = w.ev_copy; ev_zero = w.ev_zero;
+        tail_zeroed = w.zeroed && w.zeroed_at == o_tail;
+        w.zeroed = false;                     // (until this call has ended the way that leaves them zeroed again)
     }
     DetState *spec = (DetState *)(ws + o_spec), *endst = (DetState *)(ws + o_end);
     DetCount *counts = (DetCount *)(ws + o_cnt);
@@ -929,7 +938,10 @@ static int detector_stream_k(const u64 *src, u64 nbits, u64 *err, u64 *reload, b
     // (every path below has synchronised the stream before it calls this, or failed in a HIP call and does so here)
     auto cleanup = [&]() { (void)hipStreamSynchronize(st); det_ws_release(ws_slot); };
     const unsigned grid = (unsigned)((nchunks + 255) / 256);
-    const unsigned rgrid = grid < 512 ? grid : 512;
+    // (the reduce kernel's time is its atomics -- one per block and counter: 512 blocks 11 us, 128 blocks 6 us, 64 too few to
+    // stream 20 MB of chunk records; BBB_DET_RGRID: A/B timing, -DBBB_EXPERIMENTS only)
+    const unsigned rmax = (unsigned)env_knob("BBB_DET_RGRID", 128);
+    const unsigned rgrid = grid < rmax ? grid : rmax;
     // cooperative 128-byte loads need chunks and warm-up in whole 16-word rows on 16-byte aligned data
     const int tiles_ok = chunk_words % 16 == 0 && warm_words % 16 == 0 && warm_words > 0 && ((uintptr_t)src & 15) == 0;
     static const bool dense = env_knob("BBB_DET_DENSE", 0) != 0;          // (A/B timing of the two forms; -DBBB_EXPERIMENTS only)
@@ -967,7 +979,8 @@ static int detector_stream_k(const u64 *src, u64 nbits, u64 *err, u64 *reload, b
         // at once when pass 1 found nothing) -- all queued before the host looks.
         constexpr unsigned kSpec = 4096;
         u64 *const hh = hpin;
-        (void)hipMemsetAsync(tail, 0, 16 * sizeof(u64), st);
+        if (tail_zeroed) (void)hipStreamWaitEvent(st, ev_zero, 0);          // (zeroed behind the previous call's read-back, maybe on another stream)
+        else (void)hipMemsetAsync(tail, 0, 16 * sizeof(u64), st);
         hipLaunchKernelGGL(det_reduce_kernel, dim3(rgrid), dim3(256), 0, st, nchunks, counts, tail, (const DetState *)spec,
                            (const DetState *)endst, list, nlist, (const unsigned *)nullptr);
         // The repair stages are queued blind only for the dense pass, whose reset-state speculation leaves a few dozen
@@ -981,11 +994,37 @@ static int detector_stream_k(const u64 *src, u64 nbits, u64 *err, u64 *reload, b
                                (const DetState *)endst, list2, nlist2, (const unsigned *)nlist);
         }
         hipError_t e = hipMemcpyAsync(hh, tail, 16 * sizeof(u64), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        // The host waits for the read-back only; the zeroing of the tail words for the NEXT call is queued behind it and runs
+        // while the host returns (5 us of a 0.29 ms call that were in front of the first kernel)
+        bool zero_queued = false;
+        if (e == hipSuccess && sparse) {
+            e = hipEventRecord(ev_copy, st);
+            if (e == hipSuccess) e = hipMemsetAsync(tail, 0, 16 * sizeof(u64), st);
+            if (e == hipSuccess) e = hipEventRecord(ev_zero, st);
+            zero_queued = e == hipSuccess;
+            if (e == hipSuccess) e = hipEventSynchronize(ev_copy);
+        } else if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) { cleanup(); BBB_HIP(e); }
         const unsigned nbad1 = (unsigned)(hh[4] & 0xffffffffull), nbad2 = (unsigned)(hh[12] & 0xffffffffull);
         bool settled = false;
-        if (!nbad1) { for (int i = 0; i < 5; i++) h[i] = hh[i]; settled = true; }
+        if (!nbad1) {
+            for (int i = 0; i < 5; i++) h[i] = hh[i];
+            settled = true;
+            if (zero_queued) {
+                // (nothing of this call but that memset is in flight: the workspace goes back without a stream synchronisation)
+                {
+                    std::lock_guard<std::mutex> g(g_det_ws_mu);
+                    g_det_ws[ws_slot].zeroed = true; g_det_ws[ws_slot].zeroed_at = o_tail;
+                }
+                det_ws_release(ws_slot);
+                BBB_HIP(hipGetLastError());
+                if (stats) {
+                    stats->bits = nbits; stats->errors = h[0]; stats->errors_raw = h[1]; stats->reload_clocks = h[2];
+                    stats->resyncs = h[3]; stats->chunks = nchunks; stats->chunks_rerun = 0; stats->serial_fallback = 0;
+                }
+                return BBB_OK;
+            }
+        }
         else if (sparse) {
             // second trip: the listed chunks again from their predecessors' ends, verify + totals, look again
             const unsigned nb = nbad1 < kSpec ? nbad1 : kSpec;

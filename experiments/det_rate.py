@@ -3,6 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import basebandboard_amd as bbb
+if os.environ.get("EXP"): bbb._lib.select_build("experiments")
 nbits = 10_000_000_000
 gen = bbb.PRBS(31)
 pbuf = gen.generate(nbits)
