@@ -140,6 +140,11 @@ prbs_seed_kernel(int ki, u64 init_state, u64 first_bit, u64 nseeds, u64 rows_per
     }
 }
 
+// NOT USED by the shipped library (BBB_PRBS_SEEDS defaults to 0; every wave derives its own start rows, as in rounds 1-3).
+// Round 4 first shipped it with the plan remembering the STREAM of its last use (no events): 7 us of a 0.43 ms loopback gained.
+// Made safe -- an event behind the seed kernel, one behind every reader, a lease over the cache while a reader is queued -- the
+// event packets on the caller's stream cost what the shared seeds save: loopback 0.4346-0.4364 ms with, 0.4321-0.4323 without
+// (same box, alternating: experiments/prbs_loopback2.py with BBB_PRBS_SEEDS=1 / 0).  Kept for that A/B.
 struct PrbsSeedPlan {
     int dev = -1, k = 0;
     u64 init = 0, first_bit = 0, rpw = 0, nseeds = 0;
@@ -688,7 +693,7 @@ static int launch_check_rev(int k, int ki, u64 init_state, u64 first_bit, u64 nb
     if (nblocks > 0x7fffffffull) return fail(BBB_EINVAL, "nbits too large");
     dim3 grid((unsigned)nblocks), block(64);
     PrbsSeedLease lease;
-    static const int use_seeds = env_knob("BBB_PRBS_SEEDS", 1);          // (A/B timing; -DBBB_EXPERIMENTS only)
+    static const int use_seeds = env_knob("BBB_PRBS_SEEDS", 0);          // (off: see PrbsSeedPlan; A/B timing, -DBBB_EXPERIMENTS only)
     if (use_seeds) {
         const int rcs = prbs_region_seeds(k, ki, init_state, first_bit, rpw, nblocks + 1, st, &lease);
         if (rcs) return rcs;
@@ -760,7 +765,7 @@ static int launch_stream_w(int k, int ki, u64 init_state, u64 first_bit, u64 nbi
     if (nblocks > 0x7fffffffull) return fail(BBB_EINVAL, "nbits too large");
     dim3 grid((unsigned)nblocks), block(64);
     PrbsSeedLease lease;
-    static const int use_seeds = env_knob("BBB_PRBS_SEEDS", 1);          // (A/B timing; -DBBB_EXPERIMENTS only)
+    static const int use_seeds = env_knob("BBB_PRBS_SEEDS", 0);          // (off: see PrbsSeedPlan; A/B timing, -DBBB_EXPERIMENTS only)
     if (use_seeds && WPL == 1) {                    // (one more than the generator needs: the reverse checker of the same range shares the plan)
         const int rcs = prbs_region_seeds(k, ki, init_state, first_bit, rpw, nblocks + 1, st, &lease);
         if (rcs) return rcs;

@@ -233,3 +233,47 @@ def test_seed_plans_outlive_the_stream_they_were_made_on(gpu, oracle):
         b = p.generate(3_000_000, first_bit=77)
     torch.cuda.synchronize()
     assert torch.equal(a, b)
+
+
+def test_shared_region_seeds_of_the_experiments_build(oracle):
+    """The shared region seeds (PrbsSeedPlan: not shipped) stay correct where they are still compiled in: the
+    experiments build with BBB_PRBS_SEEDS=1 -- fills and reverse checks of several k, sizes and offsets, a loopback, more plans
+    than the cache holds, a plan made on a handle's internal stream that is gone when the plan is re-targeted, a plan used from
+    two streams -- must give the bits of the product build and of the oracle.  In a child process: the switch is read once."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = (
+        "import gc, json, hashlib, torch, basebandboard_amd as g\n"
+        "g._lib.select_build('experiments')\n"
+        "out = {}\n"
+        "x = g.TX(31, 1, 0, 16, 1, 8)\n"
+        "with x.stream((1 << 24) + 4096, first_sample=0) as st: st.next()\n"
+        "torch.cuda.synchronize(); del st, x; gc.collect()\n"
+        "for k, n, first in [(31, 100_000, 1_000_003), (7, 8191, 3), (23, 5_000_000, 2**40 + 17), (9, 1_000_003, 0), (31, 40_000_000, 77)] + [(31, 300_000, 999 * i) for i in range(10)]:\n"
+        "    p = g.PRBS(k)\n"
+        "    w = p.generate(n, first_bit=first, will_read_back=True)\n"
+        "    assert g.PRBSErrorDetector(k).count_errors(w, n, first_bit=first) == 0\n"
+        "    out[f'{k}/{n}/{first}'] = hashlib.sha256(w.cpu().numpy().tobytes()).hexdigest()\n"
+        "p = g.PRBS(31); s2 = torch.cuda.Stream()\n"
+        "a = p.generate(3_000_000, first_bit=77)\n"
+        "with torch.cuda.stream(s2): b = p.generate(3_000_000, first_bit=77)\n"
+        "torch.cuda.synchronize(); assert torch.equal(a, b)\n"
+        "print(json.dumps(out))\n")
+    outs = []
+    for env in ({"BBB_PRBS_SEEDS": "1"}, {"BBB_PRBS_SEEDS": "0"}):
+        r = subprocess.run([sys.executable, "-c", code], cwd=str(ROOT), env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0] == outs[1]
+    import hashlib
+    exp, _ = oracle.prbs_packed(31, 100_000, state=_state_at(oracle, 31, 1_000_003), fast=True)
+    assert outs[0]["31/100000/1000003"] == hashlib.sha256(exp.tobytes()).hexdigest()
+
+
+def _state_at(oracle, k, first):
+    """LFSR state after `first` clocks from state 1 (the oracle's own stepping: small offsets only)."""
+    _, s = oracle.prbs_packed(k, first, state=1, fast=True)
+    return s
