@@ -283,7 +283,7 @@ def test_look_ahead_at_the_bench_size(gpu):
 def test_random_mix_of_calls_on_one_staged_handle(gpu, oracle, seed):
     """Soak: a random sequence of noise fills (sequential and not, hinted and not, two output buffers and two caller
     streams), TX fills, BER trials and level changes on ONE handle; every output equals what a fresh handle in the
-    one-kernel form produces.  Aimed at the stream / event plumbing between the arithmetic stream, the mover stream, the
+    one-kernel form produces.  Aimed at the stream / event plumbing between the arithmetic streams, the movers on the caller's streams, the
     seeding stream and the caller's."""
     rng = np.random.default_rng(seed)
     m = oracle.Lutopt(path=oracle.data_path(256))
