@@ -743,6 +743,15 @@ int ber_run(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, unsigned long lo
         if (!(h->planes_valid && h->planes_first == gen_first && h->planes_L == L && h->planes_G == G)) {
             if ((rc = ensure_internal_streams(h))) return rc;
             h->pf_waited_slot = -1;
+            // (both sets of start-state buffers sized by the FIRST trial of a size: the set that is current now is the one the
+            // next trial seeds into, and an allocation there would sit in that trial's path -- 0.4 ms of a 1.5 ms call)
+            if (h->states_cap < (size_t)G * h->W32 || h->planes_cap < (size_t)2 * h->k * nlanes) {
+                if (h->cur_read_pending) BBB_HIP(hipEventSynchronize(h->cur_last_read));      // growing frees the old buffers
+                h->cur_read_pending = false;
+                h->planes_valid = false;
+                if ((rc = grow(&h->d_states, &h->states_cap, (size_t)G * h->W32))) return rc;
+                if ((rc = grow(&h->d_planes, &h->planes_cap, (size_t)2 * h->k * nlanes))) return rc;
+            }
             if (!(h->pf.valid && h->pf.first == gen_first && h->pf.L == L && h->pf.G == G) &&
                 (rc = seed_announced(h, gen_first, L, G, nlanes, h->xs2[0], 2)))
                 return rc;
@@ -752,12 +761,14 @@ int ber_run(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, unsigned long lo
         JumpPlan *pp;
         if ((rc = get_prbs_plan(h, c.prbs_k, L, &pp))) return rc;
         const int pb = h->pp_idx ^= 1;
-        if (!h->pp_read[pb]) BBB_HIP(hipEventCreateWithFlags(&h->pp_read[pb], hipEventDisableTiming));
-        if (h->pstates_cap[pb] < (size_t)G || h->pplanes_cap[pb] < (size_t)32 * nlanes) {
-            if (h->pp_pending[pb]) BBB_HIP(hipEventSynchronize(h->pp_read[pb]));          // growing frees the old buffers
-            h->pp_pending[pb] = false;
-            if ((rc = grow(&h->d_pstates[pb], &h->pstates_cap[pb], (size_t)G))) return rc;
-            if ((rc = grow(&h->d_pplanes[pb], &h->pplanes_cap[pb], (size_t)32 * nlanes))) return rc;
+        for (int b : {pb, pb ^ 1}) {               // (both pairs sized by the first trial of a size, as above)
+            if (!h->pp_read[b]) BBB_HIP(hipEventCreateWithFlags(&h->pp_read[b], hipEventDisableTiming));
+            if (h->pstates_cap[b] < (size_t)G || h->pplanes_cap[b] < (size_t)32 * nlanes) {
+                if (h->pp_pending[b]) BBB_HIP(hipEventSynchronize(h->pp_read[b]));          // growing frees the old buffers
+                h->pp_pending[b] = false;
+                if ((rc = grow(&h->d_pstates[b], &h->pstates_cap[b], (size_t)G))) return rc;
+                if ((rc = grow(&h->d_pplanes[b], &h->pplanes_cap[b], (size_t)32 * nlanes))) return rc;
+            }
         }
         uint64_t ps0 = 0;
         if ((rc = prbs_state_at_host(c.prbs_k, c.prbs_state, c.first_bit, &ps0))) return rc;

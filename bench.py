@@ -627,8 +627,11 @@ def main():
         us = u if world == 1 else bbb.LUTOPT.shipped(256, init=u.state_at(rank << 48), device=local_rank)
         # untimed: builds the jump plans (tables per segment length).  At another stream position, so that the timed sweep
         # derives its own start states: the library keeps the last start states of a handle and would hand them back
-        warm = [channel.Trial(nbits=t.nbits, amp=t.amp, noise_var=nv, first_bit=1 << 20) for t in trials]
-        channel.sweep_seeds(warm, channel.gpu_runner(us), world=world)
+        # (three of them: the handle keeps two sets of start-state buffers and takes them in turn, and the first calls of a
+        # process spend 0.2-40 ms on the host -- plans, buffers, the runtime's own pools: experiments/ber_host2.py)
+        for wi in range(3):
+            warm = [channel.Trial(nbits=t.nbits, amp=t.amp, noise_var=nv, first_bit=(wi + 1) << 20) for t in trials]
+            channel.sweep_seeds(warm, channel.gpu_runner(us), world=world)
         torch.cuda.synchronize(); barrier()
         tb0 = time.perf_counter()
         total = channel.sweep_seeds(trials, channel.gpu_runner(us), world=world)
