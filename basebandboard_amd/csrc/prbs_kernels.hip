@@ -84,7 +84,8 @@ int prbs_state_at_host(int k, uint64_t init_state, uint64_t nbits, uint64_t *sta
 }
 
 // ---------------------------------------------------------------------------------------------
-// Region seeds (round 4).  Every wave of the generator and of the checker used to open with the same private bootstrap: jump
+// Region seeds (round 4; compiled into the EXPERIMENTS build only -- see PrbsSeedPlan below for why the shipped library does
+// not use them).  Every wave of the generator and of the checker opens with the same private bootstrap: jump
 // the LFSR state to its region (up to 64 dependent mat-vecs over four fetches of the power table), form K words bit by bit,
 // then grow them to K rows -- 15-20 us in which the kernel moves no data, twice per loopback (7 % of it).  The first two steps
 // depend on nothing but (k, init, first_bit, the partition): seed r = the K words that start K rows in front of region r.
@@ -140,6 +141,7 @@ prbs_seed_kernel(int ki, u64 init_state, u64 first_bit, u64 nseeds, u64 rows_per
     }
 }
 
+#ifdef BBB_EXPERIMENTS
 // NOT USED by the shipped library (BBB_PRBS_SEEDS defaults to 0; every wave derives its own start rows, as in rounds 1-3).
 // Round 4 first shipped it with the plan remembering the STREAM of its last use (no events): 7 us of a 0.43 ms loopback gained.
 // Made safe -- an event behind the seed kernel, one behind every reader, a lease over the cache while a reader is queued -- the
@@ -233,6 +235,14 @@ static int prbs_region_seeds(int k, int ki, u64 init_state, u64 first_bit, u64 r
     lease->plan = &p;
     return BBB_OK;
 }
+#else
+// (the shipped library has no seed plans: every wave derives its own start rows)
+struct PrbsSeedLease {
+    const u64 *seeds() const { return nullptr; }
+    int queued(hipStream_t) { return BBB_OK; }
+};
+static int prbs_region_seeds(int, int, u64, u64, u64, u64, hipStream_t, PrbsSeedLease *) { return BBB_OK; }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Streaming generator / checker.  One wave per block; block b owns rows [b*rpw, (b+1)*rpw).
