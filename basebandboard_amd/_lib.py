@@ -9,7 +9,7 @@ import pathlib
 _HERE = pathlib.Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libbbb_hip.so"
 
-SHARD_TRIALS, SHARD_SEEDS, SHARD_BITS = 0, 1, 2
+SHARD_TRIALS, SHARD_SEEDS, SHARD_BITS, SHARD_GROUPS = 0, 1, 2, 3
 BBB_OK, BBB_EINVAL, BBB_ENOMEM, BBB_EHIP, BBB_EIO, BBB_ENODEV, BBB_EUNSUP = 0, -1, -2, -3, -4, -5, -6
 
 # every symbol include/bbb.h declares (tests/test_abi.py checks the list against the header)

@@ -162,6 +162,208 @@ seed_level_kernel(const uint32_t *__restrict tabs, int k, int e, unsigned long l
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Start states AND bit planes in TWO launches (round 5; the BER trial's own seeding: an isolated trial waits for this chain, and
+// the chain above is seven launches -- store16, five levels of which three are a few thousand mat-vecs each and cost a launch
+// and a table staging apiece, then a bit-slicing pass over 134 MB: 131 us, profiles/r05_base_ber_timeline.txt).
+//   seed_head_kernel         S[0 .. 65535], packed.  Thread g composes the jumps of its three upper digits itself: digit 1 from
+//                            the tables IN PLACE (a wave reads four of them, each lookup two lines of one), digits 2 and 3 -- the
+//                            same for the whole block -- from LDS, both tables staged while the first mat-vec runs.  256 blocks,
+//                            each redoes the 256 small mat-vecs in front of its own: a few microseconds of redundant work against
+//                            two launches and two drains.
+//   seed_tail_planes_kernel  one block per WAVE of the consumer = 2048 consecutive generators, eight per thread.  Above the first
+//                            65536 it derives them, S[d 65536 + i] = B^(d 65536) S[i], d = 1 .. 31: digits 4 and 5 merged into
+//                            ONE level of "top" tables (JumpPlan::d_top), so that everything there is one launch of independent
+//                            mat-vecs and a block stages its table once for 2048 states (an eighth of the staging traffic of the
+//                            256-state blocks above); below, it reads them.  Then it bit-slices them itself: the eight states of a
+//                            thread become, per state word, 32 bytes (planes8_to_bytes: byte p = bit p of the eight), which meet
+//                            the bytes of the lane's other three threads in LDS (the table's memory, dead by then) as whole
+//                            plane words, stored by rows of 64 lanes.  The packed states above 65536 never reach memory and the
+//                            bit-slicing launch with its 134 MB is gone.
+// ---------------------------------------------------------------------------------------------
+template <int W32>
+__global__ void __launch_bounds__(256)
+seed_head_kernel(const uint32_t *__restrict tabs, Seed16 s, int k, unsigned long long G, unsigned long long stride,
+                 uint32_t *__restrict S) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t tab[];      // two tables: digit 2's, digit 3's
+    const unsigned t = threadIdx.x, d0 = t & 15u, d1 = t >> 4, d2 = blockIdx.x & 15u, d3 = blockIdx.x >> 4;
+    const unsigned long long g = (unsigned long long)blockIdx.x * 256 + t;
+    if ((unsigned long long)blockIdx.x * 256 >= G) return;       // whole block beyond the last generator
+    const int nnib = (k + 3) / 4;
+    const int nt = nnib * 16 * W32;
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    // the block's two tables on their way to LDS (registers first: digit 1's mat-vec runs while the loads are in flight)
+    constexpr int kMaxPieces = (64 * 16 * W32 / 4 + 255) / 256;   // 16-byte pieces per thread and table for k <= 256
+    u4 v2[kMaxPieces], v3[kMaxPieces];
+    const int n4 = nt / 4;
+    if (d2) {
+        const u4 *src = reinterpret_cast<const u4 *>(tabs + ((size_t)2 * 15 + (d2 - 1)) * nt);
+#pragma unroll
+        for (int u = 0; u < kMaxPieces; u++) {
+            const int q = u * 256 + (int)t;
+            if (q < n4) v2[u] = src[q];
+        }
+    }
+    if (d3) {
+        const u4 *src = reinterpret_cast<const u4 *>(tabs + ((size_t)3 * 15 + (d3 - 1)) * nt);
+#pragma unroll
+        for (int u = 0; u < kMaxPieces; u++) {
+            const int q = u * 256 + (int)t;
+            if (q < n4) v3[u] = src[q];
+        }
+    }
+    uint32_t x[W32], y[W32];
+#pragma unroll
+    for (int w = 0; w < W32; w++) x[w] = s.w[d0][w];
+    if (d1) {
+#pragma unroll
+        for (int w = 0; w < W32; w++) y[w] = 0u;
+        nibble_matvec_part<W32>(tabs + ((size_t)1 * 15 + (d1 - 1)) * nt, 0, nnib, x, y);
+#pragma unroll
+        for (int w = 0; w < W32; w++) x[w] = y[w];
+    }
+    if (d2 || d3) {                                 // (block-uniform: every thread of the block reaches the barrier)
+        u4 *dst2 = reinterpret_cast<u4 *>(tab), *dst3 = reinterpret_cast<u4 *>(tab + nt);
+#pragma unroll
+        for (int u = 0; u < kMaxPieces; u++) {
+            const int q = u * 256 + (int)t;
+            if (q < n4 && d2) dst2[q] = v2[u];
+            if (q < n4 && d3) dst3[q] = v3[u];
+        }
+        __syncthreads();
+    }
+    if (d2) {
+#pragma unroll
+        for (int w = 0; w < W32; w++) y[w] = 0u;
+        nibble_matvec_part<W32>(tab, 0, nnib, x, y);
+#pragma unroll
+        for (int w = 0; w < W32; w++) x[w] = y[w];
+    }
+    if (d3) {
+#pragma unroll
+        for (int w = 0; w < W32; w++) y[w] = 0u;
+        nibble_matvec_part<W32>(tab + nt, 0, nnib, x, y);
+#pragma unroll
+        for (int w = 0; w < W32; w++) x[w] = y[w];
+    }
+    if (g < G) {
+#pragma unroll
+        for (int w = 0; w < W32; w++) S[w * stride + g] = x[w];
+    }
+}
+
+// k = 256 only (W32 = 8: the 32 KiB table holds four state words' worth of plane rows at a time)
+__global__ void __launch_bounds__(256, 4)       // <= 128 registers: the 1022 blocks of a 1e9-bit trial are resident together, four per CU
+seed_tail_planes_kernel(const uint32_t *__restrict top, unsigned long long G, unsigned long long stride, const uint32_t *__restrict S,
+                        unsigned nlanes, uint32_t *__restrict planes) {
+    constexpr int W32 = 8, nnib = 64, nt = nnib * 16 * W32;
+    extern __shared__ __attribute__((aligned(16))) uint32_t tab[];       // 32 KiB: the block's table, then the exchange buffer
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const unsigned t = threadIdx.x, lane = t & 63u, jq = t >> 6;
+    const unsigned long long wv = blockIdx.x, d = wv >> 5;               // 32 waves of the consumer per 65536 generators
+    // generator r of this thread: bit position j = 8 jq + r of consumer lane (wv, lane)
+    const unsigned long long g0 = gen_index(wv, lane, 8 * jq);           // (+ 64 per r)
+    // acc[wq][i] byte q, bit r = bit 8 q + i of word wq of the thread's state r: what planes8_to_bytes makes of the eight words,
+    // built up state by state (the eight states of a thread never exist side by side: 64 registers of accumulators instead of
+    // 64 of states + the transposition's temporaries, and the loop over r stays a loop)
+    uint32_t acc[W32][8];
+#pragma unroll
+    for (int w = 0; w < W32; w++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc[w][i] = 0u;
+    auto deposit = [&](const uint32_t (&y)[W32], unsigned r) {
+#pragma unroll
+        for (int w = 0; w < W32; w++)
+#pragma unroll
+            for (int i = 0; i < 8; i++) acc[w][i] |= ((y[w] >> i) & 0x01010101u) << r;
+    };
+    uint32_t xn[W32];
+#pragma unroll
+    for (int w = 0; w < W32; w++) xn[w] = g0 < G ? S[w * stride + (g0 & 65535ull)] : 0u;       // in flight while the table is staged
+    if (d == 0) {
+#pragma unroll 1
+        for (unsigned r = 0; r < 8; r++) {
+            uint32_t x[W32];
+#pragma unroll
+            for (int w = 0; w < W32; w++) x[w] = xn[w];
+            if (r + 1 < 8) {
+                const unsigned long long g = g0 + 64ull * (r + 1);
+#pragma unroll
+                for (int w = 0; w < W32; w++) xn[w] = g < G ? S[w * stride + g] : 0u;
+            }
+            deposit(x, r);
+        }
+    } else {
+        {
+            const u4 *src = reinterpret_cast<const u4 *>(top + (size_t)(d - 1) * nt);
+            u4 *dstp = reinterpret_cast<u4 *>(tab);
+            constexpr int n4 = nt / 4;
+#pragma unroll
+            for (int base = 0; base < n4; base += 4 * 256) {
+                u4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) v[u] = src[base + u * 256 + (int)t];
+#pragma unroll
+                for (int u = 0; u < 4; u++) dstp[base + u * 256 + (int)t] = v[u];
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (unsigned r = 0; r < 8; r++) {
+            uint32_t x[W32], y[W32];
+#pragma unroll
+            for (int w = 0; w < W32; w++) { x[w] = xn[w]; y[w] = 0u; }
+            if (r + 1 < 8) {
+                const unsigned long long g = g0 + 64ull * (r + 1);
+#pragma unroll
+                for (int w = 0; w < W32; w++) xn[w] = g < G ? S[w * stride + (g & 65535ull)] : 0u;
+            }
+            // y = M x by nibble lookups (nibble_matvec_part's scheme, eight 16-byte lookups in flight instead of sixteen: registers)
+#pragma unroll
+            for (int w = 0; w < W32; w++) {
+                uint32_t xw = x[w];
+                asm volatile("" : "+v"(xw));
+#pragma unroll
+                for (int q = 0; q < 8; q += 2) {
+                    const int n0 = w * 8 + q, n1 = n0 + 1;
+                    const uint32_t v0 = (xw >> (4 * q)) & 15u, v1 = (xw >> (4 * q + 4)) & 15u;
+#pragma unroll
+                    for (int zc = 0; zc < 2; zc++) {
+                        const u4 e0 = *reinterpret_cast<const u4 *>(tab + ((n0 * 2 + zc) * 16 + v0) * 4);
+                        const u4 e1 = *reinterpret_cast<const u4 *>(tab + ((n1 * 2 + zc) * 16 + v1) * 4);
+#pragma unroll
+                        for (int zz = 0; zz < 4; zz++) y[zc * 4 + zz] = __builtin_amdgcn_bitop3_b32(y[zc * 4 + zz], e0[zz], e1[zz], 0x96);
+                    }
+                    if (q & 2) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            deposit(y, r);                                               // (a generator beyond G: x = 0 gives y = 0)
+        }
+        __syncthreads();                                                 // the table is dead: its memory becomes the exchange buffer
+    }
+    // byte jq of the plane word (plane 32 wq + 8 q + i, lane) = byte q of acc[wq][i].  Four state words (128 plane rows of 64 lanes:
+    // 32 KiB) per round.
+    uint8_t *xb = reinterpret_cast<uint8_t *>(tab);
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        if (half) __syncthreads();                                       // the first round's rows have been read
+#pragma unroll
+        for (int wl = 0; wl < 4; wl++)
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    xb[(((unsigned)(wl * 32 + 8 * q + i)) * 64u + lane) * 4u + jq] = (uint8_t)(acc[half * 4 + wl][i] >> (8 * q));
+        __syncthreads();
+        // 128 rows of 64 words: thread (lane, jq) takes rows jq, jq + 4, ...
+#pragma unroll 8
+        for (int m = 0; m < 32; m++) {
+            const unsigned row = jq + 4u * (unsigned)m;
+            planes[(size_t)(half * 128 + row) * nlanes + wv * 64 + lane] = tab[row * 64u + lane];
+        }
+    }
+}
+
 // PRBS start states for the BER kernels (round 4): k <= 31, so a state is one word and a jump table at most 512 bytes; all of
 // them (levels 1..6 x 15 digits: 45 KiB) sit in LDS and thread g composes the jumps of generator g digit by digit -- one launch
 // (plus bitslice_kernel<1>) where the generic chain took seven on the side stream and held CUs beside the generator's own seeding.
@@ -190,6 +392,55 @@ prbs_seed_states_kernel(const uint32_t *__restrict tabs, Seed16 s, int k, int le
         }
         S[g] = x;
     }
+}
+
+// The same start states without LDS and in ONE launch (round 5).  The 32 generators of a consumer lane are 64 L bits apart
+// from each other, so ONE table-composed state per lane -- 65 408 instead of 2.09 M, from the jump tables in place (global memory:
+// the vector cache holds the few KiB a wave touches) -- and 31 steps with the 31 x 31 matrix Q = B^64 (its columns are scalars:
+// V_BFE_I32 + V_BITOP3 per column) give a lane's 32 states, a 32 x 32 bit transpose the planes.  ~2300 VALU instructions per
+// lane, no LDS: beside the generators' seeding kernels, which live on the LDS pipeline, it costs them nothing (the table-driven
+// form above took 65 us there and lengthened the tail kernel from 61 to 85: profiles/r05_ber_c_timeline.txt).
+struct PrbsLaneJump { uint32_t qcol[32]; uint32_t first[16]; };      // qcol[c]: column c of Q (bit r = Q[r][c]); first[i] = B^i p0
+__global__ void __launch_bounds__(256)
+prbs_seed_lanes_kernel(const uint32_t *__restrict tabs, PrbsLaneJump jp, int k, int levels, unsigned long long G, unsigned nlanes,
+                       uint32_t *__restrict planes) {
+    __shared__ uint32_t first[16];
+    if (threadIdx.x < 16) first[threadIdx.x] = jp.first[threadIdx.x];
+    __syncthreads();
+    const unsigned long long LG = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (LG >= nlanes) return;
+    const unsigned long long wave = LG >> 6;
+    const unsigned lane = (unsigned)(LG & 63);
+    const unsigned long long g0 = gen_index(wave, lane, 0);
+    const int nnib = (k + 3) / 4, nt = nnib * 16;
+    uint32_t x = first[g0 & 15];
+    for (int e = 1; e < levels; e++) {
+        const unsigned d = (unsigned)(g0 >> (4 * e)) & 15u;
+        if (d) {
+            const uint32_t *t = tabs + ((size_t)e * 15 + (d - 1)) * nt;
+            uint32_t y = 0;
+#pragma unroll
+            for (int n = 0; n < 8; n++)
+                if (n < nnib) y ^= t[n * 16 + ((x >> (4 * n)) & 15u)];
+            x = y;
+        }
+    }
+    uint32_t q[32];
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+        q[j] = g0 + 64ull * (unsigned)j < G ? x : 0u;
+        uint32_t y = 0;
+#pragma unroll
+        for (int c = 0; c < 31; c++) {
+            const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)x, c, 1);      // 0 or ~0: bit c of x
+            y = __builtin_amdgcn_bitop3_b32(y, jp.qcol[c], m, 0x78);                // a ^ (b & c)
+        }
+        x = y;
+    }
+    transpose32(q);
+#pragma unroll
+    for (int p = 0; p < 32; p++)
+        if (p < k) planes[(size_t)p * nlanes + LG] = q[p];
 }
 
 // Word-major packed states -> bit planes.  Thread (LG, wq) gathers word wq of the 32 generators of
@@ -1171,6 +1422,42 @@ static int seed_and_slice(int k, const uint32_t *d_tabs, const uint32_t *s16, ui
     return BBB_OK;
 }
 
+int awgn_seed_head_launch(int k, const uint32_t *d_tabs, const uint32_t *s16, uint64_t G, uint32_t *d_states, hipStream_t st) {
+    constexpr int W32 = 8;
+    if (k != 256 || G > ((uint64_t)kSeedTopTables + 1) * 65536) return fail(BBB_EINVAL, "two-launch seeding: k = 256, at most 2^21 generators");
+    Seed16 s;
+    for (int i = 0; i < 16; i++)
+        for (int w = 0; w < 16; w++) s.w[i][w] = w < W32 ? s16[i * 16 + w] : 0u;
+    const size_t lds = (size_t)2 * 64 * 16 * W32 * sizeof(uint32_t);              // two whole tables: 64 KiB of dynamic LDS
+    {   // (per device: hipFuncSetAttribute applies to the current one)
+        static std::mutex mu;
+        static bool attr_set[64] = {false};
+        int dev = 0;
+        BBB_HIP(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> g(mu);
+        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+            BBB_HIP(hipFuncSetAttribute((const void *)seed_head_kernel<W32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        }
+    }
+    const uint64_t head = G < 65536 ? G : 65536;
+    hipLaunchKernelGGL((seed_head_kernel<W32>), dim3((unsigned)((head + 255) / 256)), dim3(256), lds, st, d_tabs, s, k,
+                       (unsigned long long)G, 65536ull, d_states);
+    BBB_HIP(hipGetLastError());
+    return BBB_OK;
+}
+
+int awgn_seed_tail_planes_launch(int k, const uint32_t *d_top, uint64_t G, const uint32_t *d_states, unsigned nlanes, uint32_t *d_planes,
+                                 hipStream_t st) {
+    if (k != 256 || G > ((uint64_t)kSeedTopTables + 1) * 65536 || !d_top || (uint64_t)nlanes * 32 < G || nlanes % 64)
+        return fail(BBB_EINVAL, "two-launch seeding: k = 256, at most 2^21 generators");
+    const size_t lds = (size_t)64 * 16 * 8 * sizeof(uint32_t);                    // one table: 32 KiB
+    hipLaunchKernelGGL(seed_tail_planes_kernel, dim3(nlanes / 64), dim3(256), lds, st, d_top, (unsigned long long)G, 65536ull, d_states,
+                       nlanes, d_planes);
+    BBB_HIP(hipGetLastError());
+    return BBB_OK;
+}
+
 int prbs_seed_planes_launch(int k, const uint32_t *d_tabs, const uint32_t *s16, uint64_t G, uint32_t *d_states, unsigned nlanes,
                             uint32_t *d_planes, hipStream_t st) {
     if (k < 2 || k > 31) return fail(BBB_EINVAL, "PRBS order must be below 32");
@@ -1185,6 +1472,22 @@ int prbs_seed_planes_launch(int k, const uint32_t *d_tabs, const uint32_t *s16, 
                        (unsigned long long)G, d_states);
     hipLaunchKernelGGL((bitslice_kernel<1>), dim3((nlanes + 255) / 256), dim3(256), 0, st, d_states, (unsigned long long)G,
                        (unsigned long long)G, nlanes, k, d_planes);
+    BBB_HIP(hipGetLastError());
+    return BBB_OK;
+}
+
+int prbs_seed_lanes_launch(int k, const uint32_t *d_tabs, const uint32_t *s16, const uint32_t *qcol, uint64_t G, unsigned nlanes,
+                           uint32_t *d_planes, hipStream_t st) {
+    if (k < 2 || k > 31) return fail(BBB_EINVAL, "PRBS order must be below 32");
+    PrbsLaneJump jp{};
+    for (int i = 0; i < 16; i++) jp.first[i] = s16[i * 16];
+    for (int c = 0; c < 32; c++) jp.qcol[c] = c < k ? qcol[c] : 0u;
+    int levels = 0;
+    while ((1ull << (4 * levels)) < G) levels++;
+    if (levels < 1) levels = 1;
+    if (levels > 7) return fail(BBB_EINVAL, "too many generators for the PRBS jump plan");
+    hipLaunchKernelGGL(prbs_seed_lanes_kernel, dim3((nlanes + 255) / 256), dim3(256), 0, st, d_tabs, jp, k, levels, (unsigned long long)G, nlanes,
+                       d_planes);
     BBB_HIP(hipGetLastError());
     return BBB_OK;
 }

@@ -13,10 +13,24 @@ namespace bbb {
 // seeding is to run beside the transmitter variant of the sample kernel, which leaves less LDS free
 int awgn_seed_launch(int k, const uint32_t *d_tabs, const uint32_t *s16, uint64_t G, uint32_t *d_states,
                      uint64_t stride, unsigned nlanes, uint32_t *d_planes, hipStream_t st, int slice_mode = 0, int parts = 2);
+// round 5, the BER trial's own seeding: the same start states AND their bit planes in TWO launches (seed_head_kernel: the
+// first 65536 states; seed_tail_planes_kernel: one block per wave of the consumer -- 2048 generators -- does the top-level
+// mat-vecs and the bit transposition in LDS and writes planes[k][nlanes] directly; the packed states above the first
+// 65536 never reach memory).  d_top: the plan's merged top level, tables of B^(d 65536) for d = 1 .. kSeedTopTables; k = 256
+// (W32 = 8), G <= 2^21; d_states holds 65536 x 8 words.  Two calls, so that a caller can queue other work between them (the
+// trial's PRBS seeding goes to its side stream while the head kernel runs)
+constexpr int kSeedTopTables = 31;
+int awgn_seed_head_launch(int k, const uint32_t *d_tabs, const uint32_t *s16, uint64_t G, uint32_t *d_states, hipStream_t st);
+int awgn_seed_tail_planes_launch(int k, const uint32_t *d_top, uint64_t G, const uint32_t *d_states, unsigned nlanes, uint32_t *d_planes,
+                                 hipStream_t st);
 // PRBS start states (k <= 31) of the BER kernels' generators, d_states[G] -> bit planes [k][nlanes], two launches; d_tabs = the radix-16
 // plan of the LFSR's jump matrix (W32 = 1), s16 as above
 int prbs_seed_planes_launch(int k, const uint32_t *d_tabs, const uint32_t *s16, uint64_t G, uint32_t *d_states, unsigned nlanes,
                             uint32_t *d_planes, hipStream_t st);
+// the same planes in ONE launch without LDS (round 5): one table-composed state per consumer lane, its other 31 generators by steps
+// with Q = B^64 (qcol[c] = column c of Q: JumpPlan::qcol64)
+int prbs_seed_lanes_launch(int k, const uint32_t *d_tabs, const uint32_t *s16, const uint32_t *qcol, uint64_t G, unsigned nlanes,
+                           uint32_t *d_planes, hipStream_t st);
 // awgn512.hip: generated kernel for the shipped n512 matrix (packed state, 16 generators per lane, int16 out)
 bool awgn512p_matches(int k, const uint16_t *taps, const uint32_t *row_off);
 int bitslice512p_launch(const uint32_t *d_states, uint64_t G, uint64_t stride, unsigned nlanes, uint32_t *d_planes, hipStream_t st);

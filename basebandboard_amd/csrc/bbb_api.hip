@@ -55,6 +55,9 @@ struct JumpPlan {
     GF2Mat B;                     // the per-generator jump itself (host copy, for the first 16 states)
     GF2Mat Bt;                    // its transpose: y = B x as the XOR of the rows of Bt that x selects (GF2Mat::matvec_t)
     uint32_t *d_cols = nullptr;   // [levels][15][k/4 * 16 * W32] nibble tables of M^(j*16^e)
+    uint32_t *d_top = nullptr;    // [kSeedTopTables][k/4 * 16 * W32] tables of M^(d * 16^4), d = 1 .. 31: digits 4 and 5 as ONE level
+                                  // (awgn_seed_states_launch; built on first use: ensure_top_tables)
+    uint32_t qcol64[32] = {0};    // PRBS plans (n <= 31): column c of B^64 -- the step between two generators of one consumer lane
     int levels = 0;
 };
 
@@ -98,6 +101,20 @@ struct bbb_lutopt {
     uint32_t *d_mbits[2] = {nullptr, nullptr}; size_t mbits_cap[2] = {0, 0};   // staged TX: a call's data bits, one buffer per staging slot (written on the
                                                                                // slot's arithmetic stream in front of the sample kernel, read by the slot's mover)
     hipEvent_t ber_join = nullptr;       // ber_run: behind the PRBS seeding on the side stream
+    // BER trials (round 5): the generators' start states from awgn_seed_head_launch / _tail_planes_launch (two launches: the first 65536 states packed,
+    // u32[8][65536], then the planes [256][nlanes] directly), two buffer pairs taken in turn like the PRBS pairs; bs_read[b]: behind the
+    // trial kernel that last read pair b; bs_ready[b]: behind the seeding that filled it (on the caller's stream or an arithmetic one)
+    uint32_t *d_bstates[2] = {nullptr, nullptr}; size_t bstates_cap[2] = {0, 0};
+    uint32_t *d_bplanes[2] = {nullptr, nullptr}; size_t bplanes_cap[2] = {0, 0};
+    hipEvent_t bs_read[2] = {nullptr, nullptr}, bs_ready[2] = {nullptr, nullptr};
+    bool bs_pending[2] = {false, false}, bs_valid[2] = {false, false};
+    uint64_t bs_first[2] = {0, 0}, bs_L[2] = {0, 0}, bs_G[2] = {0, 0};
+    int bs_idx = 0;
+    unsigned long long *h_counters = nullptr; size_t h_counters_cap = 0;     // pinned: the read-back of bbb_ber_trials / bbb_ber_sweep_multi
+    // d_counters is zeroed BEHIND the read-back of the call that used it (counters_zeroed: the event behind that memset), so that the
+    // next call's seeding is the first thing it queues; a call on another stream waits for the event
+    hipEvent_t counters_zeroed = nullptr;
+    bool counters_clean = false;
     bool fbits_pending[2] = {false, false};
     int fbits_slot = 0;
     // which stream position the planes in d_planes currently describe
@@ -257,6 +274,25 @@ void first16(const JumpPlan &plan, const uint64_t *s0, uint32_t *out) {
 
 constexpr int kPlanLevels = 7;    // radix 16: up to 16^7 = 2^28 generators
 
+// the merged top level of a plan (round 5): tables of B^(d 65536), d = 1 .. 31
+int ensure_top_tables(JumpPlan *plan) {
+    if (plan->d_top) return BBB_OK;
+    const GF2Mat &M = plan->B;
+    const int k = M.n, W32 = pad_w32(k), nnib = (k + 3) / 4;
+    const size_t nt = (size_t)nnib * 16 * W32;
+    std::vector<uint32_t> host((size_t)kSeedTopTables * nt, 0);
+    GF2Mat m4 = M;                                   // M^(16^4)
+    for (int q = 0; q < 16; q++) m4 = m4.mul(m4);
+    GF2Mat md = m4;
+    for (int d = 1; d <= kSeedTopTables; d++) {
+        if (d > 1) md = md.mul(m4);
+        nibble_table(md, &host[(size_t)(d - 1) * nt]);
+    }
+    BBB_HIP(hipMalloc((void **)&plan->d_top, host.size() * sizeof(uint32_t)));
+    BBB_HIP(hipMemcpy(plan->d_top, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    return BBB_OK;
+}
+
 int get_plan(bbb_lutopt *h, uint64_t L, JumpPlan **out) {
     auto it = h->plans.find(L);
     if (it == h->plans.end()) {
@@ -277,6 +313,12 @@ int get_prbs_plan(bbb_lutopt *h, int k, uint64_t L, JumpPlan **out) {
         GF2Powers pw(prbs_matrix(k, prbs_tap(k)));
         int rc = build_plan(pw.power(L), kPlanLevels, &p);
         if (rc) return rc;
+        {
+            GF2Mat q = p.B;
+            for (int i = 0; i < 6; i++) q = q.mul(q);
+            const GF2Mat qt = q.transpose();
+            for (int c = 0; c < k && c < 32; c++) p.qcol64[c] = (uint32_t)qt.row(c)[0];
+        }
         it = h->prbs_plans.emplace(key, p).first;
     }
     *out = &it->second;
@@ -728,66 +770,102 @@ int ber_run(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, unsigned long lo
         if (L >= (1ull << 27)) return fail(BBB_EINVAL, "nbits too large for one trial (about 2^47): split it with first_bit");
         for (int j = 0; j < n; j++) { td[(size_t)(i + j)].L = (uint32_t)L; td[(size_t)(i + j)].G = G; td[(size_t)(i + j)].nbits = c.nbits; }
         int rc;
-        // The generator's start states first: their chain of launches is what the trial kernel waits for (an isolated call's
-        // wall time starts with the host work in front of the first launch).  The BER kernels take the state OF their first
-        // sample: one clock past the stream position.
-        // Neither set of start states is derived on the stream the trial kernel runs on: the generators' go to the handle's
-        // SECOND set of start-state buffers on an arithmetic stream (seed_announced, as for an announced fill) and are swapped in,
-        // the PRBS's to one of two buffer pairs on the side stream.  A caller that queues trials back to back
-        // (bbb_ber_trials_dev does not synchronise) thereby has trial s + 1 seeded BESIDE the kernel of trial s -- the seedings
-        // are latency, not work, and the trial kernel leaves 140 registers per SIMD -- and its kernel follows that of trial s
-        // directly: 1.29 -> 1.17 ms per 11 x 1e9-bit sweep in a sequence (round 4).  A single call is as before.
+        // The BER kernels take the state OF their first sample: one clock past the stream position.  Neither set of start states
+        // touches the handle's stream-fill buffers (d_states / d_planes, the prefetch set): trials own two pairs of generator buffers
+        // (the first 65536 states packed + the bit planes) and two PRBS pairs, each taken in turn.
+        //
+        // Round 5 (profiles/r05_base_ber_timeline.txt: an isolated trial's kernel started 155 us after the first launch -- seven
+        // launches of generator seeding, 131 us, and the PRBS's states, queued 58 us later and 70-80 us long beside the big levels,
+        // finishing last).  Now: everything the host has to compute comes first; then the launches, in the order the GPU needs
+        // them -- the generators' head kernel (25 us), the PRBS seeding on the side stream BESIDE it (30 us alone), the tail kernel,
+        // which writes the planes (60 us) -- two launches where there were seven, and no bit-slicing pass.
+        // Where the generators' states are derived depends on what the caller's stream is doing:
+        //   busy   (a trial queued behind another: bbb_ber_trials_dev does not synchronise) -- on an arithmetic stream, BESIDE the
+        //          kernel of the trial before (the seedings are latency, not work; the trial kernel leaves 140 registers per SIMD),
+        //          and this trial's kernel follows that one directly: round 4's 1.29 -> 1.17 ms per sweep in a sequence;
+        //   idle   (an isolated call) -- in line on the caller's stream: nothing to overlap with, and a cross-queue event in
+        //          front of the trial kernel is a round trip through the command processor (20-26 us: DESIGN.md 3.4).
+        // Both orders carry the same dependencies (a buffer's last reader -> its seeding -> the trial kernel), by stream order
+        // where the stream is the same and by events where it is not.
         if (!h->ber_join) BBB_HIP(hipEventCreateWithFlags(&h->ber_join, hipEventDisableTiming));
         { const int rcs_ = ensure_side_stream(h); if (rcs_) return rcs_; }
+        if ((rc = ensure_internal_streams(h))) return rc;
         const uint64_t gen_first = c.warmup + c.first_bit + 1;
-        if (!(h->planes_valid && h->planes_first == gen_first && h->planes_L == L && h->planes_G == G)) {
-            if ((rc = ensure_internal_streams(h))) return rc;
-            h->pf_waited_slot = -1;
-            // (both sets of start-state buffers sized by the FIRST trial of a size: the set that is current now is the one the
-            // next trial seeds into, and an allocation there would sit in that trial's path -- 0.4 ms of a 1.5 ms call)
-            if (h->states_cap < (size_t)G * h->W32 || h->planes_cap < (size_t)2 * h->k * nlanes) {
-                if (h->cur_read_pending) BBB_HIP(hipEventSynchronize(h->cur_last_read));      // growing frees the old buffers
-                h->cur_read_pending = false;
-                h->planes_valid = false;
-                if ((rc = grow(&h->d_states, &h->states_cap, (size_t)G * h->W32))) return rc;
-                if ((rc = grow(&h->d_planes, &h->planes_cap, (size_t)2 * h->k * nlanes))) return rc;
-            }
-            if (!(h->pf.valid && h->pf.first == gen_first && h->pf.L == L && h->pf.G == G) &&
-                (rc = seed_announced(h, gen_first, L, G, nlanes, h->xs2[0], 2)))
-                return rc;
-            if ((rc = acquire_planes(h, gen_first, L, G, nlanes, true))) return rc;
-        }
-        // PRBS start states: the same doubling machinery with the k x k LFSR companion matrix
-        JumpPlan *pp;
+        // -- host: plans, buffers, the first sixteen states of both chains
+        JumpPlan *pp, *plan = nullptr;
         if ((rc = get_prbs_plan(h, c.prbs_k, L, &pp))) return rc;
         const int pb = h->pp_idx ^= 1;
-        for (int b : {pb, pb ^ 1}) {               // (both pairs sized by the first trial of a size, as above)
+        for (int b : {pb, pb ^ 1}) {               // (both pairs sized by the first trial of a size: an allocation sits in the call's path)
             if (!h->pp_read[b]) BBB_HIP(hipEventCreateWithFlags(&h->pp_read[b], hipEventDisableTiming));
-            if (h->pstates_cap[b] < (size_t)G || h->pplanes_cap[b] < (size_t)32 * nlanes) {
-                if (h->pp_pending[b]) BBB_HIP(hipEventSynchronize(h->pp_read[b]));          // growing frees the old buffers
+            if (h->pplanes_cap[b] < (size_t)32 * nlanes) {
+                if (h->pp_pending[b]) BBB_HIP(hipEventSynchronize(h->pp_read[b]));          // growing frees the old buffer
                 h->pp_pending[b] = false;
-                if ((rc = grow(&h->d_pstates[b], &h->pstates_cap[b], (size_t)G))) return rc;
                 if ((rc = grow(&h->d_pplanes[b], &h->pplanes_cap[b], (size_t)32 * nlanes))) return rc;
             }
         }
-        uint64_t ps0 = 0;
-        if ((rc = prbs_state_at_host(c.prbs_k, c.prbs_state, c.first_bit, &ps0))) return rc;
-        uint64_t ps64[8] = {ps0};
-        uint32_t ps16[256];
-        first16(*pp, ps64, ps16);
+        uint32_t ps16[256], s16[256];
+        {
+            uint64_t ps0 = 0;
+            if ((rc = prbs_state_at_host(c.prbs_k, c.prbs_state, c.first_bit, &ps0))) return rc;
+            uint64_t ps64[8] = {ps0};
+            first16(*pp, ps64, ps16);
+        }
+        int sb = -1;
+        for (int b : {0, 1})
+            if (h->bs_valid[b] && h->bs_first[b] == gen_first && h->bs_L[b] == L && h->bs_G[b] == G) sb = b;     // (the same trial again)
+        const bool seed_gen = sb < 0;
+        if (seed_gen) {
+            sb = h->bs_idx ^= 1;
+            for (int b : {sb, sb ^ 1}) {
+                if (!h->bs_read[b]) BBB_HIP(hipEventCreateWithFlags(&h->bs_read[b], hipEventDisableTiming));
+                if (h->bstates_cap[b] < (size_t)65536 * h->W32 || h->bplanes_cap[b] < (size_t)h->k * nlanes) {
+                    if (h->bs_pending[b]) BBB_HIP(hipEventSynchronize(h->bs_read[b]));      // growing frees the old buffers
+                    h->bs_pending[b] = false;
+                    h->bs_valid[b] = false;
+                    if ((rc = grow(&h->d_bstates[b], &h->bstates_cap[b], (size_t)65536 * h->W32))) return rc;
+                    if ((rc = grow(&h->d_bplanes[b], &h->bplanes_cap[b], (size_t)h->k * nlanes))) return rc;
+                }
+            }
+            for (int b : {0, 1})
+                if (!h->bs_ready[b]) BBB_HIP(hipEventCreateWithFlags(&h->bs_ready[b], hipEventDisableTiming));
+            if ((rc = get_plan(h, L, &plan))) return rc;
+            if ((rc = ensure_top_tables(plan))) return rc;
+            uint64_t s0[8] = {0};
+            h->pw->apply(gen_first, h->init, s0);
+            first16(*plan, s0, s16);
+        }
+        // -- launches
+        const bool busy = seed_gen && hipStreamQuery(h->cs) == hipErrorNotReady;
+        hipStream_t ss = busy ? h->xs2[0] : h->cs;
+        if (seed_gen) {
+            h->bs_valid[sb] = false;
+            if (h->bs_pending[sb]) BBB_HIP(hipStreamWaitEvent(ss, h->bs_read[sb], 0));    // the trial before last read this pair
+            if ((rc = awgn_seed_head_launch(h->k, plan->d_cols, s16, G, h->d_bstates[sb], ss))) return rc;
+        }
         if (h->pp_pending[pb]) BBB_HIP(hipStreamWaitEvent(h->side, h->pp_read[pb], 0));    // the trial before last read this pair
-        if ((rc = prbs_seed_planes_launch(c.prbs_k, pp->d_cols, ps16, G, h->d_pstates[pb], nlanes, h->d_pplanes[pb], h->side))) return rc;
+        if ((rc = prbs_seed_lanes_launch(c.prbs_k, pp->d_cols, ps16, pp->qcol64, G, nlanes, h->d_pplanes[pb], h->side))) return rc;
         BBB_HIP(hipEventRecord(h->ber_join, h->side));
+        if (seed_gen) {
+            if ((rc = awgn_seed_tail_planes_launch(h->k, plan->d_top, G, h->d_bstates[sb], nlanes, h->d_bplanes[sb], ss))) return rc;
+            BBB_HIP(hipEventRecord(h->bs_ready[sb], ss));
+            if (busy) BBB_HIP(hipStreamWaitEvent(h->cs, h->bs_ready[sb], 0));
+            h->bs_valid[sb] = true;
+            h->bs_first[sb] = gen_first; h->bs_L[sb] = L; h->bs_G[sb] = G;
+        } else {
+            // the same trial again: its states were derived by an earlier call -- on whatever stream that call found right
+            BBB_HIP(hipStreamWaitEvent(h->cs, h->bs_ready[sb], 0));
+        }
         BBB_HIP(hipStreamWaitEvent(h->cs, h->ber_join, 0));
         if (h->specialised) {
-            if ((rc = ber256_launch(h->d_planes, h->d_pplanes[pb], &td[(size_t)i], n, nlanes, counters_dev + 2 * (size_t)i, h->cs))) return rc;
+            if ((rc = ber256_launch(h->d_bplanes[sb], h->d_pplanes[pb], &td[(size_t)i], n, nlanes, counters_dev + 2 * (size_t)i, h->cs))) return rc;
         } else {
-            const int e = h->custom_ber(h->d_planes, h->d_pplanes[pb], &td[(size_t)i], n, nlanes, (uint64_t *)(counters_dev + 2 * (size_t)i), (void *)h->cs);
+            const int e = h->custom_ber(h->d_bplanes[sb], h->d_pplanes[pb], &td[(size_t)i], n, nlanes, (uint64_t *)(counters_dev + 2 * (size_t)i), (void *)h->cs);
             if (e) return fail(e < 0 ? e : BBB_EHIP, "custom BER kernel failed");
         }
         BBB_HIP(hipEventRecord(h->pp_read[pb], h->cs));
         h->pp_pending[pb] = true;
-        if ((rc = mark_planes_read(h))) return rc;
+        BBB_HIP(hipEventRecord(h->bs_read[sb], h->cs));
+        h->bs_pending[sb] = true;
         i += n;
     }
     return BBB_OK;
@@ -918,14 +996,17 @@ int bbb_lutopt_destroy(bbb_lutopt *h) {
     if (h->device < 0) { delete h; return BBB_OK; }
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
-    for (auto &p : h->plans) (void)hipFree(p.second.d_cols);
+    for (auto &p : h->plans) { (void)hipFree(p.second.d_cols); if (p.second.d_top) (void)hipFree(p.second.d_top); }
     for (auto &p : h->prbs_plans) (void)hipFree(p.second.d_cols);
     for (void *p : {(void *)h->d_states, (void *)h->d_planes, (void *)h->d_pstates[0], (void *)h->d_pplanes[0], (void *)h->d_pstates[1], (void *)h->d_pplanes[1],
                     (void *)h->d_taps, (void *)h->d_row_off, (void *)h->d_counters, (void *)h->d_txnoise,
-                    (void *)h->d_txbits, (void *)h->d_fbits[0], (void *)h->d_fbits[1], (void *)h->d_mbits[0], (void *)h->d_mbits[1], (void *)h->pf.d_states, (void *)h->pf.d_planes})
+                    (void *)h->d_txbits, (void *)h->d_fbits[0], (void *)h->d_fbits[1], (void *)h->d_mbits[0], (void *)h->d_mbits[1], (void *)h->pf.d_states, (void *)h->pf.d_planes,
+                    (void *)h->d_bstates[0], (void *)h->d_bstates[1], (void *)h->d_bplanes[0], (void *)h->d_bplanes[1]})
         (void)hipFree(p);
+    if (h->h_counters) (void)hipHostFree(h->h_counters);
     for (hipEvent_t e : {h->pf.seeded, h->pf.last_read, h->cur_last_read, h->handover, h->stage_free[0], h->stage_free[1],
-                         h->stage_arith[0], h->stage_arith[1], h->ev_user, h->fbits_read[0], h->fbits_read[1], h->fbits_ready, h->ber_join, h->pp_read[0], h->pp_read[1]})
+                         h->stage_arith[0], h->stage_arith[1], h->ev_user, h->fbits_read[0], h->fbits_read[1], h->fbits_ready, h->ber_join, h->pp_read[0], h->pp_read[1],
+                         h->bs_read[0], h->bs_read[1], h->bs_ready[0], h->bs_ready[1], h->counters_zeroed})
         if (e) (void)hipEventDestroy(e);
     // (profiling events of calls whose times were never read: found by the scheduler model's leak check, tests/sched_model)
     for (auto &pr : h->prof_mover_pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -1707,28 +1788,66 @@ int bbb_ber_trials_dev(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, uint6
     return ber_run(h, cfgs, ncfg, (unsigned long long *)counters_dev);
 }
 
+// the handle's device counters and their pinned host mirror (a pageable read-back goes through the runtime's staging buffer)
+static int ensure_counters(bbb_lutopt *h, size_t need) {
+    if (h->counters_cap < need) {
+        if (h->d_counters) BBB_HIP(hipFree(h->d_counters));
+        h->d_counters = nullptr;
+        h->counters_cap = 0;
+        const size_t cap = need < 64 ? 64 : need;
+        BBB_HIP(hipMalloc((void **)&h->d_counters, cap * sizeof(unsigned long long)));
+        h->counters_cap = cap;
+        h->counters_clean = false;
+    }
+    if (h->h_counters_cap < need) {
+        if (h->h_counters) BBB_HIP(hipHostFree(h->h_counters));
+        h->h_counters = nullptr;
+        h->h_counters_cap = 0;
+        const size_t cap = need < 64 ? 64 : need;
+        BBB_HIP(hipHostMalloc((void **)&h->h_counters, cap * sizeof(unsigned long long), hipHostMallocDefault));
+        h->h_counters_cap = cap;
+    }
+    return BBB_OK;
+}
+
+// d_counters[0 .. need) zero on h->stream: the zeroing queued behind the previous read-back is taken (its event waited for: the
+// handle may have been re-bound to another stream since), else a memset now
+static int take_clean_counters(bbb_lutopt *h, size_t need) {
+    if (h->counters_clean && h->counters_zeroed) {
+        BBB_HIP(hipStreamWaitEvent(h->stream, h->counters_zeroed, 0));
+    } else {
+        BBB_HIP(hipMemsetAsync(h->d_counters, 0, need * sizeof(unsigned long long), h->stream));
+    }
+    h->counters_clean = false;
+    return BBB_OK;
+}
+
+// queues the pinned read-back of d_counters[0 .. need) on h->stream and, behind it, the zeroing for the next call
+static int read_back_counters(bbb_lutopt *h, size_t need) {
+    BBB_HIP(hipMemcpyAsync(h->h_counters, h->d_counters, need * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    BBB_HIP(hipMemsetAsync(h->d_counters, 0, h->counters_cap * sizeof(unsigned long long), h->stream));
+    if (!h->counters_zeroed) BBB_HIP(hipEventCreateWithFlags(&h->counters_zeroed, hipEventDisableTiming));
+    BBB_HIP(hipEventRecord(h->counters_zeroed, h->stream));
+    h->counters_clean = true;
+    return BBB_OK;
+}
+
 int bbb_ber_trials(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, bbb_ber *out) {
     if (!h || (ncfg && (!cfgs || !out)) || ncfg < 0) return fail(BBB_EINVAL, "null argument");
     if (ncfg == 0) return BBB_OK;
     if (h->device < 0) return fail(BBB_ENODEV, "host-only handle (device -1) cannot run trials");
     BBB_HIP(hipSetDevice(h->device));
     const size_t need = 2 * (size_t)ncfg;
-    if (h->counters_cap < need) {
-        if (h->d_counters) BBB_HIP(hipFree(h->d_counters));
-        h->d_counters = nullptr;
-        h->counters_cap = 0;
-        BBB_HIP(hipMalloc((void **)&h->d_counters, need * sizeof(unsigned long long)));
-        h->counters_cap = need;
-    }
-    BBB_HIP(hipMemsetAsync(h->d_counters, 0, need * sizeof(unsigned long long), h->stream));
-    int rc = ber_run(h, cfgs, ncfg, h->d_counters);
+    int rc = ensure_counters(h, need);
     if (rc) return rc;
-    std::vector<unsigned long long> host(need);
-    BBB_HIP(hipMemcpyAsync(host.data(), h->d_counters, need * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    if ((rc = take_clean_counters(h, need))) return rc;
+    rc = ber_run(h, cfgs, ncfg, h->d_counters);
+    if (rc) return rc;
+    if ((rc = read_back_counters(h, need))) return rc;
     BBB_HIP(hipStreamSynchronize(h->stream));
     for (int i = 0; i < ncfg; i++) {
-        out[i].bits = host[2 * (size_t)i];
-        out[i].errors = host[2 * (size_t)i + 1];
+        out[i].bits = h->h_counters[2 * (size_t)i];
+        out[i].errors = h->h_counters[2 * (size_t)i + 1];
     }
     return BBB_OK;
 }
@@ -1813,9 +1932,9 @@ static int ber_run_step(bbb_ber_run *r, unsigned long long *counters_dev) {
         JumpPlan *plan, *pp;
         if ((rc = get_plan(h, r->Lb, &plan))) return rc;
         if ((rc = get_prbs_plan(h, c.prbs_k, r->Lb, &pp))) return rc;
-        if ((rc = grow(&r->d_states, &r->states_cap, (size_t)r->G * h->W32))) return rc;
+        if ((rc = ensure_top_tables(plan))) return rc;
+        if ((rc = grow(&r->d_states, &r->states_cap, (size_t)65536 * h->W32))) return rc;
         if ((rc = grow(&r->d_planes, &r->planes_cap, (size_t)h->k * r->nlanes))) return rc;
-        if ((rc = grow(&r->d_pstates, &r->pstates_cap, (size_t)r->G))) return rc;
         if ((rc = grow(&r->d_pplanes, &r->pplanes_cap, (size_t)32 * r->nlanes))) return rc;
         uint64_t s0[8];
         h->pw->apply(c.warmup + block_first + 1, h->init, s0);
@@ -1831,9 +1950,10 @@ static int ber_run_step(bbb_ber_run *r, unsigned long long *counters_dev) {
             if (!*e) BBB_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
         BBB_HIP(hipEventRecord(r->fork, h->cs));                      // (the previous block's last kernel still reads the buffers)
         BBB_HIP(hipStreamWaitEvent(h->side, r->fork, 0));
-        if ((rc = prbs_seed_planes_launch(c.prbs_k, pp->d_cols, ps16, r->G, r->d_pstates, r->nlanes, r->d_pplanes, h->side))) return rc;
+        if ((rc = prbs_seed_lanes_launch(c.prbs_k, pp->d_cols, ps16, pp->qcol64, r->G, r->nlanes, r->d_pplanes, h->side))) return rc;
         BBB_HIP(hipEventRecord(r->join, h->side));
-        if ((rc = awgn_seed_launch(h->k, plan->d_cols, s16, r->G, r->d_states, r->G, r->nlanes, r->d_planes, h->cs))) return rc;
+        if ((rc = awgn_seed_head_launch(h->k, plan->d_cols, s16, r->G, r->d_states, h->cs))) return rc;
+        if ((rc = awgn_seed_tail_planes_launch(h->k, plan->d_top, r->G, r->d_states, r->nlanes, r->d_planes, h->cs))) return rc;
         BBB_HIP(hipStreamWaitEvent(h->cs, r->join, 0));
     }
     const uint64_t Lc = r->Lb / r->m;
@@ -1986,9 +2106,8 @@ int bbb_ber_sweep_multi(bbb_lutopt *const *handles, int ndev, const bbb_trial_cf
     int rc = rehearsal ? BBB_OK : get_comms(devs, &comms);
     if (rc) return rc;
     const size_t nwords = 2 * (size_t)ncfg;
-    std::vector<std::vector<unsigned long long>> host((size_t)ndev, std::vector<unsigned long long>(nwords));
-    // one host thread per device launches that device's share of the trials (csrc/sweep_threads.hpp: the same orchestration is
-    // built for the host under ThreadSanitizer with a stub launch, tests/san_sweep.cpp)
+    // one host thread per device launches that device's share of the trials (csrc/sweep_threads.hpp: persistent workers, rank 0 on
+    // this thread; the same orchestration is built for the host under ThreadSanitizer with a stub launch, tests/san_sweep.cpp)
     {
         std::string err;
         int bad = 0;
@@ -1996,14 +2115,9 @@ int bbb_ber_sweep_multi(bbb_lutopt *const *handles, int ndev, const bbb_trial_cf
             bbb_lutopt *h = handles[r];
             auto body = [&]() -> int {
                 BBB_HIP(hipSetDevice(h->device));
-                if (h->counters_cap < nwords) {
-                    if (h->d_counters) BBB_HIP(hipFree(h->d_counters));
-                    h->d_counters = nullptr;
-                    h->counters_cap = 0;
-                    BBB_HIP(hipMalloc((void **)&h->d_counters, nwords * sizeof(unsigned long long)));
-                    h->counters_cap = nwords;
-                }
-                BBB_HIP(hipMemsetAsync(h->d_counters, 0, nwords * sizeof(unsigned long long), h->stream));
+                int e = ensure_counters(h, nwords);
+                if (e) return e;
+                if ((e = take_clean_counters(h, nwords))) return e;
                 return ber_run(h, mine, ncfg, h->d_counters);
             };
             const int e = body();
@@ -2039,15 +2153,17 @@ int bbb_ber_sweep_multi(bbb_lutopt *const *handles, int ndev, const bbb_trial_cf
         g_multi_info.n_devices = ndev;
         g_multi_info.n_ranks_seen = 0;         // rehearsal: no communicator
     }
+    // ONE pinned read-back per device, the zeroing for the next call queued behind it, one synchronisation per device
     for (int r = 0; r < ndev; r++) {
         BBB_HIP(hipSetDevice(handles[r]->device));
-        BBB_HIP(hipMemcpyAsync(host[(size_t)r].data(), handles[r]->d_counters, nwords * sizeof(unsigned long long),
-                               hipMemcpyDeviceToHost, handles[r]->stream));
+        if ((rc = read_back_counters(handles[r], nwords))) return rc;
     }
     for (int r = 0; r < ndev; r++) {
         BBB_HIP(hipSetDevice(handles[r]->device));
         BBB_HIP(hipStreamSynchronize(handles[r]->stream));
     }
+    std::vector<std::vector<unsigned long long>> host((size_t)ndev);
+    for (int r = 0; r < ndev; r++) host[(size_t)r].assign(handles[r]->h_counters, handles[r]->h_counters + nwords);
     if (rehearsal) {                  // the sum the collective would have left on every device
         for (int r = 1; r < ndev; r++)
             for (size_t i = 0; i < nwords; i++) host[0][i] += host[(size_t)r][i];

@@ -125,8 +125,12 @@ ber256_fused_kernel(BerMasks mk, uint32_t *__restrict planes, uint32_t *__restri
     // the same, pinned between the scans around it: `dep` (a value the NEXT scan reads) passes through the statement, `after` (the
     // counter the PREVIOUS scan wrote) is an input -- hipcc otherwise lets the load sink to just in front of its wait
 #define BBB_SLOAD8_AT(w, c, after, dep) asm volatile("s_load_dwordx8 %0, %2, %3" : "=&s"(w), "+v"(dep) : "s"(mp), "n"((c) * 128), "v"(after))
-#define BBB_SWAIT(w) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(w))
-#define BBB_SWAIT_AFTER(w, after) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(w) : "v"(after))      // not before `after` is computed
+    // a wait names EVERY window with a load in flight as "+s": whatever reads a window afterwards -- the scans' V_BITOP3 are
+    // ordinary code hipcc is free to move -- depends on the wait's output and cannot be hoisted above it (nor can a copy or a
+    // spill of the window be placed in front of it)
+#define BBB_SWAIT2(wa, wb) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(wa), "+s"(wb))
+#define BBB_SWAIT2_AFTER(wa, wb, after) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(wa), "+s"(wb) : "v"(after))      // not before `after` is computed
+#define BBB_SWAIT_AFTER(w, after) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(w) : "v"(after))
     auto prefetch = [&]() {
         if constexpr (MODE == kBerFast && NC > kRes) BBB_SLOAD8(w0, kRes);
         if constexpr (MODE == kBerFast && NC > kRes + 1) BBB_SLOAD8(w1, kRes + 1);
@@ -149,25 +153,25 @@ ber256_fused_kernel(BerMasks mk, uint32_t *__restrict planes, uint32_t *__restri
                 nerr[c] += __builtin_popcount(ge);
             };
             if constexpr (NC > kRes) {
-                BBB_SWAIT(w0);
+                if constexpr (NC > kRes + 1) BBB_SWAIT2(w0, w1); else BBB_SWAIT_AFTER(w0, valid);
                 scan(kRes, w0);
                 if constexpr (NC > kRes + 2) BBB_SLOAD8_AT(w0, kRes + 2, nerr[kRes], X[0]);
             }
             if constexpr (NC > kRes + 1) {
-                if constexpr (NC > kRes + 2) asm volatile("" : "+s"(w1));       // (already landed: the wait above was for all)
-                scan(kRes + 1, w1);
+                scan(kRes + 1, w1);                     // (landed: the wait above named both windows)
                 if constexpr (NC > kRes + 3) BBB_SLOAD8_AT(w1, kRes + 3, nerr[kRes + 1], X[0]);
             }
 #pragma unroll
             for (int c = 0; c < kRes; c++) scan(c, tmr[c]);
             if constexpr (NC > kRes + 2) {
-                BBB_SWAIT_AFTER(w0, nerr[kRes - 1]);
+                if constexpr (NC > kRes + 3) BBB_SWAIT2_AFTER(w0, w1, nerr[kRes - 1]);     // (w1: setting kRes + 3's load, issued behind scan kRes + 1)
+                else BBB_SWAIT_AFTER(w0, nerr[kRes - 1]);
                 scan(kRes + 2, w0);
                 if constexpr (NC > kRes + 4) BBB_SLOAD8_AT(w0, kRes + 4, nerr[kRes + 2], X[0]);
             }
-            if constexpr (NC > kRes + 3) scan(kRes + 3, w1);
+            if constexpr (NC > kRes + 3) scan(kRes + 3, w1);     // (landed and pinned by the two-window wait above)
             if constexpr (NC > kRes + 4) {
-                BBB_SWAIT_AFTER(w0, nerr[kRes + 3]);
+                BBB_SWAIT_AFTER(w0, nerr[kRes + 3]);          // (the only load in flight here is w0's)
                 scan(kRes + 4, w0);
             }
             static_assert(NC <= kRes + 5, "two windows serve five streamed settings");
@@ -231,7 +235,8 @@ ber256_fused_kernel(BerMasks mk, uint32_t *__restrict planes, uint32_t *__restri
     BBB_BER_STAMP(2);
 #undef BBB_SLOAD8
 #undef BBB_SLOAD8_AT
-#undef BBB_SWAIT
+#undef BBB_SWAIT2
+#undef BBB_SWAIT2_AFTER
 #undef BBB_SWAIT_AFTER
 #pragma unroll
     for (int c = 0; c < NC; c++) {

@@ -11,8 +11,12 @@ namespace bbb {
 // -1 bad arguments / mode, -2 first_bit + nbits overflows.
 inline int sweep_shard(const bbb_trial_cfg *cfgs, int ncfg, int ndev, int rank, int mode, bbb_trial_cfg *mine) {
     if (ncfg < 0 || (ncfg && (!cfgs || !mine)) || ndev < 1 || rank < 0 || rank >= ndev) return -1;
+    int group = -1;                                   // BBB_SHARD_GROUPS: index of the run of same-stream trials trial i lies in
     for (int i = 0; i < ncfg; i++) {
         bbb_trial_cfg c = cfgs[i];
+        if (i == 0 || cfgs[i].prbs_k != cfgs[i - 1].prbs_k || cfgs[i].prbs_state != cfgs[i - 1].prbs_state ||
+            cfgs[i].warmup != cfgs[i - 1].warmup || cfgs[i].first_bit != cfgs[i - 1].first_bit || cfgs[i].nbits != cfgs[i - 1].nbits)
+            group++;
         switch (mode) {
         case BBB_SHARD_TRIALS:                        // trial i belongs to rank i % ndev
             if (i % ndev != rank) c.nbits = 0;
@@ -28,6 +32,9 @@ inline int sweep_shard(const bbb_trial_cfg *cfgs, int ncfg, int ndev, int rank, 
             c.nbits = hi - lo;
             break;
         }
+        case BBB_SHARD_GROUPS:                        // a run of trials on one noise / PRBS stream stays on one rank
+            if (group % ndev != rank) c.nbits = 0;
+            break;
         default:
             return -1;
         }

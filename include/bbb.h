@@ -317,10 +317,17 @@ int bbb_ber_run_close(bbb_ber_run *r);
  *                     (seeds): the points x seeds form, N times the bits per point in the time of one sweep;
  *   BBB_SHARD_BITS    every rank runs every trial over ITS slice of the trial's bit range
  *                     [first_bit + r nbits / ndev, first_bit + (r+1) nbits / ndev) -- same reset state on all
- *                     handles; the totals equal the single-device counters of the same trials exactly. */
+ *                     handles; the totals equal the single-device counters of the same trials exactly;
+ *   BBB_SHARD_GROUPS  consecutive trials that read the same noise and PRBS streams (same prbs_k, prbs_state, warmup,
+ *                     first_bit, nbits: an Eb/N0 sweep on one seed) stay together -- group q runs on rank q % ndev, in one
+ *                     pass over its streams as on one device.  The form of BASELINE configs[4]: 11 points x 8 seeds given
+ *                     as 8 groups of 11 trials (the seeds as stretches of the one cycle: warmup = 16 + (s << 48)) is one
+ *                     11-point sweep per device on eight devices and eight sweeps back to back on one; the totals do not
+ *                     depend on ndev. */
 #define BBB_SHARD_TRIALS 0
 #define BBB_SHARD_SEEDS 1
 #define BBB_SHARD_BITS 2
+#define BBB_SHARD_GROUPS 3
 int bbb_ber_sweep_multi(bbb_lutopt *const *handles, int ndev, const bbb_trial_cfg *cfgs, int ncfg, int mode,
                         bbb_ber *out);
 /* The share of `rank` among `ndev`: mine[i] is trial i as that rank runs it (nbits = 0: not at all). */

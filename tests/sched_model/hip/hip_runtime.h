@@ -42,6 +42,7 @@ hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t s);
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned flags);
 hipError_t hipStreamDestroy(hipStream_t s);
 hipError_t hipStreamSynchronize(hipStream_t s);
+hipError_t hipStreamQuery(hipStream_t s);
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags);
 hipError_t hipEventCreate(hipEvent_t *e);
 hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned flags);

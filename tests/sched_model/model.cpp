@@ -21,7 +21,7 @@
 #include "../../basebandboard_amd/csrc/bbb_common.hpp"
 #include "../../basebandboard_amd/csrc/awgn_launch.hpp"
 
-struct MockStream { int id; model::VC vc; };
+struct MockStream { int id; model::VC vc; bool destroyed = false; };
 struct MockEvent { bool recorded = false; model::VC vc; };
 
 namespace model {
@@ -49,6 +49,16 @@ static MockStream *stream_of(hipStream_t s) {
     return g_streams[0];
 }
 
+static void error(const std::string &what);
+// Stream LIFETIMES (round 5; the round-4 crash was a cache that remembered a hipStream_t and synchronised with it after its
+// owner had destroyed it -- ordering alone cannot see that): hipStreamDestroy poisons the handle, and every later use of it
+// -- a launch, a record, a wait, a synchronisation, a query -- is reported.  (The object itself is kept: the report must not crash.)
+static MockStream *live_stream(hipStream_t s, const char *call) {
+    MockStream *m = stream_of(s);
+    if (m->destroyed) error(std::string(call) + " on stream " + std::to_string(m->id) + ", which was destroyed (use after hipStreamDestroy)");
+    return m;
+}
+
 static Buffer *buffer_of(const void *p) {
     if (!p) return nullptr;
     auto it = g_buffers.upper_bound((char *)p);
@@ -72,7 +82,7 @@ static std::string describe(const Buffer &b) { return "buffer #" + std::to_strin
 // one operation on a stream
 void op(hipStream_t hs, const std::string &what, std::initializer_list<const void *> reads, std::initializer_list<const void *> writes) {
     std::lock_guard<std::mutex> g(g_mu);
-    MockStream *s = stream_of(hs);
+    MockStream *s = live_stream(hs, what.c_str());
     join(s->vc, g_host);                                         // issued by the host now: after everything it has waited for
     if (s->vc.size() <= (size_t)s->id) s->vc.resize((size_t)s->id + 1, 0);
     s->vc[(size_t)s->id]++;
@@ -216,17 +226,42 @@ hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) {
     *s = m;
     return hipSuccess;
 }
-hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }      // (kept: a destroyed stream's work still completes)
+hipError_t hipStreamDestroy(hipStream_t s) {                          // (the object is kept: a destroyed stream's work still completes)
+    std::lock_guard<std::mutex> g(g_mu);
+    if (!s) { error("hipStreamDestroy of the null stream"); return hipErrorInvalidValue; }
+    MockStream *m = live_stream(s, "hipStreamDestroy");
+    m->destroyed = true;
+    g_trace.push_back("-- hipStreamDestroy(stream " + std::to_string(m->id) + ")");
+    return hipSuccess;
+}
+// hipStreamQuery: hipSuccess means the host has SEEN everything on the stream complete (it is then synchronised with it);
+// work the host has not waited for may or may not be done -- the model answers either way, so that both branches of a caller
+// that asks are explored
+static uint64_t g_coin = 0x9E3779B97F4A7C15ull;
+hipError_t hipStreamQuery(hipStream_t s) {
+    std::lock_guard<std::mutex> g(g_mu);
+    MockStream *m = live_stream(s, "hipStreamQuery");
+    bool pending = false;
+    for (size_t i = 0; i < m->vc.size(); i++)
+        if (m->vc[i] > (i < g_host.size() ? g_host[i] : 0u)) pending = true;
+    if (pending) {
+        g_coin ^= g_coin << 13; g_coin ^= g_coin >> 7; g_coin ^= g_coin << 17;
+        if (g_coin & 1) { g_trace.push_back("-- hipStreamQuery(stream " + std::to_string(m->id) + "): not ready"); return hipErrorNotReady; }
+        join(g_host, m->vc);
+    }
+    g_trace.push_back("-- hipStreamQuery(stream " + std::to_string(m->id) + "): done");
+    return hipSuccess;
+}
 hipError_t hipStreamSynchronize(hipStream_t s) {
     std::lock_guard<std::mutex> g(g_mu);
-    MockStream *m = stream_of(s);
+    MockStream *m = live_stream(s, "hipStreamSynchronize");
     join(g_host, m->vc);
     g_trace.push_back("-- hipStreamSynchronize(stream " + std::to_string(m->id) + ")");
     return hipSuccess;
 }
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) {
     std::lock_guard<std::mutex> g(g_mu);
-    MockStream *m = stream_of(s);
+    MockStream *m = live_stream(s, "hipStreamWaitEvent");
     if (e && e->recorded) join(m->vc, e->vc);
     g_trace.push_back("-- stream " + std::to_string(m->id) + " waits for event " + std::to_string((uintptr_t)e & 0xffff) + (e && e->recorded ? "" : " (never recorded: no wait)"));
     return hipSuccess;
@@ -236,7 +271,7 @@ hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = new MockEvent
 hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) {
     std::lock_guard<std::mutex> g(g_mu);
-    MockStream *m = stream_of(s);
+    MockStream *m = live_stream(s, "hipEventRecord");
     join(m->vc, g_host);
     e->recorded = true;
     e->vc = m->vc;
@@ -271,9 +306,21 @@ int awgn_seed_launch(int, const uint32_t *d_tabs, const uint32_t *, uint64_t, ui
     op(st, "bitslice", {d_states}, {d_planes});
     return BBB_OK;
 }
+int awgn_seed_head_launch(int, const uint32_t *d_tabs, const uint32_t *, uint64_t, uint32_t *d_states, hipStream_t st) {
+    op(st, "seed_head_kernel", {d_tabs}, {d_states});
+    return BBB_OK;
+}
+int awgn_seed_tail_planes_launch(int, const uint32_t *d_top, uint64_t, const uint32_t *d_states, unsigned, uint32_t *d_planes, hipStream_t st) {
+    op(st, "seed_tail_planes_kernel", {d_top, d_states}, {d_planes});
+    return BBB_OK;
+}
 int prbs_seed_planes_launch(int, const uint32_t *d_tabs, const uint32_t *, uint64_t, uint32_t *d_states, unsigned, uint32_t *d_planes, hipStream_t st) {
     op(st, "PRBS seeding", {d_tabs}, {d_states});
     op(st, "PRBS bitslice", {d_states}, {d_planes});
+    return BBB_OK;
+}
+int prbs_seed_lanes_launch(int, const uint32_t *d_tabs, const uint32_t *, const uint32_t *, uint64_t, unsigned, uint32_t *d_planes, hipStream_t st) {
+    op(st, "PRBS seeding (one state per lane + Q steps)", {d_tabs}, {d_planes});
     return BBB_OK;
 }
 int awgn512p_fill_launch(const uint32_t *d_planes, int16_t *dst, uint64_t, unsigned, uint64_t, unsigned, hipStream_t st) {

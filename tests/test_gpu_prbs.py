@@ -140,14 +140,27 @@ def test_prbs31_beyond_2_pow_35_bits(gpu, oracle):
     torch.cuda.empty_cache()
 
 
-def test_baseline_config3_full_size_with_error_mask(gpu):
+def test_baseline_config3_full_size_with_error_mask(gpu, oracle):
     """BASELINE.json configs[2] at its full size: 1e10 bits of PRBS-31 through generator -> checker, clean and
     with a fixed XOR mask on every (1e6+7)-th bit: exact counts from the phase-known
-    checker AND from the self-synchronising detector (isolated errors: each flagged exactly once)."""
+    checker AND from the self-synchronising detector (isolated errors: each flagged exactly once).
+    The generator's whole 1.25 GB output is first held to the ORACLE's sequential stream (prbs.py:32-35, 112-113 restated
+    word-parallel: one core, under a second), so the loopback is not only the device agreeing with itself; the
+    read-back form of the fill (the one the timed loopback uses) against the same words."""
     nbits = 10_000_000_000
     p = gpu.PRBS(31)
     det = gpu.PRBSErrorDetector(31)
     buf2 = p.generate(nbits)
+    exp, s_end = oracle.prbs_packed(31, nbits, fast=True)
+    exp_t = torch.from_numpy(exp.view(np.int64))
+    assert buf2.numel() == exp_t.numel() == (nbits + 63) // 64
+    piece = 1 << 24                                            # 128 MiB of words at a time on the host
+    for lo in range(0, buf2.numel(), piece):
+        assert torch.equal(buf2[lo: lo + piece].cpu(), exp_t[lo: lo + piece]), f"PRBS-31 fill differs from the oracle in words [{lo}, {lo + piece})"
+    assert s_end == p.state_at(nbits)                         # and the LFSR state behind the last bit (the host's jump-ahead)
+    hinted = p.generate(nbits, will_read_back=True)
+    assert torch.equal(hinted, buf2)
+    del hinted, exp, exp_t
     assert det.count_errors(buf2, nbits) == 0
     pos = torch.arange(0, nbits, 1_000_007, dtype=torch.int64, device=buf2.device)
     flip = torch.zeros_like(buf2)

@@ -131,6 +131,13 @@ def test_found_k256_matrix_runs_ber_trials_and_tx(gpu, oracle, tmp_path):
     got = bbb.run_trials(u, t)
     assert got == [m.ber_trial(0xABCDEF, x.prbs_k, 1, x.amp, x.noise_var, 16, 0, x.nbits) for x in t]
     assert np.array_equal(bbb.CLTGRNG(u).generate(100_000, first_step=16).cpu().numpy(), m.awgn(0xABCDEF, 16, 100_000))
+    # full groups: the run-time library holds the short instance list (Fast<12> serves 5 ... 12 settings), i.e. the kernel
+    # with seven resident settings and FIVE streamed through the two scalar-load windows, around a network the shipped
+    # library's tests never see.  Twelve, eleven and five settings on one stream, against the oracle.
+    amps = (91, 102, 114, 128, 143, 161, 181, 203, 228, 255, 287, 322)
+    for n in (12, 11, 5):
+        grp = [bbb.Trial(nbits=300_007, amp=a, noise_var=8, prbs_k=31) for a in amps[:n]]
+        assert bbb.run_trials(u, grp) == [m.ber_trial(0xABCDEF, 31, 1, x.amp, 8, 16, 0, x.nbits) for x in grp], n
 
 
 def test_cli_search_writes_the_reference_format_and_the_file_loads(gpu, oracle, tmp_path):
