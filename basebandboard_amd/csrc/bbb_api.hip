@@ -484,12 +484,10 @@ int queue_mover_with(bbb_lutopt *h, int slot, LaunchMover launch_mover) {
     }
     BBB_HIP(hipStreamWaitEvent(ms, h->stage_arith[slot], 0));
     // stage_free[slot] stands for ALL movers that read the slot: the caller may have re-bound the handle to another stream since
-    // the slot's previous mover, so that one is chained in front of this call's record (same stream: already in its past)
-    // (BBB_SCHED_MODEL_REVERT_MOVER_CHAIN: without it -- defined only by tests/test_sched_model.py, whose model must then find a
-    // sample kernel overwriting a slot that a mover on the caller's OTHER stream still reads)
-#ifndef BBB_SCHED_MODEL_REVERT_MOVER_CHAIN
+    // the slot's previous mover, so that one is chained in front of this call's record (same stream: already in its past).
+    // (tests/test_sched_model.py takes this line out of a COPY of this file -- mutant "mover_chain" -- and requires the model to find
+    // a sample kernel overwriting a slot that a mover on the caller's OTHER stream still reads)
     if (h->stage_busy[slot]) BBB_HIP(hipStreamWaitEvent(ms, h->stage_free[slot], 0));
-#endif
     hipEvent_t m0 = nullptr, m1 = nullptr;
     if (h->profiling) {
         BBB_HIP(hipEventCreate(&m0)); BBB_HIP(hipEventCreate(&m1));
@@ -534,12 +532,8 @@ int produce_planes(bbb_lutopt *h, uint64_t L, unsigned nlanes, bbb_lutopt::ProfE
     }
     // (the skip holds only while no LATER mover was queued on the slot: a prefetch stays valid across fills that do not
     // match it, and those may have put new movers on this very slot since its seeding waited)
-    // (BBB_SCHED_MODEL_REVERT_STALE_SKIP: without the generation check -- the round-2 advisor's case; tests/test_sched_model.py only)
-#ifndef BBB_SCHED_MODEL_REVERT_STALE_SKIP
+    // (the round-2 advisor's case; tests/test_sched_model.py's mutant "stale_skip" drops the generation check from a copy of this file)
     const bool seeding_saw_last_mover = planes_seeded_after_mover && h->pf_waited_slot == slot && h->pf_waited_gen == h->stage_gen[slot];
-#else
-    const bool seeding_saw_last_mover = planes_seeded_after_mover && h->pf_waited_slot == slot;
-#endif
     if (planes_seeded_after_mover) h->pf_waited_slot = -1;          // consumed
     if (h->stage_busy[slot] && !seeding_saw_last_mover)
         BBB_HIP(hipStreamWaitEvent(h->cs, h->stage_free[slot], 0));   // its last mover has read it
@@ -1140,14 +1134,10 @@ static int seed_announced(bbb_lutopt *h, uint64_t first_step, uint64_t L, uint64
     // An announcement that was never taken leaves its seeding behind -- queued on the arithmetic stream of the fill it expected,
     // which need not be the one this seeding goes to: without this wait the two would write the same buffers side by side
     // (the soak test's case: a hint whose fill came with another partition, then the next hint).
-    // (BBB_SCHED_MODEL_REVERT_UNTAKEN_HINT: the scheduler as it stood BEFORE this wait existed -- defined only by
-    // tests/test_sched_model.py, which must see the model of tests/sched_model/ find that race)
-#ifndef BBB_SCHED_MODEL_REVERT_UNTAKEN_HINT
+    // (tests/test_sched_model.py's mutant "untaken_hint" is a copy of this file as it stood BEFORE this wait existed: the model of
+    // tests/sched_model/ must find that race)
     if (pf.seeded) BBB_HIP(hipStreamWaitEvent(side, pf.seeded, 0));
     else BBB_HIP(hipEventCreateWithFlags(&pf.seeded, hipEventDisableTiming));
-#else
-    if (!pf.seeded) BBB_HIP(hipEventCreateWithFlags(&pf.seeded, hipEventDisableTiming));
-#endif
     // the buffers may still be read by the sample kernel that used them last (main stream)
     if (pf.read_pending) BBB_HIP(hipStreamWaitEvent(side, pf.last_read, 0));
     if (pf.states_cap < (size_t)G * h->W32 || pf.planes_cap < (size_t)2 * h->k * nlanes) {

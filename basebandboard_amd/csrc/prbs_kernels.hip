@@ -84,167 +84,6 @@ int prbs_state_at_host(int k, uint64_t init_state, uint64_t nbits, uint64_t *sta
 }
 
 // ---------------------------------------------------------------------------------------------
-// Region seeds (round 4; compiled into the EXPERIMENTS build only -- see PrbsSeedPlan below for why the shipped library does
-// not use them).  Every wave of the generator and of the checker opens with the same private bootstrap: jump
-// the LFSR state to its region (up to 64 dependent mat-vecs over four fetches of the power table), form K words bit by bit,
-// then grow them to K rows -- 15-20 us in which the kernel moves no data, twice per loopback (7 % of it).  The first two steps
-// depend on nothing but (k, init, first_bit, the partition): seed r = the K words that start K rows in front of region r.
-// They are computed ONCE by prbs_seed_kernel and kept (a small per-device cache keyed on those parameters, like an FFT
-// plan); the generator's wave r starts from seed r, and the reverse checker's wave r from seed r + 1 -- the K rows in front
-// of region r + 1 ARE the last K rows of region r, the first window the descending pass needs.  What is left per wave is the
-// growth in LDS (~3 us).
-// ---------------------------------------------------------------------------------------------
-template <int K>
-__device__ __forceinline__ uint32_t lfsr_matvec(const uint32_t *__restrict rows, uint32_t s);      // (below)
-
-template <int K>
-__global__ void __launch_bounds__(64)
-prbs_seed_kernel(int ki, u64 init_state, u64 first_bit, u64 nseeds, u64 rows_per_wave, u64 *__restrict seeds) {
-    constexpr int TAP = tap_of(K);
-    constexpr int RW = 64;
-    constexpr uint32_t SMASK = (uint32_t)((1ull << K) - 1ull);
-    const int lane = threadIdx.x;
-    const u64 r = blockIdx.x;
-    if (r >= nseeds) return;
-    const PrbsPowTable &pw = d_prbs_pow[ki];
-    constexpr u64 PERIOD = (1ull << K) - 1ull;
-    constexpr u64 BACK = (u64)K * RW * 64;                       // bits in K rows
-    constexpr u64 WRAP = ((BACK + PERIOD - 1) / PERIOD) * PERIOD;  // multiple of the period >= BACK
-    const u64 word0 = r * rows_per_wave * RW;
-    const u64 t0 = (first_bit % PERIOD) + ((word0 % PERIOD) * 64) % PERIOD + (WRAP - BACK);
-    uint32_t s = (uint32_t)init_state;
-#pragma unroll 1
-    for (int i0 = 0; i0 < 64; i0 += 16) {
-        if (((t0 >> i0) & 0xffffull) == 0) continue;
-        uint32_t myrow[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++) myrow[i] = pw.rows[i0 + i][lane & 31];
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            if ((t0 >> (i0 + i)) & 1) s = (uint32_t)__ballot(lane < K && (__builtin_popcount(myrow[i] & s) & 1));
-        }
-    }
-    if (lane < K) {
-        uint32_t si = s;
-#pragma unroll
-        for (int m = 0; m < 5; m++) {
-            const uint32_t sj = lfsr_matvec<K>(pw.rows[6 + m], si);
-            si = ((lane >> m) & 1) ? sj : si;
-        }
-        u64 w = 0;
-        for (int j = 0; j < 64; j++) {
-            const uint32_t bit = ((si >> (K - 1)) ^ (si >> (TAP - 1))) & 1u;
-            si = ((si << 1) | bit) & SMASK;
-            w |= (u64)bit << j;
-        }
-        seeds[r * 32 + (u64)lane] = w;
-    }
-}
-
-#ifdef BBB_EXPERIMENTS
-// NOT USED by the shipped library (BBB_PRBS_SEEDS defaults to 0; every wave derives its own start rows, as in rounds 1-3).
-// Round 4 first shipped it with the plan remembering the STREAM of its last use (no events): 7 us of a 0.43 ms loopback gained.
-// Made safe -- an event behind the seed kernel, one behind every reader, a lease over the cache while a reader is queued -- the
-// event packets on the caller's stream cost what the shared seeds save: loopback 0.4346-0.4364 ms with, 0.4321-0.4323 without
-// (same box, alternating: experiments/prbs_loopback2.py with BBB_PRBS_SEEDS=1 / 0).  Kept for that A/B.
-struct PrbsSeedPlan {
-    int dev = -1, k = 0;
-    u64 init = 0, first_bit = 0, rpw = 0, nseeds = 0;
-    u64 *d = nullptr;
-    size_t cap = 0;
-    // ready: behind the seed kernel; used: behind the last kernel that reads the seeds.  Events, not the streams they were
-    // recorded on: a caller's stream (a handle's internal one, a torch stream) may be destroyed while the plan lives on --
-    // synchronising with a remembered stream handle then is a use after free (the full GPU suite of round 4 crashed there).
-    hipEvent_t ready = nullptr, used = nullptr;
-    bool has_used = false;
-    u64 stamp = 0;
-};
-static std::mutex g_seed_mu;
-static PrbsSeedPlan g_seed_plans[8];
-static u64 g_seed_clock = 0;
-
-// A plan handed to one caller: the cache stays locked until the caller has queued the kernel that reads the seeds and said so
-// (`queued`), so that no other thread re-targets or frees the buffer in between (bbb_ber_sweep_multi runs a host thread per device).
-struct PrbsSeedLease {
-    std::unique_lock<std::mutex> lock;
-    PrbsSeedPlan *plan = nullptr;
-    const u64 *seeds() const { return plan ? plan->d : nullptr; }
-    int queued(hipStream_t st) {
-        if (!plan) return BBB_OK;
-        PrbsSeedPlan *p = plan;
-        plan = nullptr;
-        // (`used` stands for ALL readers so far: an earlier one on another stream is chained in front of this record)
-        hipError_t e = p->has_used ? hipStreamWaitEvent(st, p->used, 0) : hipSuccess;
-        if (e == hipSuccess) e = hipEventRecord(p->used, st);
-        p->has_used = p->has_used || e == hipSuccess;
-        lock.unlock();
-        BBB_HIP(e);
-        return BBB_OK;
-    }
-};
-
-// seeds[r * 32 + i], r < nseeds: ready on `st` when this returns (computed there if no plan matched)
-static int prbs_region_seeds(int k, int ki, u64 init_state, u64 first_bit, u64 rpw, u64 nseeds, hipStream_t st, PrbsSeedLease *lease) {
-    int dev = 0;
-    BBB_HIP(hipGetDevice(&dev));
-    lease->lock = std::unique_lock<std::mutex>(g_seed_mu);
-    lease->plan = nullptr;
-    PrbsSeedPlan *victim = &g_seed_plans[0];
-    for (PrbsSeedPlan &p : g_seed_plans) {
-        if (p.d && p.dev == dev && p.k == k && p.init == init_state && p.first_bit == first_bit && p.rpw == rpw && p.nseeds >= nseeds) {
-            BBB_HIP(hipStreamWaitEvent(st, p.ready, 0));          // (a plan computed on another stream)
-            p.stamp = ++g_seed_clock;
-            lease->plan = &p;
-            return BBB_OK;
-        }
-        if (p.stamp < victim->stamp) victim = &p;
-    }
-    PrbsSeedPlan &p = *victim;
-    if (p.d && p.dev != dev) {                      // another device's buffer: release it there (hipFree waits for its readers)
-        (void)hipSetDevice(p.dev);
-        if (p.has_used) (void)hipEventSynchronize(p.used);
-        (void)hipFree(p.d); (void)hipEventDestroy(p.ready); (void)hipEventDestroy(p.used);
-        (void)hipSetDevice(dev);
-        p = PrbsSeedPlan();
-    }
-    if (!p.ready) {
-        BBB_HIP(hipEventCreateWithFlags(&p.ready, hipEventDisableTiming));
-        BBB_HIP(hipEventCreateWithFlags(&p.used, hipEventDisableTiming));
-    }
-    const size_t need = (size_t)nseeds * 32 * sizeof(u64);
-    if (p.cap < need) {
-        if (p.d) {
-            if (p.has_used) BBB_HIP(hipEventSynchronize(p.used));
-            BBB_HIP(hipFree(p.d));
-        }
-        p.d = nullptr; p.cap = 0; p.has_used = false;
-        BBB_HIP(hipMalloc((void **)&p.d, need));
-        p.cap = need;
-    }
-    if (p.has_used) BBB_HIP(hipStreamWaitEvent(st, p.used, 0));          // the buffer's last reader may still run
-    p.dev = dev; p.k = k; p.init = init_state; p.first_bit = first_bit; p.rpw = rpw; p.nseeds = nseeds; p.stamp = ++g_seed_clock;
-#define BBB_PRBS_CASE(KK) case KK: hipLaunchKernelGGL(prbs_seed_kernel<KK>, dim3((unsigned)nseeds), dim3(64), 0, st, ki, init_state, first_bit, nseeds, rpw, p.d); break;
-    switch (k) {
-        BBB_PRBS_CASE(7) BBB_PRBS_CASE(9) BBB_PRBS_CASE(11) BBB_PRBS_CASE(15)
-        BBB_PRBS_CASE(20) BBB_PRBS_CASE(23) BBB_PRBS_CASE(31)
-    }
-#undef BBB_PRBS_CASE
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipEventRecord(p.ready, st);
-    if (e != hipSuccess) { p.nseeds = 0; p.k = 0; BBB_HIP(e); }          // (never matched again)
-    lease->plan = &p;
-    return BBB_OK;
-}
-#else
-// (the shipped library has no seed plans: every wave derives its own start rows)
-struct PrbsSeedLease {
-    const u64 *seeds() const { return nullptr; }
-    int queued(hipStream_t) { return BBB_OK; }
-};
-static int prbs_region_seeds(int, int, u64, u64, u64, u64, hipStream_t, PrbsSeedLease *) { return BBB_OK; }
-#endif
-
-// ---------------------------------------------------------------------------------------------
 // Streaming generator / checker.  One wave per block; block b owns rows [b*rpw, (b+1)*rpw).
 // A row is RW = 64*WPL words; lane l owns words WPL*l .. WPL*l+WPL-1 of every row (8- or 16-byte
 // accesses).  Row lag identity: row[q] = row[q-K] ^ row[q-TAP]  (bit lags K*RW*64, TAP*RW*64).
@@ -306,7 +145,7 @@ __device__ __forceinline__ void fill_store(T *p, const T &v) {
 template <int K, bool CHECK, int WPL, bool LW>
 __global__ void __launch_bounds__(64, 2)   // >= 2 waves per SIMD: at most 256 registers
 prbs_stream_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwords, u64 rows_per_wave,
-                   u64 *__restrict buf, u64 *__restrict nerr, int nt_stores, const u64 *__restrict seeds) {
+                   u64 *__restrict buf, u64 *__restrict nerr, int nt_stores) {
     typedef typename LaneWords<WPL>::type lw_t;
     constexpr int TAP = tap_of(K);
     constexpr int RW = 64 * WPL;                 // words per row
@@ -324,10 +163,7 @@ prbs_stream_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwords,
     //    sequence has period 2^K - 1 (maximal length), which extends it to negative positions.
     //    s = T^(t0) * init, lane r evaluating row r; the candidate rows of T^(2^i) are fetched 16 at
     //    a time (four memory round trips, not one per set bit).
-    if (seeds) {
-        // (steps 1 and 2 were done once for the whole partition: prbs_region_seeds)
-        if (lane < K) X[lane] = seeds[(u64)blockIdx.x * 32 + (u64)lane];
-    } else {
+    {
     constexpr u64 PERIOD = (1ull << K) - 1ull;
     constexpr u64 BACK = (u64)K * RW * 64;                       // bits in K rows
     constexpr u64 WRAP = ((BACK + PERIOD - 1) / PERIOD) * PERIOD;  // multiple of the period >= BACK
@@ -535,7 +371,7 @@ prbs_stream_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwords,
 template <int K>
 __global__ void __launch_bounds__(64, 2)
 prbs_check_rev_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwords, u64 rows_per_wave,
-                      const u64 *__restrict buf, u64 *__restrict nerr, const u64 *__restrict seeds) {
+                      const u64 *__restrict buf, u64 *__restrict nerr) {
     constexpr int TAP = tap_of(K);
     constexpr int RW = 64;
     constexpr int LEVELS = 6;
@@ -549,12 +385,7 @@ prbs_check_rev_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwor
     const u64 rows_total = (nwords - word0 + RW - 1) / RW;
     const long long nrows = (long long)(rows_total < rows_per_wave ? rows_total : rows_per_wave);
 
-    // A whole region with the partition's seeds at hand starts from seed r + 1: the K rows in FRONT of the next region are
-    // this region's last K rows -- the window after the first retreat, which is then skipped (prbs_region_seeds).
-    const bool seeded = seeds != nullptr && (u64)nrows == rows_per_wave;
-    if (seeded) {
-        if (lane < K) X[lane] = seeds[((u64)blockIdx.x + 1) * 32 + (u64)lane];
-    } else {
+    {
     // 1. LFSR state at the first bit of the K rows that FOLLOW this region
     constexpr u64 PERIOD = (1ull << K) - 1ull;
     const u64 wtop = word0 + (u64)nrows * RW;
@@ -615,14 +446,10 @@ prbs_check_rev_kernel(int ki, u64 init_state, u64 first_bit, u64 nbits, u64 nwor
     u64 errs = 0;
     constexpr int DB = 16;
     constexpr int NB = (K + DB - 1) / DB;
-    bool first_pass = seeded;
     for (long long q0 = nrows - K; q0 > -(long long)K; q0 -= K) {       // the pass covers rows [q0, q0 + K)
-        // retreat the window: V[i] = row q0 + i (a seeded wave's window starts there)
-        if (!first_pass) {
+        // retreat the window: V[i] = row q0 + i
 #pragma unroll
-            for (int i = K - 1; i >= 0; i--) xor_inplace(V[i], V[(i - TAP + K) % K]);
-        }
-        first_pass = false;
+        for (int i = K - 1; i >= 0; i--) xor_inplace(V[i], V[(i - TAP + K) % K]);
         if (q0 >= 0 && word0 + (u64)(q0 + K) * RW <= last_word) {
             const u64 *rowp = buf + (word0 + (u64)q0 * RW);
             u32x2 D[2][DB];
@@ -702,29 +529,17 @@ static int launch_check_rev(int k, int ki, u64 init_state, u64 first_bit, u64 nb
     const u64 nblocks = (rows + rpw - 1) / rpw;
     if (nblocks > 0x7fffffffull) return fail(BBB_EINVAL, "nbits too large");
     dim3 grid((unsigned)nblocks), block(64);
-    PrbsSeedLease lease;
-    static const int use_seeds = env_knob("BBB_PRBS_SEEDS", 0);          // (off: see PrbsSeedPlan; A/B timing, -DBBB_EXPERIMENTS only)
-    if (use_seeds) {
-        const int rcs = prbs_region_seeds(k, ki, init_state, first_bit, rpw, nblocks + 1, st, &lease);
-        if (rcs) return rcs;
-    }
-    const u64 *const seeds = lease.seeds();
 #define BBB_PRBS_CASE(KK)                                                                                          \
     case KK:                                                                                                       \
         hipLaunchKernelGGL((prbs_check_rev_kernel<KK>), grid, block, 0, st, ki, init_state, first_bit, nbits, nwords, \
-                           rpw, buf, nerr, seeds);                                                                 \
+                           rpw, buf, nerr);                                                                        \
         break;
     switch (k) {
         BBB_PRBS_CASE(7) BBB_PRBS_CASE(9) BBB_PRBS_CASE(11) BBB_PRBS_CASE(15)
         BBB_PRBS_CASE(20) BBB_PRBS_CASE(23) BBB_PRBS_CASE(31)
     }
 #undef BBB_PRBS_CASE
-    {
-        const hipError_t e = hipGetLastError();
-        const int rcq = lease.queued(st);
-        BBB_HIP(e);
-        if (rcq) return rcq;
-    }
+    BBB_HIP(hipGetLastError());
     return BBB_OK;
 }
 
@@ -774,29 +589,17 @@ static int launch_stream_w(int k, int ki, u64 init_state, u64 first_bit, u64 nbi
     const u64 nblocks = (rows + rpw - 1) / rpw;
     if (nblocks > 0x7fffffffull) return fail(BBB_EINVAL, "nbits too large");
     dim3 grid((unsigned)nblocks), block(64);
-    PrbsSeedLease lease;
-    static const int use_seeds = env_knob("BBB_PRBS_SEEDS", 0);          // (off: see PrbsSeedPlan; A/B timing, -DBBB_EXPERIMENTS only)
-    if (use_seeds && WPL == 1) {                    // (one more than the generator needs: the reverse checker of the same range shares the plan)
-        const int rcs = prbs_region_seeds(k, ki, init_state, first_bit, rpw, nblocks + 1, st, &lease);
-        if (rcs) return rcs;
-    }
-    const u64 *const seeds = lease.seeds();
 #define BBB_PRBS_CASE(KK)                                                                                       \
     case KK:                                                                                                    \
         hipLaunchKernelGGL((prbs_stream_kernel<KK, CHECK, WPL, LW>), grid, block, 0, st, ki, init_state, first_bit, \
-                           nbits, nwords, rpw, buf, nerr, nt_stores, seeds);                                    \
+                           nbits, nwords, rpw, buf, nerr, nt_stores);                                           \
         break;
     switch (k) {
         BBB_PRBS_CASE(7) BBB_PRBS_CASE(9) BBB_PRBS_CASE(11) BBB_PRBS_CASE(15)
         BBB_PRBS_CASE(20) BBB_PRBS_CASE(23) BBB_PRBS_CASE(31)
     }
 #undef BBB_PRBS_CASE
-    {
-        const hipError_t e = hipGetLastError();
-        const int rcq = lease.queued(st);
-        BBB_HIP(e);
-        if (rcq) return rcq;
-    }
+    BBB_HIP(hipGetLastError());
     return BBB_OK;
 }
 

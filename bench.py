@@ -409,7 +409,7 @@ def main():
     # committed summary of this round's passes and says which file it came from (stale if the kernels changed since)
     traffic = traffic_src = traffic_step = None
     pmc_rec = {}
-    for name in ("r04_awgn_pmc.json", "r03_awgn_pmc.json"):
+    for name in ("r05_awgn_pmc.json", "r04_awgn_pmc.json", "r03_awgn_pmc.json"):
         pmc = ROOT / "profiles" / name
         if pmc.exists() and staged:
             try:
@@ -633,36 +633,121 @@ def main():
             warm = [channel.Trial(nbits=t.nbits, amp=t.amp, noise_var=nv, first_bit=(wi + 1) << 20) for t in trials]
             channel.sweep_seeds(warm, channel.gpu_runner(us), world=world)
         torch.cuda.synchronize(); barrier()
-        tb0 = time.perf_counter()
-        total = channel.sweep_seeds(trials, channel.gpu_runner(us), world=world)
-        torch.cuda.synchronize(); barrier()
-        tber_isolated = time.perf_counter() - tb0
-        tot = total.cpu().tolist()
         # the same sweep sixteen times back to back (bbb_ber_trials_dev does not synchronise), every one at another stream
         # position, so every one derives its own start states: the library does that on internal streams while the kernel of
-        # the sweep before runs, and the host's work in front of a call's first launch (55 us) overlaps it too.  The first of
-        # the sixteen starts on an idle GPU (isolated_call_gbit_s is such a call alone).
+        # the sweep before runs, and the host's work in front of a call's first launch overlaps it too.  (These sixteen also
+        # are the clock ramp in front of the isolated calls below: the governor needs ~50 ms of load to leave its idle state.)
         nrep = 16
-        reps_t = [[channel.Trial(nbits=t.nbits, amp=t.amp, noise_var=nv, first_bit=(2 + i) << 21) for t in trials] for i in range(nrep)]
+        reps_t = [[channel.Trial(nbits=t.nbits, amp=t.amp, noise_var=nv, first_bit=(2 + i) << 21) for t in trials] for i in range(2 * nrep)]
+        runner = channel.gpu_runner(us)
+        for i in range(nrep):                       # (untimed: clocks)
+            channel.sweep_seeds(reps_t[nrep + i], runner, world=world)
         torch.cuda.synchronize(); barrier()
         tb0 = time.perf_counter()
-        runner = channel.gpu_runner(us)
         for i in range(nrep):
             channel.sweep_seeds(reps_t[i], runner, world=world)
         torch.cuda.synchronize(); barrier()
         tber = (time.perf_counter() - tb0) / nrep
+        # ONE isolated call (the GPU idle before and after, its seeding, zeroing and read-back inside): what configs[3] literally is,
+        # and every device's share of configs[4].  Through the C ABI's synchronous entry, bbb_ber_trials; five calls at five stream
+        # positions, each alone, the median reported (the first of them follows the sixteen above directly: hot clocks).
+        iso = []
+        for i in range(5):
+            ts_i = [channel.Trial(nbits=t.nbits, amp=t.amp, noise_var=nv, first_bit=(100 + i) << 21) for t in trials] if i else trials
+            torch.cuda.synchronize(); barrier()
+            tb0 = time.perf_counter()
+            got_i = channel.run_trials(us, ts_i)
+            iso.append(time.perf_counter() - tb0)
+            if i == 0:
+                tot_local = got_i
+        tber_isolated = sorted(iso)[len(iso) // 2]
+        total = torch.tensor([list(x) for x in tot_local], dtype=torch.int64, device=dev)
+        if world > 1:
+            if backend == "nccl":
+                dist.all_reduce(total, op=dist.ReduceOp.SUM)
+            else:
+                hc = total.cpu(); dist.all_reduce(hc, op=dist.ReduceOp.SUM); total.copy_(hc)
+        tot = total.cpu().tolist()
         extra["ber_sweep"] = {
             "points": [{"ebn0_db": round(channel.ebn0_db(t.amp, nv), 3), "ebn0_db_effective": round(channel.ebn0_db_effective(t.amp, nv), 3),
                         "amp": t.amp, "noise_var": nv, "bits": b_, "errors": e_, "ber": e_ / b_ if b_ else None,
                         "q_theory": channel.ber_theory(channel.ebn0_db(t.amp, nv)), "q_lattice": channel.ber_lattice(t.amp, nv)}
                        for t, (b_, e_) in zip(trials, tot)],
-            "gbit_s": round(sum(b_ for b_, _ in tot) / tber / 1e9, 2), "seconds": round(tber, 6),
-            "gbit_s_is": "per sweep over sixteen sweeps queued back to back, each at its own stream position with its own seeding (counters below: the first, isolated one)",
-            "isolated_call_gbit_s": round(sum(b_ for b_, _ in tot) / tber_isolated / 1e9, 2), "isolated_call_seconds": round(tber_isolated, 6),
+            # (round 3's meaning of gbit_s: ONE isolated call.  Round 4 reported the back-to-back figure under this key)
+            "gbit_s": round(11e9 / tber_isolated / 1e9, 2), "seconds": round(tber_isolated, 6),
+            "gbit_s_is": "ONE isolated bbb_ber_trials call per rank (11 points x 1e9 bits, one pass of the noise stream), its seeding, the zeroing of its counters, "
+                         "its read-back and the host's synchronisation inside; median of five calls at five stream positions, each alone on an idle "
+                         "(hot) GPU",
+            "isolated_call_gbit_s": round(11e9 / tber_isolated / 1e9, 2), "isolated_call_seconds": round(tber_isolated, 6),
+            "isolated_calls_ms": [round(x * 1e3, 4) for x in iso],
+            "back_to_back_gbit_s": round(11e9 / tber / 1e9, 2), "back_to_back_seconds": round(tber, 6),
+            "back_to_back_is": "per sweep over sixteen sweeps queued back to back (bbb_ber_trials_dev), each at its own stream position with its own seeding",
             "seeds": world, "seeding_in_timed_region": True,
             "labels": "ebn0_db = amp^2 / (2 (8 nv)^2), ignores that the sample is an integer; ebn0_db_effective / q_lattice account for "
                       "the integer decision threshold (channel.ber_lattice) and are the ones comparable with Q(sqrt(2 Eb/N0))",
             "reduce": "torch.distributed.all_reduce(int64[11,2], SUM) over RCCL, one seed per rank" if world > 1 else "single rank"}
+        # BASELINE configs[4] at its stated size: 11 points x 8 seeds = 88 trials, the seeds as stretches of the one cycle 2^48 apart
+        # (warmup = 16 + (s << 48)), eight groups of eleven.  N = 1: all of them on this device through the C ABI's multi-device entry
+        # (bbb_ber_sweep_multi, BBB_SHARD_GROUPS: eight sweeps back to back) -- the figure an N-GPU run of the SAME 88 trials is
+        # divided by.  N > 1 (one process per GPU): rank r runs groups r, r + N, ... and ONE all-reduce sums the counters.
+        from basebandboard_amd import _lib as _l2
+        from basebandboard_amd.channel import sweep_multi, multi_info
+        def trials88(pos):
+            return [channel.Trial(nbits=t.nbits, amp=t.amp, noise_var=nv, first_bit=pos << 21, warmup=WARM_STATE + (s_ << 48))
+                    for s_ in range(8) for t in trials]
+        c88 = torch.zeros((88, 2), dtype=torch.int64, device=dev)
+        def run88(pos):
+            ts88 = trials88(pos)
+            if world == 1:
+                return sweep_multi([u], ts88, mode=_l2.SHARD_GROUPS)
+            mine = channel.shard_trials(ts88, rank, world, _l2.SHARD_GROUPS)
+            c88.zero_()
+            channel.run_trials_into(u, mine, c88)
+            if backend == "nccl":
+                dist.all_reduce(c88, op=dist.ReduceOp.SUM)
+            else:
+                hc = c88.cpu(); dist.all_reduce(hc, op=dist.ReduceOp.SUM); c88.copy_(hc)
+            return [tuple(x) for x in c88.cpu().tolist()]
+        run88(200); run88(201)
+        t88 = []
+        for i in range(3):
+            torch.cuda.synchronize(); barrier()
+            tb0 = time.perf_counter()
+            got88 = run88(210 + i)
+            torch.cuda.synchronize(); barrier()
+            t88.append(time.perf_counter() - tb0)
+        t88m = sorted(t88)[1]
+        extra["ber_sweep_88"] = {
+            "trials": 88, "bits": 88_000_000_000, "n_devices": world, "seconds": round(t88m, 6), "gbit_s": round(88e9 / t88m / 1e9, 2),
+            "runs_ms": [round(x * 1e3, 4) for x in t88],
+            "counters_first_point_first_seed": list(got88[0]),
+            "what": ("bbb_ber_sweep_multi(BBB_SHARD_GROUPS) over this one device: eight 11-point sweeps back to back, ONE ncclAllReduce(uint64[176]), one read-back"
+                     if world == 1 else
+                     f"one process per GPU: rank r runs groups r, r + {world}, ... (bbb_sweep_shard, BBB_SHARD_GROUPS) through bbb_ber_trials_dev, ONE all-reduce of int64[88, 2]"),
+            "scaling": "strong: the SAME 88 trials at every N; speed-up at N = this record's seconds at N = 1 / at N"}
+        if world == 1:
+            # the projection for eight devices from what ONE device measures: each device runs ONE isolated sweep through the same
+            # entry, then the all-reduce of 176 words over eight ranks (not measurable here: priced at 30 us, RCCL's small-message latency)
+            sweep_multi([u], [channel.Trial(nbits=t.nbits, amp=t.amp, noise_var=nv, first_bit=300 << 21) for t in trials])
+            tmi = []
+            for i in range(5):
+                ts_i = [channel.Trial(nbits=t.nbits, amp=t.amp, noise_var=nv, first_bit=(301 + i) << 21) for t in trials]
+                torch.cuda.synchronize()
+                tb0 = time.perf_counter()
+                got = sweep_multi([u], ts_i)
+                tmi.append(time.perf_counter() - tb0)
+            tm = sorted(tmi)[2]
+            got0 = sweep_multi([u], trials)
+            extra["ber_sweep_multi_c_abi"] = {"n_devices": 1, "equals_single_device_counters": [list(x) for x in got0] == tot,
+                                              "gbit_s": round(11e9 / tm / 1e9, 2), "seconds": round(tm, 6), "calls_ms": [round(x * 1e3, 4) for x in tmi],
+                                              "what": "ONE isolated 11-point sweep through bbb_ber_sweep_multi (median of five, each alone)",
+                                              "reduce": "ncclAllReduce(ncclUint64, ncclSum) of uint64[22] inside bbb_ber_sweep_multi",
+                                              **multi_info()}
+            allreduce_8_s = 30e-6
+            extra["ber_sweep_88"]["projected_8_gpu"] = {
+                "seconds": round(tm + allreduce_8_s, 6), "speedup": round(t88m / (tm + allreduce_8_s), 2),
+                "arithmetic": "t(1 GPU, 88 trials) / (t(one isolated sweep through bbb_ber_sweep_multi on one device) + 30 us for the eight-rank all-reduce of 176 words)",
+                "measured": False}
         # The same sweep CONTINUED over many calls (bbb_ber_run_*: one seeding of the generators per block of 8 calls, the
         # kernel leaves its states for the next call): what a Monte-Carlo run that keeps adding bits until it has seen enough
         # errors pays per 11 x 1e9 bits.  16 calls timed, the blocks' seedings inside; every rank on its own seed, ONE
@@ -722,19 +807,6 @@ def main():
             extra["ber_sweep_bits_sharded"] = {"n_ranks": world, "gbit_s": round(11e9 / tb1 / 1e9, 2),
                                                "equals_single_device_counters": (btot.cpu().tolist() == [list(x) for x in single]) if rank == 0 else None,
                                                "reduce": "torch.distributed.all_reduce(int64[11,2], SUM) over RCCL, one bit slice per rank"}
-        if world == 1:
-            # the same sweep through the C ABI's own multi-device entry (host thread per device + ONE ncclAllReduce),
-            # here over this one device
-            from basebandboard_amd.channel import sweep_multi, multi_info
-            sweep_multi([u], warm)
-            tm = time.perf_counter()
-            got = sweep_multi([u], trials)
-            tm = time.perf_counter() - tm
-            extra["ber_sweep_multi_c_abi"] = {"n_devices": 1, "equals_single_device_counters": [list(x) for x in got] == tot,
-                                              "gbit_s": round(sum(b_ for b_, _ in got) / tm / 1e9, 2),
-                                              "reduce": "ncclAllReduce(ncclUint64, ncclSum) of uint64[22] inside bbb_ber_sweep_multi",
-                                              **multi_info()}
-
     if rank == 0:
         # issued VALU instructions per step and wave: from the SQ pass of this round (SQ_INSTS_VALU), else the ISA count
         sk = pmc_rec.get("sample_kernel", {})
@@ -803,6 +875,10 @@ def main():
                          "valu_frac": round(net_t / 78.64, 3),
                          "valu_frac_issued": round(issued_t / 78.64, 3),
                          "valu_frac_issued_of_1wave_ceiling": round(issued_t / 39.32, 3),
+                         # (the same figure under the name the round-4 verdict asked for: the bound this line is judged on is VALU issue at
+                         # one wave per SIMD, not HBM -- `bound` / `frac` stay what the contract defines them as)
+                         "valu_frac_of_1wave_ceiling": round(issued_t / 39.32, 3),
+                         "bound_that_binds": "valu issue at one wave per SIMD (256-plane bit-sliced state: 512 registers per wave)",
                          "valu_frac_issued_of_measured_attainable": round(issued_t / 56.0, 3)},
         }
         extra["cold_start"] = {"ms_per_step": round(cold_ms, 4), "gsample_s": round(NSAMP / cold_ms / 1e6, 1),

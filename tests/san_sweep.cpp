@@ -24,7 +24,8 @@ int main() {
         cfgs.push_back(c);
     }
     const int ncfg = (int)cfgs.size();
-    for (int mode : {BBB_SHARD_TRIALS, BBB_SHARD_SEEDS, BBB_SHARD_BITS}) {
+    // (BBB_SHARD_GROUPS: every trial of this list has its own bit range, so every trial is its own group)
+    for (int mode : {BBB_SHARD_TRIALS, BBB_SHARD_SEEDS, BBB_SHARD_BITS, BBB_SHARD_GROUPS}) {
         for (int ndev : {1, 2, 3, 8}) {
             std::vector<std::vector<unsigned long long>> counters((size_t)ndev, std::vector<unsigned long long>(2 * (size_t)ncfg, 0));
             std::string err;
@@ -46,6 +47,37 @@ int main() {
                     return 1;
                 }
             }
+        }
+    }
+    // BASELINE configs[4]: 8 seeds x 11 points as eight groups of eleven same-stream trials -- a group stays on one rank, the groups
+    // go round robin, and the pool's persistent workers serve calls of changing width (8, 3, 8, 1 ranks) one after the other
+    {
+        std::vector<bbb_trial_cfg> g88;
+        for (int s = 0; s < 8; s++)
+            for (int i = 0; i < 11; i++) {
+                bbb_trial_cfg c{};
+                c.prbs_k = 31; c.amp = 90 + i; c.noise_var = 8; c.prbs_state = 1; c.warmup = 16 + ((unsigned long long)s << 48);
+                c.first_bit = 0; c.nbits = 1000003ull;
+                g88.push_back(c);
+            }
+        for (int ndev : {8, 3, 8, 1}) {
+            std::vector<std::vector<int>> ran((size_t)ndev);
+            std::string err;
+            int bad = -1;
+            const int rc = bbb::run_shares_on_threads(g88.data(), 88, ndev, BBB_SHARD_GROUPS, [&](int r, const bbb_trial_cfg *mine, std::string *) -> int {
+                for (int i = 0; i < 88; i++)
+                    if (mine[i].nbits) ran[(size_t)r].push_back(i);
+                return 0;
+            }, &err, &bad);
+            if (rc) { std::printf("FAIL groups rc %d\n", rc); return 1; }
+            std::vector<int> owner(88, -1);
+            for (int r = 0; r < ndev; r++)
+                for (int i : ran[(size_t)r]) {
+                    if (owner[(size_t)i] != -1 || (i / 11) % ndev != r) { std::printf("FAIL groups: trial %d on rank %d\n", i, r); return 1; }
+                    owner[(size_t)i] = r;
+                }
+            for (int i = 0; i < 88; i++)
+                if (owner[(size_t)i] < 0) { std::printf("FAIL groups: trial %d not run\n", i); return 1; }
         }
     }
     // a failing rank: its code and text come back, the other threads are joined

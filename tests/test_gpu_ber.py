@@ -39,6 +39,60 @@ def test_trial_offsets_and_sizes(gpu, oracle, nbits, first, warm):
     assert (bits, errs) == oracle_trial(oracle, t, init=0xABCDEF0123456789)
 
 
+def fast_trials(oracle, init, ts):
+    """[(bits, errors)] of trials that share one noise / PRBS stream, from the oracle's BULK paths -- the byte-table sample stream and
+    the word-parallel PRBS, both pinned against the literal restatements in tests/test_oracle.py -- and the channel of tx.py:75-81 /
+    rx.py:29 in numpy: millions of bits per second where the literal bbo_ber_trial does one (it is held to that one below, at a
+    small size)."""
+    t = ts[0]
+    m = oracle.Lutopt(path=oracle.data_path(256))
+    g = m.awgn(init, t.warmup + t.first_bit, t.nbits, fast=True).astype(np.int32)
+    _, s0 = oracle.prbs_packed(t.prbs_k, t.first_bit, state=t.prbs_state, fast=True)
+    words, _ = oracle.prbs_packed(t.prbs_k, t.nbits, state=s0, fast=True)
+    bit = np.unpackbits(words.view(np.uint8), bitorder="little")[: t.nbits].astype(np.int32)
+    w12 = lambda v: ((v + 2048) & 4095) - 2048
+    out = []
+    for x_ in ts:
+        x = w12(np.where(bit == 1, x_.amp, -x_.amp) + w12(g * x_.noise_var))
+        out.append((t.nbits, int(np.count_nonzero((x >= 0).astype(np.int32) != bit))))
+    return out
+
+
+@pytest.mark.parametrize("nbits,k,first", [(9_000_001, 31, 0), (4_200_000, 9, 123_457), (30_000_000, 23, 5_000_003)])
+def test_generators_beyond_the_head_of_the_seeding(gpu, oracle, nbits, k, first):
+    """Round 5's two-launch seeding: the first 65536 start states come from seed_head_kernel, everything above from the tail kernel's
+    top-level tables (d = 1, 2, ... per 65536 generators), which also writes the bit planes; the PRBS states come from ONE state per
+    consumer lane and 31 steps with B^64.  Trials of 65 626 ... 468 750 generators (segments of 64 bits), all settings of a group,
+    against the oracle's sequential pass."""
+    u = gpu.LUTOPT.shipped(256, init=0x1234_5678_9ABC_DEF0_0FED_CBA9)
+    ts = [gpu.Trial(nbits=nbits, amp=a, noise_var=8, prbs_k=k, prbs_state=5, first_bit=first) for a in (91, 128, 181)]
+    init = 0x1234_5678_9ABC_DEF0_0FED_CBA9
+    got = gpu.run_trials(u, ts)
+    assert got == fast_trials(oracle, init, ts)
+    # the same trials again: the library hands back the start states it kept (no seeding), same counters
+    assert gpu.run_trials(u, ts) == got
+    # (the bulk pricing against the literal restatement of the whole trial)
+    small = gpu.Trial(nbits=60_001, amp=128, noise_var=8, prbs_k=k, prbs_state=5, first_bit=1000)
+    m = oracle.Lutopt(path=oracle.data_path(256))
+    assert fast_trials(oracle, init, [small]) == [m.ber_trial(init, k, 5, 128, 8, 16, 1000, 60_001)]
+
+
+def test_sweep_multi_groups_on_one_device(gpu, oracle):
+    """BBB_SHARD_GROUPS through bbb_ber_sweep_multi on one device (BASELINE configs[4]'s shape in small: 3 seeds x 4 points, the seeds
+    as stretches of the one cycle 2^48 apart): every group one pass of its own noise stream, counters equal bbb_ber_trials' and,
+    for the first and the last seed, the oracle's (its jump to 2 x 2^48 is the product's own state_at: the oracle steps)."""
+    from basebandboard_amd import _lib
+    from basebandboard_amd.channel import sweep_multi
+    u = gpu.LUTOPT.shipped(256)
+    ts = [gpu.Trial(nbits=300_011, amp=a, noise_var=8, warmup=16 + (s << 48)) for s in range(3) for a in (91, 114, 143, 181)]
+    got = sweep_multi([u], ts, mode=_lib.SHARD_GROUPS)
+    assert got == gpu.run_trials(u, ts)
+    m = oracle.Lutopt(path=oracle.data_path(256))
+    assert got[:4] == [m.ber_trial(1, 31, 1, t.amp, 8, 16, 0, t.nbits) for t in ts[:4]]
+    far = u.state_at(2 << 48)                       # seed 2 = the reset state 2^49 clocks on
+    assert got[8:] == [m.ber_trial(far, 31, 1, t.amp, 8, 16, 0, t.nbits) for t in ts[8:]]
+
+
 def test_grouped_trials_equal_individual_trials(gpu, oracle):
     """Trials that share one noise/PRBS stream are evaluated in one pass (up to 12 per launch); the
     counters must equal those of the same trials run one at a time, and the oracle's."""

@@ -185,6 +185,34 @@ def test_c_abi_shard_arithmetic():
         shard_trials(trials, 0, 1, 7)
 
 
+def test_c_abi_shard_groups_keeps_a_sweep_on_one_rank():
+    """BBB_SHARD_GROUPS (round 5; host only): consecutive trials on one noise / PRBS stream are one group, group q runs on rank
+    q % ndev -- BASELINE configs[4]'s 11 points x 8 seeds is one 11-point sweep per device on eight devices, eight sweeps on one;
+    trials that differ in any stream parameter start a new group; a rank's share keeps the trials' order and parameters."""
+    from basebandboard_amd import Trial
+    from basebandboard_amd import _lib
+    from basebandboard_amd.channel import shard_trials
+    t88 = [Trial(nbits=10**9, amp=90 + i, noise_var=8, warmup=16 + (s << 48)) for s in range(8) for i in range(11)]
+    for world in (1, 2, 3, 8):
+        seen = [0] * 88
+        for r in range(world):
+            mine = shard_trials(t88, r, world, _lib.SHARD_GROUPS)
+            for i, (m, t) in enumerate(zip(mine, t88)):
+                assert (m.amp, m.warmup, m.first_bit) == (t.amp, t.warmup, t.first_bit)
+                assert m.nbits == (t.nbits if (i // 11) % world == r else 0)
+                seen[i] += m.nbits != 0
+        assert seen == [1] * 88
+    # group boundaries: any of prbs_k, prbs_state, warmup, first_bit, nbits
+    mixed = [Trial(nbits=100, amp=1, noise_var=8), Trial(nbits=100, amp=2, noise_var=8), Trial(nbits=101, amp=3, noise_var=8),
+             Trial(nbits=101, amp=4, noise_var=8, first_bit=5), Trial(nbits=101, amp=5, noise_var=8, first_bit=5, prbs_k=9),
+             Trial(nbits=101, amp=6, noise_var=8, first_bit=5, prbs_k=9, prbs_state=3), Trial(nbits=101, amp=7, noise_var=8, first_bit=5, prbs_k=9, prbs_state=3)]
+    groups = [0, 0, 1, 2, 3, 4, 4]
+    for world in (2, 5):
+        for r in range(world):
+            mine = shard_trials(mixed, r, world, _lib.SHARD_GROUPS)
+            assert [bool(m.nbits) for m in mine] == [g % world == r for g in groups]
+
+
 def test_thread_per_device_orchestration_under_thread_sanitizer(tmp_path):
     """csrc/sweep_threads.hpp (the host side of bbb_ber_sweep_multi: a thread per device, shares, error hand-back) built for
     the host with -fsanitize=thread and a stub in place of the kernel launches (tests/san_sweep.cpp): no race, totals equal
