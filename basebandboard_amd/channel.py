@@ -268,13 +268,17 @@ def sweep_seeds(trials, runner, world=1, group=None):
 def gpu_runner(urng):
     """The `runner` for `sweep` on a GPU rank.  The counters of consecutive calls are slices of one zeroed block (32 calls'
     worth at a time): a zeroing kernel per call would sit on the stream between two trial kernels that otherwise follow each
-    other directly."""
-    pool = {"buf": None, "next": 0}
+    other directly.  The returned tensors are VIEWS into that block (all-reduced in place by the sweeps): copy what is to be
+    kept beyond the runner.  The block belongs to the torch stream that was current when it was zeroed: a call under another
+    current stream gets a fresh block (zeroed there) -- the old one stays alive as long as its views do."""
+    pool = {"buf": None, "next": 0, "stream": None}
 
     def run(local_trials, n):
-        if pool["buf"] is None or pool["buf"].shape[1] != n or pool["next"] == pool["buf"].shape[0]:
+        cur = torch.cuda.current_stream(urng.device)
+        if pool["buf"] is None or pool["buf"].shape[1] != n or pool["next"] == pool["buf"].shape[0] or pool["stream"] != cur:
             pool["buf"] = torch.zeros((32, n, 2), dtype=torch.int64, device=torch.device("cuda", urng.device))
             pool["next"] = 0
+            pool["stream"] = cur
         c = pool["buf"][pool["next"]]
         pool["next"] += 1
         return run_trials_into(urng, local_trials, c)

@@ -162,6 +162,70 @@ seed_level_kernel(const uint32_t *__restrict tabs, int k, int e, unsigned long l
     }
 }
 
+// The same start states without LDS and in ONE launch (round 5).  The 32 generators of a consumer lane are 64 L bits apart
+// from each other, so ONE table-composed state per lane -- 65 408 instead of 2.09 M, from the jump tables in place (global memory:
+// the vector cache holds the few KiB a wave touches) -- and 31 steps with the 31 x 31 matrix Q = B^64 (its columns are scalars:
+// V_BFE_I32 + V_BITOP3 per column) give a lane's 32 states, a 32 x 32 bit transpose the planes.  ~2300 VALU instructions per
+// lane, no LDS: beside the generators' seeding kernels, which live on the LDS pipeline, it costs them nothing (the table-driven
+// form above took 65 us there and lengthened the tail kernel from 61 to 85: profiles/r05_ber_c_timeline.txt).
+struct PrbsLaneJump { uint32_t qcol[32]; uint32_t first[16]; };      // qcol[c]: column c of Q (bit r = Q[r][c]); first[i] = B^i p0
+// (a block of 256 consumer lanes; `block` = its index: the body of prbs_seed_lanes_kernel and of the extra blocks of seed_head_kernel)
+__device__ __forceinline__ void prbs_seed_lanes_block(const uint32_t *__restrict tabs, const PrbsLaneJump &jp, int k, int levels,
+                                                      unsigned long long G, unsigned nlanes, uint32_t *__restrict planes, unsigned block) {
+    __shared__ uint32_t first[16];
+    if (threadIdx.x < 16) first[threadIdx.x] = jp.first[threadIdx.x];
+    __syncthreads();
+    const unsigned long long LG = (unsigned long long)block * 256 + threadIdx.x;
+    if (LG >= nlanes) return;
+    const unsigned long long wave = LG >> 6;
+    const unsigned lane = (unsigned)(LG & 63);
+    const unsigned long long g0 = gen_index(wave, lane, 0);
+    const int nnib = (k + 3) / 4, nt = nnib * 16;
+    uint32_t x = first[g0 & 15];
+    for (int e = 1; e < levels; e++) {
+        const unsigned d = (unsigned)(g0 >> (4 * e)) & 15u;
+        if (d) {
+            const uint32_t *t = tabs + ((size_t)e * 15 + (d - 1)) * nt;
+            uint32_t y = 0;
+#pragma unroll
+            for (int n = 0; n < 8; n++)
+                if (n < nnib) y ^= t[n * 16 + ((x >> (4 * n)) & 15u)];
+            x = y;
+        }
+    }
+    uint32_t q[32];
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+        q[j] = g0 + 64ull * (unsigned)j < G ? x : 0u;
+        uint32_t y = 0;
+#pragma unroll
+        for (int c = 0; c < 31; c++) {
+            const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)x, c, 1);      // 0 or ~0: bit c of x
+            y = __builtin_amdgcn_bitop3_b32(y, jp.qcol[c], m, 0x78);                // a ^ (b & c)
+        }
+        x = y;
+    }
+    transpose32(q);
+#pragma unroll
+    for (int p = 0; p < 32; p++)
+        if (p < k) planes[(size_t)p * nlanes + LG] = q[p];
+}
+
+__global__ void __launch_bounds__(256)
+prbs_seed_lanes_kernel(const uint32_t *__restrict tabs, PrbsLaneJump jp, int k, int levels, unsigned long long G, unsigned nlanes,
+                       uint32_t *__restrict planes) {
+    prbs_seed_lanes_block(tabs, jp, k, levels, G, nlanes, planes, blockIdx.x);
+}
+
+// the PRBS seeding that rides on a head launch (blocks [nhead, nhead + nblocks) of seed_head_kernel): nblocks = 0 -- none
+struct PrbsRide {
+    const uint32_t *tabs;
+    uint32_t *planes;
+    PrbsLaneJump jp;
+    int k, levels;
+    unsigned nlanes, nblocks;
+};
+
 // ---------------------------------------------------------------------------------------------
 // Start states AND bit planes in TWO launches (round 5; the BER trial's own seeding: an isolated trial waits for this chain, and
 // the chain above is seven launches -- store16, five levels of which three are a few thousand mat-vecs each and cost a launch
@@ -184,8 +248,14 @@ seed_level_kernel(const uint32_t *__restrict tabs, int k, int e, unsigned long l
 template <int W32>
 __global__ void __launch_bounds__(256)
 seed_head_kernel(const uint32_t *__restrict tabs, Seed16 s, int k, unsigned long long G, unsigned long long stride,
-                 uint32_t *__restrict S) {
+                 uint32_t *__restrict S, unsigned nhead, PrbsRide pr) {
     extern __shared__ __attribute__((aligned(16))) uint32_t tab[];      // two tables: digit 2's, digit 3's
+    // The trial's PRBS start states ride on this launch as extra blocks (VALU only, no LDS to speak of: they share the CUs with the
+    // head blocks, which wait on LDS and L2): no second stream, no event and no barrier packet between the seeding and the trial kernel
+    if (blockIdx.x >= nhead) {
+        prbs_seed_lanes_block(pr.tabs, pr.jp, pr.k, pr.levels, G, pr.nlanes, pr.planes, blockIdx.x - nhead);
+        return;
+    }
     const unsigned t = threadIdx.x, d0 = t & 15u, d1 = t >> 4, d2 = blockIdx.x & 15u, d3 = blockIdx.x >> 4;
     const unsigned long long g = (unsigned long long)blockIdx.x * 256 + t;
     if ((unsigned long long)blockIdx.x * 256 >= G) return;       // whole block beyond the last generator
@@ -392,55 +462,6 @@ prbs_seed_states_kernel(const uint32_t *__restrict tabs, Seed16 s, int k, int le
         }
         S[g] = x;
     }
-}
-
-// The same start states without LDS and in ONE launch (round 5).  The 32 generators of a consumer lane are 64 L bits apart
-// from each other, so ONE table-composed state per lane -- 65 408 instead of 2.09 M, from the jump tables in place (global memory:
-// the vector cache holds the few KiB a wave touches) -- and 31 steps with the 31 x 31 matrix Q = B^64 (its columns are scalars:
-// V_BFE_I32 + V_BITOP3 per column) give a lane's 32 states, a 32 x 32 bit transpose the planes.  ~2300 VALU instructions per
-// lane, no LDS: beside the generators' seeding kernels, which live on the LDS pipeline, it costs them nothing (the table-driven
-// form above took 65 us there and lengthened the tail kernel from 61 to 85: profiles/r05_ber_c_timeline.txt).
-struct PrbsLaneJump { uint32_t qcol[32]; uint32_t first[16]; };      // qcol[c]: column c of Q (bit r = Q[r][c]); first[i] = B^i p0
-__global__ void __launch_bounds__(256)
-prbs_seed_lanes_kernel(const uint32_t *__restrict tabs, PrbsLaneJump jp, int k, int levels, unsigned long long G, unsigned nlanes,
-                       uint32_t *__restrict planes) {
-    __shared__ uint32_t first[16];
-    if (threadIdx.x < 16) first[threadIdx.x] = jp.first[threadIdx.x];
-    __syncthreads();
-    const unsigned long long LG = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (LG >= nlanes) return;
-    const unsigned long long wave = LG >> 6;
-    const unsigned lane = (unsigned)(LG & 63);
-    const unsigned long long g0 = gen_index(wave, lane, 0);
-    const int nnib = (k + 3) / 4, nt = nnib * 16;
-    uint32_t x = first[g0 & 15];
-    for (int e = 1; e < levels; e++) {
-        const unsigned d = (unsigned)(g0 >> (4 * e)) & 15u;
-        if (d) {
-            const uint32_t *t = tabs + ((size_t)e * 15 + (d - 1)) * nt;
-            uint32_t y = 0;
-#pragma unroll
-            for (int n = 0; n < 8; n++)
-                if (n < nnib) y ^= t[n * 16 + ((x >> (4 * n)) & 15u)];
-            x = y;
-        }
-    }
-    uint32_t q[32];
-#pragma unroll
-    for (int j = 0; j < 32; j++) {
-        q[j] = g0 + 64ull * (unsigned)j < G ? x : 0u;
-        uint32_t y = 0;
-#pragma unroll
-        for (int c = 0; c < 31; c++) {
-            const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)x, c, 1);      // 0 or ~0: bit c of x
-            y = __builtin_amdgcn_bitop3_b32(y, jp.qcol[c], m, 0x78);                // a ^ (b & c)
-        }
-        x = y;
-    }
-    transpose32(q);
-#pragma unroll
-    for (int p = 0; p < 32; p++)
-        if (p < k) planes[(size_t)p * nlanes + LG] = q[p];
 }
 
 // Word-major packed states -> bit planes.  Thread (LG, wq) gathers word wq of the 32 generators of
@@ -779,7 +800,7 @@ template <bool SMALL>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 awgn256_planes_kernel(const uint32_t *__restrict planes, u32x4 *__restrict stage, unsigned L, unsigned nlanes
 #ifdef BBB_EXPERIMENTS
-                      , unsigned long long *dbg, unsigned exp_flags      // 4: wave priority 0 (1 and 2 -- no stores, plain stores -- were measured and removed: profiles/r03_mover_beside_flags.log)
+                      , unsigned long long *dbg, unsigned exp_flags      // 4: wave priority 0; 1: NO STORES (round 5: what the staging traffic costs this kernel, alone -- experiments/store_cost.py)
 #endif
 ) {
     const unsigned lane = threadIdx.x;
@@ -820,11 +841,21 @@ awgn256_planes_kernel(const uint32_t *__restrict planes, u32x4 *__restrict stage
 #pragma unroll 1
     for (unsigned t = 0; t < L; t += 2) {
         lutopt256_step_parked_hi(a, pa, b, pb, cnt);
+#ifdef BBB_EXPERIMENTS
+        if (exp_flags & 1) asm volatile("" :: "v"(cnt[0]), "v"(cnt[1]), "v"(cnt[2]), "v"(cnt[3]), "v"(cnt[4]), "v"(cnt[5]), "v"(cnt[6]), "v"(cnt[7])); else
+#endif
+        {
         __builtin_nontemporal_store((u32x4){cnt[0], cnt[1], cnt[2], cnt[3]}, out);
         __builtin_nontemporal_store((u32x4){cnt[4], cnt[5], cnt[6], cnt[7]}, out + 64);
+        }
         lutopt256_step_parked_hi(b, pb, a, pa, cnt);
+#ifdef BBB_EXPERIMENTS
+        if (exp_flags & 1) asm volatile("" :: "v"(cnt[0]), "v"(cnt[1]), "v"(cnt[2]), "v"(cnt[3]), "v"(cnt[4]), "v"(cnt[5]), "v"(cnt[6]), "v"(cnt[7])); else
+#endif
+        {
         __builtin_nontemporal_store((u32x4){cnt[0], cnt[1], cnt[2], cnt[3]}, out + 128);
         __builtin_nontemporal_store((u32x4){cnt[4], cnt[5], cnt[6], cnt[7]}, out + 192);
+        }
         out += 256;
     }
 #ifdef BBB_EXPERIMENTS
@@ -1422,12 +1453,32 @@ static int seed_and_slice(int k, const uint32_t *d_tabs, const uint32_t *s16, ui
     return BBB_OK;
 }
 
-int awgn_seed_head_launch(int k, const uint32_t *d_tabs, const uint32_t *s16, uint64_t G, uint32_t *d_states, hipStream_t st) {
+static int make_prbs_jump(int k, const uint32_t *s16, const uint32_t *qcol, uint64_t G, PrbsLaneJump *jp, int *levels) {
+    if (k < 2 || k > 31) return fail(BBB_EINVAL, "PRBS order must be below 32");
+    *jp = PrbsLaneJump{};
+    for (int i = 0; i < 16; i++) jp->first[i] = s16[i * 16];
+    for (int c = 0; c < 32; c++) jp->qcol[c] = c < k ? qcol[c] : 0u;
+    int lv = 0;
+    while ((1ull << (4 * lv)) < G) lv++;
+    if (lv < 1) lv = 1;
+    if (lv > 7) return fail(BBB_EINVAL, "too many generators for the PRBS jump plan");
+    *levels = lv;
+    return BBB_OK;
+}
+
+int awgn_seed_head_launch(int k, const uint32_t *d_tabs, const uint32_t *s16, uint64_t G, uint32_t *d_states, hipStream_t st,
+                          const PrbsSeedRide *ride) {
     constexpr int W32 = 8;
     if (k != 256 || G > ((uint64_t)kSeedTopTables + 1) * 65536) return fail(BBB_EINVAL, "two-launch seeding: k = 256, at most 2^21 generators");
     Seed16 s;
     for (int i = 0; i < 16; i++)
         for (int w = 0; w < 16; w++) s.w[i][w] = w < W32 ? s16[i * 16 + w] : 0u;
+    PrbsRide pr{};
+    if (ride) {
+        const int rc = make_prbs_jump(ride->k, ride->s16, ride->qcol, G, &pr.jp, &pr.levels);
+        if (rc) return rc;
+        pr.tabs = ride->d_tabs; pr.planes = ride->d_planes; pr.k = ride->k; pr.nlanes = ride->nlanes; pr.nblocks = (ride->nlanes + 255) / 256;
+    }
     const size_t lds = (size_t)2 * 64 * 16 * W32 * sizeof(uint32_t);              // two whole tables: 64 KiB of dynamic LDS
     {   // (per device: hipFuncSetAttribute applies to the current one)
         static std::mutex mu;
@@ -1441,8 +1492,9 @@ int awgn_seed_head_launch(int k, const uint32_t *d_tabs, const uint32_t *s16, ui
         }
     }
     const uint64_t head = G < 65536 ? G : 65536;
-    hipLaunchKernelGGL((seed_head_kernel<W32>), dim3((unsigned)((head + 255) / 256)), dim3(256), lds, st, d_tabs, s, k,
-                       (unsigned long long)G, 65536ull, d_states);
+    const unsigned nhead = (unsigned)((head + 255) / 256);
+    hipLaunchKernelGGL((seed_head_kernel<W32>), dim3(nhead + pr.nblocks), dim3(256), lds, st, d_tabs, s, k,
+                       (unsigned long long)G, 65536ull, d_states, nhead, pr);
     BBB_HIP(hipGetLastError());
     return BBB_OK;
 }
@@ -1478,14 +1530,10 @@ int prbs_seed_planes_launch(int k, const uint32_t *d_tabs, const uint32_t *s16, 
 
 int prbs_seed_lanes_launch(int k, const uint32_t *d_tabs, const uint32_t *s16, const uint32_t *qcol, uint64_t G, unsigned nlanes,
                            uint32_t *d_planes, hipStream_t st) {
-    if (k < 2 || k > 31) return fail(BBB_EINVAL, "PRBS order must be below 32");
-    PrbsLaneJump jp{};
-    for (int i = 0; i < 16; i++) jp.first[i] = s16[i * 16];
-    for (int c = 0; c < 32; c++) jp.qcol[c] = c < k ? qcol[c] : 0u;
+    PrbsLaneJump jp;
     int levels = 0;
-    while ((1ull << (4 * levels)) < G) levels++;
-    if (levels < 1) levels = 1;
-    if (levels > 7) return fail(BBB_EINVAL, "too many generators for the PRBS jump plan");
+    const int rc = make_prbs_jump(k, s16, qcol, G, &jp, &levels);
+    if (rc) return rc;
     hipLaunchKernelGGL(prbs_seed_lanes_kernel, dim3((nlanes + 255) / 256), dim3(256), 0, st, d_tabs, jp, k, levels, (unsigned long long)G, nlanes,
                        d_planes);
     BBB_HIP(hipGetLastError());

@@ -20,7 +20,10 @@ int awgn_seed_launch(int k, const uint32_t *d_tabs, const uint32_t *s16, uint64_
 // (W32 = 8), G <= 2^21; d_states holds 65536 x 8 words.  Two calls, so that a caller can queue other work between them (the
 // trial's PRBS seeding goes to its side stream while the head kernel runs)
 constexpr int kSeedTopTables = 31;
-int awgn_seed_head_launch(int k, const uint32_t *d_tabs, const uint32_t *s16, uint64_t G, uint32_t *d_states, hipStream_t st);
+// `ride`: the trial's PRBS start states (prbs_seed_lanes_launch's arguments) seeded by extra blocks of the head launch, or null
+struct PrbsSeedRide { int k; const uint32_t *d_tabs, *s16, *qcol; unsigned nlanes; uint32_t *d_planes; };
+int awgn_seed_head_launch(int k, const uint32_t *d_tabs, const uint32_t *s16, uint64_t G, uint32_t *d_states, hipStream_t st,
+                          const PrbsSeedRide *ride = nullptr);
 int awgn_seed_tail_planes_launch(int k, const uint32_t *d_top, uint64_t G, const uint32_t *d_states, unsigned nlanes, uint32_t *d_planes,
                                  hipStream_t st);
 // PRBS start states (k <= 31) of the BER kernels' generators, d_states[G] -> bit planes [k][nlanes], two launches; d_tabs = the radix-16

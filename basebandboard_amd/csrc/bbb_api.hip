@@ -771,8 +771,9 @@ int ber_run(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, unsigned long lo
         // Round 5 (profiles/r05_base_ber_timeline.txt: an isolated trial's kernel started 155 us after the first launch -- seven
         // launches of generator seeding, 131 us, and the PRBS's states, queued 58 us later and 70-80 us long beside the big levels,
         // finishing last).  Now: everything the host has to compute comes first; then the launches, in the order the GPU needs
-        // them -- the generators' head kernel (25 us), the PRBS seeding on the side stream BESIDE it (30 us alone), the tail kernel,
-        // which writes the planes (60 us) -- two launches where there were seven, and no bit-slicing pass.
+        // them -- the generators' head kernel (25 us) with the PRBS seeding as extra blocks of the same launch (15 us of VALU work, one
+        // state per consumer lane), the tail kernel, which writes the planes (60 us) -- two launches where there were nine, no
+        // bit-slicing pass, no side stream and no event in front of the trial kernel.
         // Where the generators' states are derived depends on what the caller's stream is doing:
         //   busy   (a trial queued behind another: bbb_ber_trials_dev does not synchronise) -- on an arithmetic stream, BESIDE the
         //          kernel of the trial before (the seedings are latency, not work; the trial kernel leaves 140 registers per SIMD),
@@ -781,8 +782,6 @@ int ber_run(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, unsigned long lo
         //          front of the trial kernel is a round trip through the command processor (20-26 us: DESIGN.md 3.4).
         // Both orders carry the same dependencies (a buffer's last reader -> its seeding -> the trial kernel), by stream order
         // where the stream is the same and by events where it is not.
-        if (!h->ber_join) BBB_HIP(hipEventCreateWithFlags(&h->ber_join, hipEventDisableTiming));
-        { const int rcs_ = ensure_side_stream(h); if (rcs_) return rcs_; }
         if ((rc = ensure_internal_streams(h))) return rc;
         const uint64_t gen_first = c.warmup + c.first_bit + 1;
         // -- host: plans, buffers, the first sixteen states of both chains
@@ -831,25 +830,25 @@ int ber_run(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, unsigned long lo
         // -- launches
         const bool busy = seed_gen && hipStreamQuery(h->cs) == hipErrorNotReady;
         hipStream_t ss = busy ? h->xs2[0] : h->cs;
+        // (the PRBS pair's last reader, the trial before last: wherever its seeding goes now)
+        if (h->pp_pending[pb]) BBB_HIP(hipStreamWaitEvent(seed_gen ? ss : h->cs, h->pp_read[pb], 0));
         if (seed_gen) {
             h->bs_valid[sb] = false;
             if (h->bs_pending[sb]) BBB_HIP(hipStreamWaitEvent(ss, h->bs_read[sb], 0));    // the trial before last read this pair
-            if ((rc = awgn_seed_head_launch(h->k, plan->d_cols, s16, G, h->d_bstates[sb], ss))) return rc;
-        }
-        if (h->pp_pending[pb]) BBB_HIP(hipStreamWaitEvent(h->side, h->pp_read[pb], 0));    // the trial before last read this pair
-        if ((rc = prbs_seed_lanes_launch(c.prbs_k, pp->d_cols, ps16, pp->qcol64, G, nlanes, h->d_pplanes[pb], h->side))) return rc;
-        BBB_HIP(hipEventRecord(h->ber_join, h->side));
-        if (seed_gen) {
+            // the PRBS start states ride on the head launch (extra blocks: VALU work beside the head's LDS and L2 latency)
+            const PrbsSeedRide ride{c.prbs_k, pp->d_cols, ps16, pp->qcol64, nlanes, h->d_pplanes[pb]};
+            if ((rc = awgn_seed_head_launch(h->k, plan->d_cols, s16, G, h->d_bstates[sb], ss, &ride))) return rc;
             if ((rc = awgn_seed_tail_planes_launch(h->k, plan->d_top, G, h->d_bstates[sb], nlanes, h->d_bplanes[sb], ss))) return rc;
             BBB_HIP(hipEventRecord(h->bs_ready[sb], ss));
             if (busy) BBB_HIP(hipStreamWaitEvent(h->cs, h->bs_ready[sb], 0));
             h->bs_valid[sb] = true;
             h->bs_first[sb] = gen_first; h->bs_L[sb] = L; h->bs_G[sb] = G;
         } else {
-            // the same trial again: its states were derived by an earlier call -- on whatever stream that call found right
+            // the same trial again: its generator states were derived by an earlier call -- on whatever stream that call found right;
+            // the PRBS states (their pairs alternate) in line
             BBB_HIP(hipStreamWaitEvent(h->cs, h->bs_ready[sb], 0));
+            if ((rc = prbs_seed_lanes_launch(c.prbs_k, pp->d_cols, ps16, pp->qcol64, G, nlanes, h->d_pplanes[pb], h->cs))) return rc;
         }
-        BBB_HIP(hipStreamWaitEvent(h->cs, h->ber_join, 0));
         if (h->specialised) {
             if ((rc = ber256_launch(h->d_bplanes[sb], h->d_pplanes[pb], &td[(size_t)i], n, nlanes, counters_dev + 2 * (size_t)i, h->cs))) return rc;
         } else {
@@ -1901,7 +1900,10 @@ int bbb_ber_run_open(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, uint32_
     partition(h, nblock, 2 * r->m, &r->Lb, &r->G, &r->nlanes);
     if (r->Lb / r->m >= (1ull << 27)) return fail(BBB_EINVAL, "nbits too large for one call (about 2^47): lower it");
     BBB_HIP(hipMalloc((void **)&r->d_totals, 2 * (size_t)ncfg * sizeof(unsigned long long)));
-    BBB_HIP(hipMemset(r->d_totals, 0, 2 * (size_t)ncfg * sizeof(unsigned long long)));
+    if (hipMemset(r->d_totals, 0, 2 * (size_t)ncfg * sizeof(unsigned long long)) != hipSuccess) {
+        (void)hipFree(r->d_totals);            // (the unique_ptr frees the struct only)
+        return fail(BBB_EHIP, "hipMemset of the run's totals failed");
+    }
     *out = r.release();
     return BBB_OK;
 }
@@ -2055,6 +2057,16 @@ int bbb_multi_last_info(bbb_multi_info *out) {
 }
 
 int bbb_multi_release(void) {
+    {   // the pooled internal streams as well: a host that is about to call hipDeviceReset releases them here first (handles created
+        // afterwards get fresh ones; handles that are still alive must have been destroyed before)
+        std::lock_guard<std::mutex> gs(g_streams_mu);
+        for (auto &kv : g_streams) {
+            if (hipSetDevice(kv.first) != hipSuccess) continue;
+            for (hipStream_t st : {kv.second.xs[0], kv.second.xs[1], kv.second.side})
+                if (st) (void)hipStreamDestroy(st);
+        }
+        g_streams.clear();
+    }
     std::lock_guard<std::mutex> g(g_comm_mu);
     const Rccl &r = rccl();
     for (CommSet &c : g_comm_sets)

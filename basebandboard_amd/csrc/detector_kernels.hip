@@ -922,14 +922,20 @@ static int detector_stream_k(const u64 *src, u64 nbits, u64 *err, u64 *reload, b
     char *ws;
     u64 *hpin;
     hipEvent_t ev_copy, ev_zero;
-    bool tail_zeroed;
+    bool tail_zeroed, zero_pending;
     {
         std::lock_guard<std::mutex> g(g_det_ws_mu);
         DetWorkspace &w = g_det_ws[ws_slot];
         ws = w.d; hpin = w.h; ev_copy = w.ev_copy; ev_zero = w.ev_zero;
         tail_zeroed = w.zeroed && w.zeroed_at == o_tail;
+        zero_pending = w.zeroed;
         w.zeroed = false;                     // (until this call has ended the way that leaves them zeroed again)
     }
+    // The previous user of this workspace left a 128-byte memset queued behind its read-back (ev_zero) and handed the workspace back
+    // without waiting for it.  A call with ANOTHER layout (other nbits or chunking: the old tail lies inside this call's chunk
+    // records), on another stream, must not start before that memset has run -- round 4's advisor: a late memset zeroing 16 words
+    // of the new call's records.  Whoever finds the flag set waits for the event first (same stream: nothing to wait for).
+    if (zero_pending) (void)hipStreamWaitEvent(st, ev_zero, 0);
     DetState *spec = (DetState *)(ws + o_spec), *endst = (DetState *)(ws + o_end);
     DetCount *counts = (DetCount *)(ws + o_cnt);
     unsigned *list = (unsigned *)(ws + o_list), *list2 = list + nchunks;
@@ -979,8 +985,7 @@ static int detector_stream_k(const u64 *src, u64 nbits, u64 *err, u64 *reload, b
         // at once when pass 1 found nothing) -- all queued before the host looks.
         constexpr unsigned kSpec = 4096;
         u64 *const hh = hpin;
-        if (tail_zeroed) (void)hipStreamWaitEvent(st, ev_zero, 0);          // (zeroed behind the previous call's read-back, maybe on another stream)
-        else (void)hipMemsetAsync(tail, 0, 16 * sizeof(u64), st);
+        if (!tail_zeroed) (void)hipMemsetAsync(tail, 0, 16 * sizeof(u64), st);      // (else: zeroed behind the previous call's read-back; waited for above)
         hipLaunchKernelGGL(det_reduce_kernel, dim3(rgrid), dim3(256), 0, st, nchunks, counts, tail, (const DetState *)spec,
                            (const DetState *)endst, list, nlist, (const unsigned *)nullptr);
         // The repair stages are queued blind only for the dense pass, whose reset-state speculation leaves a few dozen

@@ -21,13 +21,16 @@ __device__ __forceinline__ void stream_chunk(char *buf, unsigned long long lo, u
         }
     }
 }
-template <typename V, bool DYN>
+// DYN 0: static regions; 1: chunks from a counter, chunk c at c * chunk (all waves inside one moving window); 2: chunks from a
+// counter, chunk c in stretch c % S at position c / S (S far-apart sequential streams, dynamically balanced: what a generator whose
+// waves chain through their own stretch and steal from slow ones would look like to the memory system)
+template <typename V, int DYN>
 __global__ void __launch_bounds__(64) k(char *buf, unsigned long long total, unsigned long long chunk, unsigned long long *counter,
                                         unsigned long long *stamps) {
     const unsigned lane = threadIdx.x;
     V acc; acc.x = lane; acc.y = blockIdx.x;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    if (!DYN) {
+    if (DYN == 0) {
         const unsigned long long lo = (unsigned long long)blockIdx.x * chunk;
         stream_chunk<V>(buf, lo, lo + chunk < total ? lo + chunk : total, lane, acc);
     } else {
@@ -35,8 +38,14 @@ __global__ void __launch_bounds__(64) k(char *buf, unsigned long long total, uns
             unsigned long long c = 0;
             if (lane == 0) c = atomicAdd(counter, 1ull);
             c = __shfl(c, 0, 64);
-            const unsigned long long lo = c * chunk;
+            unsigned long long lo = c * chunk;
             if (lo >= total) break;
+            if (DYN == 2) {
+                const unsigned long long S = gridDim.x, nchunks = (total + chunk - 1) / chunk, per = (nchunks + S - 1) / S;
+                const unsigned long long cc = (c % S) * per + c / S;
+                if (c / S >= per || cc >= nchunks) continue;
+                lo = cc * chunk;
+            }
             stream_chunk<V>(buf, lo, lo + chunk < total ? lo + chunk : total, lane, acc);
         }
     }
@@ -44,7 +53,7 @@ __global__ void __launch_bounds__(64) k(char *buf, unsigned long long total, uns
     const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
     if (lane == 0) { stamps[2 * blockIdx.x] = t0; stamps[2 * blockIdx.x + 1] = t1; }
 }
-template <typename V, bool DYN> void run(const char *name, char *buf, unsigned long long total, unsigned long long chunk, unsigned grid,
+template <typename V, int DYN> void run(const char *name, char *buf, unsigned long long total, unsigned long long chunk, unsigned grid,
                                          unsigned long long *counter, unsigned long long *stamps) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e9f, sum = 0;
@@ -72,12 +81,14 @@ int main() {
     hipMalloc(&buf, total + 4096); hipMalloc(&counter, 8); hipMalloc(&stamps, 16 * 8192);
     hipMemset(buf, 1, total);
     const unsigned long long region = ((total + 1023) / 1024 + 4095) / 4096 * 4096;
-    run<u32x2, false>("static regions, 8 B/lane", buf, total, region, (unsigned)((total + region - 1) / region), counter, stamps);
-    run<u32x4, false>("static regions, 16 B/lane", buf, total, region, (unsigned)((total + region - 1) / region), counter, stamps);
-    for (unsigned waves : {128u, 256u, 384u, 512u, 640u, 768u, 1024u})
-        for (unsigned long long c : {128ull << 10, 256ull << 10, 512ull << 10}) {
-            run<u32x2, true>("dynamic chunks, 8 B/lane", buf, total, c, waves, counter, stamps);
-            run<u32x4, true>("dynamic chunks, 16 B/lane", buf, total, c, waves, counter, stamps);
+    run<u32x2, 0>("static regions, 8 B/lane", buf, total, region, (unsigned)((total + region - 1) / region), counter, stamps);
+    run<u32x4, 0>("static regions, 16 B/lane", buf, total, region, (unsigned)((total + region - 1) / region), counter, stamps);
+    for (unsigned waves : {256u, 384u, 512u, 1024u})
+        for (unsigned long long c : {128ull << 10, 256ull << 10}) {
+            run<u32x2, 1>("dynamic, one moving window, 8 B/lane", buf, total, c, waves, counter, stamps);
+            run<u32x2, 2>("dynamic, far-apart stretches, 8 B/lane", buf, total, c, waves, counter, stamps);
+            run<u32x4, 1>("dynamic, one moving window, 16 B/lane", buf, total, c, waves, counter, stamps);
+            run<u32x4, 2>("dynamic, far-apart stretches, 16 B/lane", buf, total, c, waves, counter, stamps);
         }
     return 0;
 }

@@ -295,7 +295,9 @@ int bbb_ber_trials_dev(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, uint6
  * one LFSR, one LUTOPT, clocked for as long as the test lasts (gateware/bbb/tx.py:56-81, prbs.py:32-35).
  * _next: runs the next call on the handle's stream and returns the running totals of the whole run (host, synchronises;
  * totals may be NULL: no read-back, no synchronisation).  _next_dev: ADDS the call's counters to counters_dev
- * ([ncfg][2] uint64, device) without synchronising.  _tell: calls made so far / first bit of the next block to start. */
+ * ([ncfg][2] uint64, device) without synchronising.  _tell: calls made so far / first bit of the next block to start.
+ * LIFETIME: a run borrows its handle -- every call on the run, _close included, uses the handle's streams and plans: close
+ * the run BEFORE bbb_lutopt_destroy of its handle (a run that outlives its handle is a use after free). */
 typedef struct bbb_ber_run bbb_ber_run;
 int bbb_ber_run_open(bbb_lutopt *h, const bbb_trial_cfg *cfgs, int ncfg, uint32_t calls_per_block, bbb_ber_run **out);
 int bbb_ber_run_next(bbb_ber_run *r, bbb_ber *totals);
@@ -344,7 +346,8 @@ typedef struct {
     char    rccl_path[256];
 } bbb_multi_info;
 int bbb_multi_last_info(bbb_multi_info *out);
-/* Destroy the cached RCCL communicators (optional; before unloading the library or resetting devices). */
+/* Destroy the cached RCCL communicators and the library's pooled internal streams (optional; before unloading the
+ * library or resetting devices: destroy every handle first -- handles created afterwards get fresh streams). */
 int bbb_multi_release(void);
 
 /* ---- pulse shaper and transmitter output (8 samples per data bit) -------------------------- */

@@ -306,8 +306,9 @@ int awgn_seed_launch(int, const uint32_t *d_tabs, const uint32_t *, uint64_t, ui
     op(st, "bitslice", {d_states}, {d_planes});
     return BBB_OK;
 }
-int awgn_seed_head_launch(int, const uint32_t *d_tabs, const uint32_t *, uint64_t, uint32_t *d_states, hipStream_t st) {
-    op(st, "seed_head_kernel", {d_tabs}, {d_states});
+int awgn_seed_head_launch(int, const uint32_t *d_tabs, const uint32_t *, uint64_t, uint32_t *d_states, hipStream_t st, const PrbsSeedRide *ride) {
+    if (ride) op(st, "seed_head_kernel (+ PRBS lanes)", {d_tabs, ride->d_tabs}, {d_states, ride->d_planes});
+    else op(st, "seed_head_kernel", {d_tabs}, {d_states});
     return BBB_OK;
 }
 int awgn_seed_tail_planes_launch(int, const uint32_t *d_top, uint64_t, const uint32_t *d_states, unsigned, uint32_t *d_planes, hipStream_t st) {
