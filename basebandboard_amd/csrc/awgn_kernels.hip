@@ -502,10 +502,6 @@ bitslice_kernel(const uint32_t *__restrict S, unsigned long long G, unsigned lon
 // ---------------------------------------------------------------------------------------------
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-#ifdef BBB_EXPERIMENTS
-static void *g_exp_awgn_debug = nullptr;      // u64[4 * waves], device memory, or null
-extern "C" void bbb_exp_set_awgn_debug(void *dev_ptr) { g_exp_awgn_debug = dev_ptr; }
-#endif
 
 // The transmitter's output fused into the sample kernel (tx.py:60-81; bitshaper.py:25-86): instead of the
 // int8 noise stream the round end writes x = wrap12(bit_en * shaped + wrap12(g * noise_var)) as int16, 32
@@ -572,12 +568,6 @@ awgn256_kernel(const uint32_t *__restrict planes, void *__restrict dst_, unsigne
     // highest wave priority: when the seeding of the next fill (bbb_awgn_prefetch) shares the SIMD it gets the
     // issue slots this wave leaves free instead of every other one
     __builtin_amdgcn_s_setprio(3);
-#ifdef BBB_EXPERIMENTS
-    // per-wave time stamps (experiments/wave_clock.py): shader-clock ticks (s_memtime) and the constant 100 MHz counter
-    // (s_memrealtime) at both ends of the wave -- cycles per wave and the clock they ran at, alone and beside guests
-    unsigned long long dbg_t0 = 0, dbg_r0 = 0, dbg_round_end = 0;
-    if (!TX && tx.bits) { dbg_t0 = __builtin_amdgcn_s_memtime(); dbg_r0 = __builtin_amdgcn_s_memrealtime(); }
-#endif
 
     uint32_t selmask[4] = {0, 0, 0, 0};
     if (TX) {
@@ -753,23 +743,9 @@ awgn256_kernel(const uint32_t *__restrict planes, void *__restrict dst_, unsigne
                 }
             }
         };
-#ifdef BBB_EXPERIMENTS
-        unsigned long long dbg_ta = 0;
-        if (!TX && tx.bits) dbg_ta = __builtin_amdgcn_s_memtime();
-#endif
         if (wave_full) all_iterations(std::true_type{});
         else all_iterations(std::false_type{});
-#ifdef BBB_EXPERIMENTS
-        if (!TX && tx.bits) dbg_round_end += __builtin_amdgcn_s_memtime() - dbg_ta;
-#endif
     }
-#ifdef BBB_EXPERIMENTS
-    if (!TX && tx.bits && lane == 0) {
-        unsigned long long *d = (unsigned long long *)tx.bits + 4 * wave;
-        d[0] = dbg_t0; d[1] = __builtin_amdgcn_s_memtime(); d[2] = dbg_r0; d[3] = __builtin_amdgcn_s_memrealtime();
-        ((unsigned long long *)tx.bits)[4 * 1024 + wave] = dbg_round_end;       // cycles inside the round ends
-    }
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -799,21 +775,11 @@ awgn256_kernel(const uint32_t *__restrict planes, void *__restrict dst_, unsigne
 template <bool SMALL>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 awgn256_planes_kernel(const uint32_t *__restrict planes, u32x4 *__restrict stage, unsigned L, unsigned nlanes
-#ifdef BBB_EXPERIMENTS
-                      , unsigned long long *dbg, unsigned exp_flags      // 4: wave priority 0; 1: NO STORES (round 5: what the staging traffic costs this kernel, alone -- experiments/store_cost.py)
-#endif
 ) {
     const unsigned lane = threadIdx.x;
     const unsigned long long wave = blockIdx.x;
     const unsigned long long LG = wave * 64 + lane;
-#ifdef BBB_EXPERIMENTS
-    if (exp_flags & 4) __builtin_amdgcn_s_setprio(0); else
-#endif
     __builtin_amdgcn_s_setprio(3);
-#ifdef BBB_EXPERIMENTS
-    unsigned long long dbg_t0 = 0, dbg_r0 = 0;
-    if (dbg) { dbg_t0 = __builtin_amdgcn_s_memtime(); dbg_r0 = __builtin_amdgcn_s_memrealtime(); }
-#endif
     uint32_t a[256], b[256], pa[256], pb[256], cnt[8];
     if constexpr (SMALL) {
 #ifdef BBB_SMALL_THROTTLE
@@ -841,51 +807,25 @@ awgn256_planes_kernel(const uint32_t *__restrict planes, u32x4 *__restrict stage
 #pragma unroll 1
     for (unsigned t = 0; t < L; t += 2) {
         lutopt256_step_parked_hi(a, pa, b, pb, cnt);
-#ifdef BBB_EXPERIMENTS
-        if (exp_flags & 1) asm volatile("" :: "v"(cnt[0]), "v"(cnt[1]), "v"(cnt[2]), "v"(cnt[3]), "v"(cnt[4]), "v"(cnt[5]), "v"(cnt[6]), "v"(cnt[7])); else
-#endif
         {
         __builtin_nontemporal_store((u32x4){cnt[0], cnt[1], cnt[2], cnt[3]}, out);
         __builtin_nontemporal_store((u32x4){cnt[4], cnt[5], cnt[6], cnt[7]}, out + 64);
         }
         lutopt256_step_parked_hi(b, pb, a, pa, cnt);
-#ifdef BBB_EXPERIMENTS
-        if (exp_flags & 1) asm volatile("" :: "v"(cnt[0]), "v"(cnt[1]), "v"(cnt[2]), "v"(cnt[3]), "v"(cnt[4]), "v"(cnt[5]), "v"(cnt[6]), "v"(cnt[7])); else
-#endif
         {
         __builtin_nontemporal_store((u32x4){cnt[0], cnt[1], cnt[2], cnt[3]}, out + 128);
         __builtin_nontemporal_store((u32x4){cnt[4], cnt[5], cnt[6], cnt[7]}, out + 192);
         }
         out += 256;
     }
-#ifdef BBB_EXPERIMENTS
-    if (dbg && lane == 0) {
-        unsigned long long *d = dbg + 4 * wave;
-        d[0] = dbg_t0; d[1] = __builtin_amdgcn_s_memtime(); d[2] = dbg_r0; d[3] = __builtin_amdgcn_s_memrealtime();
-        dbg[4 * 1024 + wave] = 0;
-        unsigned hwid, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        dbg[5 * 1024 + wave] = ((hwid >> 4) & 0x3ff) | ((unsigned long long)(xcc & 15) << 10);      // simd, pipe, cu, sh, se | xcc
-    }
-#endif
 }
 
 int awgn256_planes_launch(const uint32_t *d_planes, void *stage, unsigned L, unsigned nlanes, hipStream_t st, bool small_footprint) {
     if (L & 1) return fail(BBB_EINVAL, "segment length must be even");
-#ifdef BBB_EXPERIMENTS
-    if (small_footprint)
-        hipLaunchKernelGGL(awgn256_planes_kernel<true>, dim3(nlanes / 64), dim3(64), 0, st, d_planes, (u32x4 *)stage, L, nlanes,
-                           (unsigned long long *)g_exp_awgn_debug, (unsigned)env_knob("BBB_EXP_PLANES_FLAGS", 0));
-    else
-        hipLaunchKernelGGL(awgn256_planes_kernel<false>, dim3(nlanes / 64), dim3(64), 0, st, d_planes, (u32x4 *)stage, L, nlanes,
-                           (unsigned long long *)g_exp_awgn_debug, (unsigned)env_knob("BBB_EXP_PLANES_FLAGS", 0));
-#else
     if (small_footprint)
         hipLaunchKernelGGL(awgn256_planes_kernel<true>, dim3(nlanes / 64), dim3(64), 0, st, d_planes, (u32x4 *)stage, L, nlanes);
     else
         hipLaunchKernelGGL(awgn256_planes_kernel<false>, dim3(nlanes / 64), dim3(64), 0, st, d_planes, (u32x4 *)stage, L, nlanes);
-#endif
     BBB_HIP(hipGetLastError());
     return BBB_OK;
 }
@@ -974,16 +914,6 @@ unplane_kernel(const u32x4 *__restrict stage, char *__restrict dst, unsigned lon
         }
         __syncthreads();      // (TT is overwritten by the first unit's phase 1; nothing is in flight yet, so the full barrier costs nothing)
     }
-#ifdef BBB_EXPERIMENTS
-    if (!TXM && tx.bits && lane == 0) {      // which SIMD this mover wave sits on, and when it ran
-        unsigned hwid, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        unsigned long long *d = (unsigned long long *)tx.bits + 6 * 1024 + 2 * ((blockIdx.x * 4 + wv) & 1023);
-        d[0] = (((hwid >> 4) & 0x3ff) | ((unsigned long long)(xcc & 15) << 10)) | (1ull << 63);
-        d[1] = __builtin_amdgcn_s_memrealtime();
-    }
-#endif
     // a unit's place: 8 lanes q8 of source wave w (relative to ge.w_lo), steps 128 rg ..; unit index = (w * 8 + q8) * ngroups + rg.
     // A block takes CONSECUTIVE units: the step groups of the same 8 lanes one after the other.  A generator's 128 bytes of a
     // unit are not aligned to the 128-byte lines of the stream unless L is a multiple of 128 (1e9 samples: L = 480); the rest
@@ -1059,27 +989,17 @@ unplane_kernel(const u32x4 *__restrict stage, char *__restrict dst, unsigned lon
     advance(nxt);
     unsigned buf = 0;
     bool fast1 = false;      // wave-uniform: the whole wave took the straight-line store path in the previous unit
-#ifdef BBB_EXPERIMENTS
-    // where a unit's time goes (experiments/mover_phases.py): shader-clock ticks summed per wave over its units
-    unsigned long long ph_t[6] = {0, 0, 0, 0, 0, 0}, ph_last = __builtin_amdgcn_s_memtime();
-#define BBB_PH(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph_t[i] += now_ - ph_last; ph_last = now_; }
-#else
-#define BBB_PH(i)
-#endif
     dma_unit(cur, 0);
     for (unsigned it = 0; it < n_it; it++, buf ^= 1) {
         const unsigned q8 = cur.q8, step0 = cur.rg * 128;
         const unsigned long long w = (unsigned long long)ge.w_lo + cur.w;
         const bool more1 = it + 1 < n_it;
         if (more1) dma_unit(nxt, buf ^ 1);
-        BBB_PH(0)
         // This unit's DMA must have landed.  vmcnt counts loads, DMA and stores together, in issue order.  Younger than this
         // unit's DMA are the previous unit's stores and the DMA just issued: with a KNOWN count (a straight-line unit issues
         // exactly NST store instructions per wave) they stay in flight; otherwise the wait covers the stores too.
         wait_vm((more1 ? NDMA : 0u) + (fast1 ? NST : 0u));
-        BBB_PH(1)
         __builtin_amdgcn_s_barrier();
-        BBB_PH(2)
         // ---- phase 1
         {
             const uint32_t *raw = lds + buf * (kUnplaneRaw / 4) + (qs * 8 + l8) * 4;
@@ -1102,9 +1022,7 @@ unplane_kernel(const u32x4 *__restrict stage, char *__restrict dst, unsigned lon
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        BBB_PH(3)
         __builtin_amdgcn_s_barrier();
-        BBB_PH(4)
         // ---- phase 2: row (4 k + wv) * 8 + lq = generator (w * 32 + 4 k + wv) * 64 + q8 * 8 + lq, its bytes step0 + 16 c2 ..
         const unsigned inseg = step0 + c2 * 16;
         const unsigned long long g0 = (w * 32 + wv) * 64 + q8 * 8 + lq;
@@ -1200,22 +1118,10 @@ unplane_kernel(const u32x4 *__restrict stage, char *__restrict dst, unsigned lon
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        BBB_PH(5)
         __builtin_amdgcn_s_barrier();           // the tile and raw[buf] are free for the next unit
-        BBB_PH(4)
         cur = nxt;
         advance(nxt);
     }
-#ifdef BBB_EXPERIMENTS
-    if (!TXM && tx.bits && lane == 0 && blockIdx.x * 4 + wv < 1024) {
-        // [7 * 1024 + ...] is beyond the 8 x 1024 buffer's stamps in use: [6*1024 .. 8*1024) holds the SIMD ids (2 per wave);
-        // the phase sums go to a second buffer handed over through tx.coeffs' place: see mover_phases.py
-        unsigned long long *d = (unsigned long long *)tx.bits + 8 * 1024 + 8 * (blockIdx.x * 4 + wv);
-        for (int i = 0; i < 6; i++) d[i] = ph_t[i];
-        d[6] = n_it;
-    }
-#endif
-#undef BBB_PH
 }
 
 static int unplane_launch_with(const void *stage, void *dst, uint64_t win_lo, uint64_t nbytes, unsigned L, uint64_t G, unsigned nlanes,
@@ -1255,9 +1161,6 @@ static int unplane_launch_with(const void *stage, void *dst, uint64_t win_lo, ui
                            (unsigned long long)win_lo, (unsigned long long)nbytes, L, (unsigned long long)G, ge, *tx);
     } else {
         TxFuse none{};
-#ifdef BBB_EXPERIMENTS
-        none.bits = (const uint32_t *)g_exp_awgn_debug;
-#endif
         hipLaunchKernelGGL(unplane_kernel<false>, dim3((unsigned)blocks), dim3(256), kUnplaneLds, st, (const u32x4 *)stage, (char *)dst,
                            (unsigned long long)win_lo, (unsigned long long)nbytes, L, (unsigned long long)G, ge, none);
     }
@@ -1558,9 +1461,6 @@ int awgn256_fill_launch(const uint32_t *d_planes, int8_t *dst, uint64_t nsamples
                         unsigned nlanes, hipStream_t st) {
     const unsigned nwaves = nlanes / 64;
     TxFuse none{};
-#ifdef BBB_EXPERIMENTS
-    none.bits = (const uint32_t *)g_exp_awgn_debug;      // per-wave time stamps, see the kernel
-#endif
     hipLaunchKernelGGL((awgn256_kernel<false>), dim3(nwaves), dim3(64), 0, st, d_planes, (void *)dst, (unsigned long long)nsamples, L,
                        (unsigned long long)G, nlanes, none);
     BBB_HIP(hipGetLastError());

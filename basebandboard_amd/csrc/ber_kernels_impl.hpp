@@ -40,13 +40,6 @@ enum { kBerFast = 0, kBerPair = 1, kBerGeneral = 2 };
 // ---------------------------------------------------------------------------------------------
 struct BerMasks { uint32_t m[kMaxCfg][32]; };   // fast: [c][0..7] tm, [c][8] eq; pair: [c][0..7] thr0, [8..15] thr1, [16] inv0, [17] inv1;
                                                 // general (one setting): [bv * 4 + i][0..7] tm, [..][8] enable, m[8][bv] inv
-#if defined(BBB_EXPERIMENTS) && BBB_BER_PART == 0
-__device__ unsigned long long g_ber_dbg[8 * 1024];      // per wave: kernel start, loop start, loop end, kernel end (s_memtime), the same four in s_memrealtime (100 MHz)
-extern "C" int bbb_exp_ber_debug_read(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ber_dbg), sizeof(g_ber_dbg)); }
-#define BBB_BER_STAMP(i) if (lane == 0 && wave < 1024) { g_ber_dbg[8 * wave + (i)] = __builtin_amdgcn_s_memtime(); g_ber_dbg[8 * wave + 4 + (i)] = __builtin_amdgcn_s_memrealtime(); }
-#else
-#define BBB_BER_STAMP(i)
-#endif
 struct TrialF {
     int32_t k, tap, ncfg, save;     // save: leave the generator's and the PRBS state behind (a continued trial)
     uint32_t L, last_len;
@@ -62,7 +55,6 @@ ber256_fused_kernel(BerMasks mk, uint32_t *__restrict planes, uint32_t *__restri
     const unsigned long long wave = blockIdx.x;
     const unsigned long long LG = wave * 64 + lane;
     __builtin_amdgcn_s_setprio(3);
-    BBB_BER_STAMP(0);
 
     // `planes` = the state OF the first sample (the host seeds one clock past the stream position: no advance in front of the
     // loop, and a continued trial -- bbb_ber_run_* -- finds the state this kernel left); the parked planes go straight to
@@ -137,10 +129,6 @@ ber256_fused_kernel(BerMasks mk, uint32_t *__restrict planes, uint32_t *__restri
     };
 
     auto compare = [&](const uint32_t pbit, const uint32_t valid) {
-#if defined(BBB_EXPERIMENTS) && defined(BBB_BER_X) && (BBB_BER_X & 2)
-        nerr[0] += __builtin_popcount((cnt[0] ^ cnt[1] ^ cnt[2] ^ cnt[3] ^ cnt[4] ^ cnt[5] ^ cnt[6] ^ cnt[7] ^ pbit) & valid);      // (timing experiment: no comparators)
-        return;
-#endif
         if constexpr (MODE == kBerFast) {
             uint32_t X[8];
 #pragma unroll
@@ -212,18 +200,13 @@ ber256_fused_kernel(BerMasks mk, uint32_t *__restrict planes, uint32_t *__restri
         }
     };
 
-    BBB_BER_STAMP(1);
 #pragma unroll 1
     for (unsigned t = 0; t < tk.L; t += 2) {
         const unsigned u = (t & 31u) * 64 + lane;
-#if defined(BBB_EXPERIMENTS) && defined(BBB_BER_X) && (BBB_BER_X & 1)
-        const uint32_t p0 = u * 0x9E3779B9u + ka, p1 = ~p0 + ta;        // (timing experiment: no PRBS ring)
-#else
         const uint32_t x0 = ring[u + ka], x1 = ring[u + ka + 64], y0 = ring[u + ta], y1 = ring[u + ta + 64];
         const uint32_t p0 = x0 ^ y0, p1 = x1 ^ y1;
         ring[u] = p0; ring[u + 64] = p1;
         ring[u + 32 * 64] = p0; ring[u + 33 * 64] = p1;
-#endif
         const uint32_t s0 = t >= tk.last_len ? ~0u : 0u, s1 = t + 1 >= tk.last_len ? ~0u : 0u;
         prefetch();
         lutopt256_step_parked_ber(a, pa, b, pb, cnt);
@@ -232,7 +215,6 @@ ber256_fused_kernel(BerMasks mk, uint32_t *__restrict planes, uint32_t *__restri
         lutopt256_step_parked_ber(b, pb, a, pa, cnt);
         compare(p1, __builtin_amdgcn_bitop3_b32(vm_all, vm_last, s1, 0x70));
     }
-    BBB_BER_STAMP(2);
 #undef BBB_SLOAD8
 #undef BBB_SLOAD8_AT
 #undef BBB_SWAIT2
@@ -258,7 +240,6 @@ ber256_fused_kernel(BerMasks mk, uint32_t *__restrict planes, uint32_t *__restri
             if (!lutopt256_ber_is_parked(p)) planes[(size_t)p * nlanes + LG] = a[p];
         for (int i = 0; i < tk.k; i++) prbs_planes[(size_t)i * nlanes + LG] = ring[((tk.L - 1u - (unsigned)i) & 31u) * 64 + lane];
     }
-    BBB_BER_STAMP(3);
     (void)mk;
 }
 

@@ -125,19 +125,11 @@ __device__ __forceinline__ void xor_inplace(u32x4 &a, const u32x4 &b) {
 // stores non-temporal (no gain in round 1).
 template <typename T>
 __device__ __forceinline__ T check_load(const T *p) {
-#if defined(BBB_EXPERIMENTS) && defined(BBB_PRBS_CHECK_PLAIN)
-    return *p;
-#else
     return __builtin_nontemporal_load(p);
-#endif
 }
 template <typename T>
 __device__ __forceinline__ void fill_store(T *p, const T &v) {
-#if defined(BBB_EXPERIMENTS) && defined(BBB_PRBS_FILL_NT)
-    __builtin_nontemporal_store(v, p);
-#else
     *p = v;
-#endif
 }
 
 // LW = true keeps the K-row window in (lane-private) LDS instead of registers: the checker then
