@@ -628,13 +628,15 @@ det_sparse_kernel(const u64 *__restrict src, const u64 *__restrict flags, u64 nb
 // CU (latency-bound lanes beside a memory-bound stream), the flags never travel through memory, and the few words a lane
 // goes back to were read by its own wave microseconds earlier.  Needs chunks of whole 128-word flag blocks and a warm-up of
 // at most one; other geometries take the two kernels above.
-constexpr int kDetFusedMaxChunkWords = 512;
+constexpr int kDetFusedMaxChunkWords = 1024;
 template <int K>
 __global__ void __launch_bounds__(256)
 det_fused_kernel(const u64 *__restrict src, u64 nbits, u64 nwords, u64 chunk_words, u64 warm_words, u64 nchunks,
                  DetState *__restrict spec, DetState *__restrict endst, DetCount *__restrict counts, u64 *__restrict err,
                  u64 *__restrict reload) {
-    __shared__ __attribute__((aligned(16))) u64 lflags[4][kDetFusedMaxChunkWords + 8];      // 2 words per 128-word block of the region, + slack
+    // 2 flag words per 128-word block of a wave's region (64 chunks + the block in front), + slack: DYNAMIC, sized by the chunk length
+    // (round 5: chunks of up to 1024 words; a static array for the largest would cost the shorter ones two blocks per CU)
+    extern __shared__ __attribute__((aligned(16))) u64 lflags_dyn[];
     const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const u64 c0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x - lane);                    // the wave's first chunk
     if (c0 >= nchunks) return;
@@ -642,7 +644,7 @@ det_fused_kernel(const u64 *__restrict src, u64 nbits, u64 nwords, u64 chunk_wor
     const u64 r0 = c0 ? c0 * chunk_words - 128 : 0;                                        // region: one block in front of the first chunk ...
     const u64 r1e = (c0 + 64) * chunk_words;
     const u64 r1 = r1e < nwords ? r1e : nwords;                                            // ... to the end of the last
-    u64 *const lf = lflags[wv];
+    u64 *const lf = lflags_dyn + (size_t)wv * (chunk_words + 8);
     {
         // two steps (4 KiB per wave) of loads in flight beyond the one being judged
         u64 base = r0;
@@ -961,8 +963,8 @@ static int detector_stream_k(const u64 *src, u64 nbits, u64 *err, u64 *reload, b
             const unsigned cgrid = (unsigned)((nblk + 3) / 4 < 8192 ? (nblk + 3) / 4 : 8192);
             static const bool two_kernels = env_knob("BBB_DET_TWO_KERNELS", 0) != 0;      // (A/B timing; -DBBB_EXPERIMENTS only)
             if (chunk_words % 128 == 0 && chunk_words <= (u64)kDetFusedMaxChunkWords && warm_words <= 128 && !two_kernels) {
-                hipLaunchKernelGGL(det_fused_kernel<K>, dim3(grid), dim3(256), 0, st, src, nbits, nwords, chunk_words, warm_words, nchunks,
-                                   spec, endst, counts, err, reload);
+                hipLaunchKernelGGL(det_fused_kernel<K>, dim3(grid), dim3(256), 4 * (chunk_words + 8) * sizeof(u64), st, src, nbits, nwords, chunk_words,
+                                   warm_words, nchunks, spec, endst, counts, err, reload);
             } else {
                 hipLaunchKernelGGL(det_classify_kernel<K>, dim3(cgrid), dim3(256), 0, st, src, nbits, nwords, flags);
                 hipLaunchKernelGGL(det_sparse_kernel<K>, dim3(grid), dim3(256), 0, st, src, (const u64 *)flags, nbits, nwords, chunk_words,
@@ -1112,6 +1114,23 @@ int prbs_detector_stream_launch(int k, const uint64_t *src, uint64_t nbits, uint
         // changed nothing measurable: 0.455-0.46 ms either way.)
         const uint64_t want = (nbits / 262144 + 127) / 128 * 128;
         chunk_bits = want < 4096 ? 4096 : (want > 32768 ? 32768 : want);
+        if (want > 32768) {
+            // Long streams (round 5; profiles/r05_det_chunk_sweep.log): the fused kernel takes chunks of 512 ... 1024 words, a block
+            // four waves x 64 chunks, and all blocks are resident at once -- the kernel then takes as long as the CU with the MOST
+            // blocks, so the chunk length is chosen for the smallest (blocks on the fullest CU) x (words per chunk); ties go to the
+            // longer chunk (fewer chunk records, fewer speculative starts).  1e10 bits: 640 words (954 blocks on 256 CUs: 4 x 640)
+            // where round 4's fixed 512 gave 1192 blocks (5 x 512): 0.277 -> 0.258 ms per call.
+            int dev = 0, ncu = 256;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1) ncu = 256;
+            const uint64_t nwords = (nbits + 63) / 64;
+            uint64_t best_cost = ~0ull, best_cw = 512;
+            for (uint64_t cw = 512; cw <= (uint64_t)kDetFusedMaxChunkWords; cw += 128) {
+                const uint64_t nblocks = ((nwords + cw - 1) / cw + 255) / 256;
+                const uint64_t cost = ((nblocks + (uint64_t)ncu - 1) / (uint64_t)ncu) * cw;
+                if (cost <= best_cost) { best_cost = cost; best_cw = cw; }
+            }
+            chunk_bits = best_cw * 64;
+        }
     }
     if (warm_bits == 0) warm_bits = 1024;
     if (chunk_bits % 64) return fail(BBB_EINVAL, "chunk_bits must be a multiple of 64");

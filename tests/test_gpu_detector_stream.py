@@ -60,7 +60,8 @@ def test_reference_test_protocol_at_scale(gpu, oracle, k, ber):
     assert got["resyncs"] >= 2
 
 
-@pytest.mark.parametrize("chunk_bits,warm_bits", [(64, 64), (128, 64), (640, 128), (4096, 64), (4096, 1024), (65536, 256)])
+@pytest.mark.parametrize("chunk_bits,warm_bits", [(64, 64), (128, 64), (640, 128), (4096, 64), (4096, 1024), (65536, 256),
+                                                  (40960, 1024), (57344, 1024), (65536, 1024)])      # (round 5: the fused kernel's longer chunks)
 def test_chunking_never_changes_the_result(gpu, oracle, chunk_bits, warm_bits):
     """Short warm-ups make many speculative starts wrong: the verify / re-run passes must repair all of them."""
     k, nbits = 31, 700_003
