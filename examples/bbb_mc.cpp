@@ -3,7 +3,7 @@
 // Build: make -C examples   (hipcc, links ../basebandboard_amd/libbbb_hip.so)
 //
 //   bbb_mc [--matrix FILE] [--init HEX] [--gpus N] [--json 1]
-//          BER sweep:   [--prbs 31] [--bits 1e9] [--nv 8] [--ebn0 A:B:STEP] [--seeds N] [--shard bits|seeds|trials]
+//          BER sweep:   [--prbs 31] [--bits 1e9] [--nv 8] [--ebn0 A:B:STEP] [--seeds N] [--shard bits|seeds|trials|groups]
 //          AWGN fill:   --nsamples 1e9 [--steps 5] [--staged 0|1|m]   the sample stream drained through bbb_awgn_stream_next;
 //                       --staged picks the level of bbb_lutopt_set_staged for it (default: the stream's own choice, two reads
 //                       per sample kernel; 0 = plain bbb_awgn_fill_i8 calls in the one-kernel form)
@@ -21,7 +21,8 @@
 //            all-reduce of the uint64 counters.  --shard bits (default): every device runs every point over its
 //            slice of the bit range, the counters equal the 1-GPU counters exactly; seeds: device d runs every
 //            point on its own seed (below), counters summed (points x seeds, BASELINE configs[4]); trials: point i
-//            on device i % N.  AWGN fill: device d reads stream positions [16 + 2^48 d + s n, +n) in step s -- its own
+//            on device i % N; groups (with --seeds S): the sweep once per seed as ONE call of S x points trials, a seed's
+//            sweep on one device (group q on device q % N: configs[4] as eight sweeps on one device, one each on eight).  AWGN fill: device d reads stream positions [16 + 2^48 d + s n, +n) in step s -- its own
 //            contiguous stretch of the one sequential stream, no collective.
 // --multi 1  take the bbb_ber_sweep_multi route (RCCL) even with --gpus 1.
 // --seeds N  (1 GPU) repeat the sweep on N seeds and sum the counters.  Seed d = the reset state `init` advanced 2^48 d
@@ -177,7 +178,8 @@ int main(int argc, char **argv) {
     int mode = BBB_SHARD_BITS;
     if (shard == "seeds") mode = BBB_SHARD_SEEDS;
     else if (shard == "trials") mode = BBB_SHARD_TRIALS;
-    else if (shard != "bits") { std::fprintf(stderr, "--shard bits|seeds|trials\n"); return 2; }
+    else if (shard == "groups") mode = BBB_SHARD_GROUPS;
+    else if (shard != "bits") { std::fprintf(stderr, "--shard bits|seeds|trials|groups\n"); return 2; }
     if (seeds < 1 || init0 == 0 || gpus < 1 || step <= 0 || steps < 1) { std::fprintf(stderr, "bad --seeds / --init / --gpus / --step / --steps\n"); return 2; }
     int ndev_seen = 0;
     CHECK(bbb_device_count(&ndev_seen));
@@ -291,6 +293,19 @@ int main(int argc, char **argv) {
         c.nbits = (uint64_t)bits;
         cfg.push_back(c);
     }
+    // --shard groups (BASELINE configs[4] as ONE call): the sweep once per seed -- the seeds as stretches of the one cycle 2^48
+    // clocks apart, all on the same reset state -- as --seeds groups of consecutive trials; a group stays on one device
+    // (bbb_ber_sweep_multi, BBB_SHARD_GROUPS: group q on device q mod N), the rows below are the sums over the seeds
+    const size_t npoints = cfg.size();
+    if (mode == BBB_SHARD_GROUPS) {
+        for (int sd = 1; sd < seeds; sd++)
+            for (size_t i = 0; i < npoints; i++) {
+                bbb_trial_cfg c = cfg[i];
+                c.warmup = 16 + ((uint64_t)sd << 48);
+                cfg.push_back(c);
+            }
+    }
+    const int group_seeds = seeds;
     std::vector<bbb_ber> out(cfg.size()), part(cfg.size());
     double ms = 0;
     const char *reduce = "single device";
@@ -321,7 +336,16 @@ int main(int argc, char **argv) {
         for (auto *h : hs) CHECK(bbb_lutopt_destroy(h));
         CHECK(bbb_multi_release());
         reduce = "ncclAllReduce(uint64[2 x points], sum) over the devices of this process";
-        seeds = mode == BBB_SHARD_SEEDS ? gpus : 1;
+        seeds = mode == BBB_SHARD_SEEDS ? gpus : (mode == BBB_SHARD_GROUPS ? group_seeds : 1);
+        if (mode == BBB_SHARD_GROUPS) {                                  // fold the seeds' rows into the points'
+            for (int sd = 1; sd < group_seeds; sd++)
+                for (size_t i = 0; i < npoints; i++) { out[i].bits += out[(size_t)sd * npoints + i].bits; out[i].errors += out[(size_t)sd * npoints + i].errors; }
+            out.resize(npoints);
+            cfg.resize(npoints);
+        }
+    } else if (mode == BBB_SHARD_GROUPS) {
+        std::fprintf(stderr, "--shard groups runs through bbb_ber_sweep_multi: add --multi 1 (one device) or --gpus N\n");
+        return 2;
     } else {
         bbb_lutopt *h = nullptr;
         for (int sd = 0; sd < seeds; sd++) {

@@ -301,6 +301,19 @@ def test_cli_json_multi_and_awgn_modes(gpu, oracle):
         assert a["samples_per_launch"] == per and a["gsample_s"] > 0 and a["head"] == m.awgn(1, 16, 64, fast=True).tolist()
     r = subprocess.run([str(exe), "--gpus", "64"], cwd=str(ROOT), capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "visible" in r.stderr
+    # --shard groups: BASELINE configs[4]'s shape as ONE call -- the sweep once per seed (stretches of the one cycle 2^48 apart) as groups
+    # that stay on one device; the rows are the sums over the seeds, here three seeds on the one device, against the oracle
+    r = subprocess.run([str(exe), "--bits", "200000", "--ebn0", "2:6:2", "--json", "1", "--multi", "1", "--shard", "groups", "--seeds", "3"],
+                       cwd=str(ROOT), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = [json.loads(l) for l in r.stdout.strip().splitlines()]
+    pts = [l for l in lines if "ebn0_db" in l]
+    u = gpu.LUTOPT.shipped(256)
+    for p in pts:
+        want = [m.ber_trial(u.state_at(s << 48) if s else 1, 31, 1, p["amp"], 8, 16, 0, 200_000) for s in range(3)]
+        assert (p["bits"], p["errors"]) == (sum(b for b, _ in want), sum(e for _, e in want))
+    summ = [l for l in lines if l.get("mode") == "ber_sweep"][0]
+    assert summ["seeds"] == 3 and summ["shard"] == "groups" and summ["equals_single_device_counters"] is True and summ["total_bits"] == 3 * 3 * 200_000
 
 
 def test_thread_per_device_body_rehearsed_on_one_gpu():
