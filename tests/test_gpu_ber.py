@@ -306,7 +306,7 @@ def test_cli_json_multi_and_awgn_modes(gpu, oracle):
     r = subprocess.run([str(exe), "--bits", "200000", "--ebn0", "2:6:2", "--json", "1", "--multi", "1", "--shard", "groups", "--seeds", "3"],
                        cwd=str(ROOT), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
-    lines = [json.loads(l) for l in r.stdout.strip().splitlines()]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]      # (RCCL prints its banner to stdout)
     pts = [l for l in lines if "ebn0_db" in l]
     u = gpu.LUTOPT.shipped(256)
     for p in pts:
