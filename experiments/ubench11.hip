@@ -104,6 +104,75 @@ __global__ void __launch_bounds__(64) rd(const char *buf, unsigned long long tot
     }
     if (acc.x == 0x12345678u && acc.y == 0x9abcdef0u) sink[0] = 1;
 }
+// the shipped checker's shape: 8-byte lanes, passes of 31 rows in batches of 16 + 15 (the second in flight while the first is compared),
+// a popcount of the XOR with a register window per row; LW 16: the same with 16-byte lanes (batches of 8 rows)
+template <int LW>
+__global__ void __launch_bounds__(64, 2) rd_prbs(const char *buf, unsigned long long total, unsigned long long chunk, unsigned long long *sink) {
+    constexpr int K = 31, NW = LW / 4, DB = LW == 8 ? 16 : 8;
+    const unsigned lane = threadIdx.x;
+    const unsigned long long lo = (unsigned long long)blockIdx.x * chunk, hi = lo + chunk < total ? lo + chunk : total;
+    uint32_t V[K][NW];
+#pragma unroll
+    for (int i = 0; i < K; i++)
+#pragma unroll
+        for (int w = 0; w < NW; w++) V[i][w] = lane * 2654435761u + i * 40503u + w;
+    constexpr unsigned ROW = 64 * LW;
+    unsigned errs = 0;
+    const long long npass = (long long)((hi - lo) / ((unsigned long long)K * ROW));
+    for (long long ps = npass - 1; ps >= 0; ps--) {
+        const char *rowp = buf + lo + (unsigned long long)ps * K * ROW + lane * LW;
+#pragma unroll
+        for (int i = K - 1; i >= 0; i--)
+#pragma unroll
+            for (int w = 0; w < NW; w++) asm("v_xor_b32 %0, %0, %1" : "+v"(V[i][w]) : "v"(V[(i + K - 3) % K][w]));
+        uint32_t D[2][DB][NW];
+        auto load = [&](int b, int slot) {
+#pragma unroll
+            for (int i = 0; i < DB; i++) {
+                const int r = b * DB + i;
+                if (r < K) {
+                    if (LW == 8) { const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(rowp + (unsigned long long)r * ROW)); D[slot][i][0] = v.x; D[slot][i][1 % NW] = v.y; }
+                    else { const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(rowp + (unsigned long long)r * ROW)); D[slot][i][0] = v.x; D[slot][i][1 % NW] = v.y; D[slot][i][2 % NW] = v.z; D[slot][i][3 % NW] = v.w; }
+                }
+            }
+        };
+        constexpr int NB = (K + DB - 1) / DB;
+        load(0, 0);
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            if (b + 1 < NB) load(b + 1, (b + 1) & 1);
+#pragma unroll
+            for (int i = 0; i < DB; i++) {
+                const int r = b * DB + i;
+                if (r < K)
+#pragma unroll
+                    for (int w = 0; w < NW; w++) errs += __builtin_popcount(D[b & 1][i][w] ^ V[r][w]);
+            }
+        }
+    }
+    if (errs == 0x12345678u) sink[0] = 1;
+}
+template <int LW> void run_rd_prbs(const char *name, char *buf, unsigned long long total, unsigned long long *sink) {
+    const unsigned long long unit = 31ull * 64 * LW;
+    const unsigned long long chunk = ((total + 1023) / 1024 + unit - 1) / unit * unit;
+    const unsigned grid = (unsigned)((total + chunk - 1) / chunk);
+    const unsigned long long wchunk = ((total + 1023) / 1024 + 16383) / 16384 * 16384;
+    const unsigned wgrid = (unsigned)((total + wchunk - 1) / wchunk);
+    hipEvent_t e[4]; for (auto &x : e) hipEventCreate(&x);
+    float w = 0, rb = 0, rc = 0;
+    for (int rep = 0; rep < 7; rep++) {
+        hipEventRecord(e[0]);
+        hipLaunchKernelGGL((wr<0, false>), dim3(wgrid), dim3(64), 0, 0, buf, total, wchunk);
+        hipEventRecord(e[1]);
+        hipLaunchKernelGGL(rd_prbs<LW>, dim3(grid), dim3(64), 0, 0, buf, total, chunk, sink);
+        hipEventRecord(e[2]);
+        hipLaunchKernelGGL(rd_prbs<LW>, dim3(grid), dim3(64), 0, 0, buf, total, chunk, sink);
+        hipEventRecord(e[3]); hipEventSynchronize(e[3]);
+        float a, b, c; hipEventElapsedTime(&a, e[0], e[1]); hipEventElapsedTime(&b, e[1], e[2]); hipEventElapsedTime(&c, e[2], e[3]);
+        if (rep >= 2) { w += a / 5; rb += b / 5; rc += c / 5; }
+    }
+    printf("%-44s write %.4f ms | checker-shaped read behind it %.4f ms (%.2f TB/s) | again (clean) %.4f ms (%.2f)\n", name, w, rb, total / rb / 1e9, rc, total / rc / 1e9);
+}
 template <int FL, bool RND = false> void run(const char *name, char *buf, unsigned long long total, unsigned long long *sink) {
     const unsigned long long chunk = ((total + 1023) / 1024 + 16383) / 16384 * 16384;
     const unsigned grid = (unsigned)((total + chunk - 1) / chunk);
@@ -135,14 +204,9 @@ int main() {
     hipMalloc(&buf, total + 65536); hipMalloc(&sink, 8);
     hipMemset(buf, 1, total);
     for (int pass = 0; pass < 2; pass++) {
-        run_prbs<8, false>("PRBS-shaped, 8 B lanes, C++ stores", buf, total);
-        run_prbs<8, true>("PRBS-shaped, 8 B lanes, asm stores", buf, total);
-        run_prbs<16, false>("PRBS-shaped, 16 B lanes, C++ stores", buf, total);
-        run_prbs<16, true>("PRBS-shaped, 16 B lanes, asm stores", buf, total);
-        run_prbs<8, true, true>("PRBS-shaped, 8 B lanes, store behind its XOR", buf, total);
-        run_prbs<16, true, true>("PRBS-shaped, 16 B lanes, store behind its XOR", buf, total);
         run<0>("store", buf, total, sink);
-        run<0, true>("store, random data", buf, total, sink);
+        run_rd_prbs<8>("checker-shaped reader, 8 B lanes", buf, total, sink);
+        run_rd_prbs<16>("checker-shaped reader, 16 B lanes", buf, total, sink);
         run<1>("store nt", buf, total, sink);
     }
     return 0;
