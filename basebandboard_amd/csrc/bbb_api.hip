@@ -414,14 +414,28 @@ int prepare_planes(bbb_lutopt *h, uint64_t first, uint64_t L, uint64_t G, unsign
     JumpPlan *plan;
     int rc = get_plan(h, L, &plan);
     if (rc) return rc;
-    if ((rc = grow(&h->d_states, &h->states_cap, (size_t)G * h->W32))) return rc;
+    // the shipped n256 matrix (or a k = 256 matrix with its own kernels): the two-launch seeding of the BER trials (round 5: head +
+    // plane-writing tail, 85 us instead of 160).  This is the seeding that nothing hides -- a fill that was not announced derives its
+    // start states in line, in front of its own sample kernel; announced fills keep the level chain, which is built to run as a
+    // guest beside the previous sample kernel and its mover (8-16 KiB of LDS per block; the head kernel takes 64)
+    // (BBB_EXP_SEED_CHAIN=1, experiments build: the level chain here as well, for the A/B of experiments/r05_unhinted.py)
+    const bool two_launch = h->k == 256 && (h->specialised || h->custom_fill) && !h->fast512 && G <= ((uint64_t)kSeedTopTables + 1) * 65536 &&
+                            !env_knob("BBB_EXP_SEED_CHAIN", 0);
+    const size_t states_words = two_launch && (size_t)G * h->W32 < (size_t)65536 * 8 ? (size_t)65536 * 8 : (size_t)G * h->W32;
+    if ((rc = grow(&h->d_states, &h->states_cap, states_words))) return rc;
     if ((rc = grow(&h->d_planes, &h->planes_cap, (size_t)2 * h->k * nlanes))) return rc;
     uint64_t s0[8];
     h->pw->apply(first, h->init, s0);
     uint32_t s16[256];
     first16(*plan, s0, s16);
     h->planes_valid = false;
-    rc = awgn_seed_launch(h->k, plan->d_cols, s16, G, h->d_states, G, nlanes, h->d_planes, h->cs);
+    if (two_launch) {
+        if ((rc = ensure_top_tables(plan))) return rc;
+        if ((rc = awgn_seed_head_launch(h->k, plan->d_cols, s16, G, h->d_states, h->cs))) return rc;
+        rc = awgn_seed_tail_planes_launch(h->k, plan->d_top, G, h->d_states, nlanes, h->d_planes, h->cs);
+    } else {
+        rc = awgn_seed_launch(h->k, plan->d_cols, s16, G, h->d_states, G, nlanes, h->d_planes, h->cs);
+    }
     if (rc) return rc;
     if ((rc = mark_planes_read(h))) return rc;
     h->planes_valid = true;

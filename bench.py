@@ -530,8 +530,8 @@ def main():
         noise = torch.randint(0, 1000, (pbuf.numel(),), device=pbuf.device) == 0
         pbuf ^= noise.to(torch.int64) << 13
         del noise
-        for _ in range(3):                      # (workspace, pinned read-back buffer, clocks: the first call takes 2 ms, the second 0.34)
-            det.run_stream(pbuf, nbits)
+        for _ in range(40):                     # (workspace, pinned read-back buffer -- the first call takes 2 ms, the second 0.34 -- and the clocks:
+            det.run_stream(pbuf, nbits)         #  every call synchronises, and the calls speed up over the first dozen: profiles/r05_det_chunk_sweep.log)
         torch.cuda.synchronize()
         tds = []
         for _ in range(6):
