@@ -6,6 +6,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import basebandboard_amd as bbb
+if os.environ.get("EXP"): bbb._lib.select_build("experiments")
 from basebandboard_amd import channel, _lib
 u = bbb.LUTOPT.shipped(256)
 nv = 8

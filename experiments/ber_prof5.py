@@ -4,6 +4,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, basebandboard_amd as g
 from basebandboard_amd import channel
+if os.environ.get("EXP"): g._lib.select_build("experiments")
 u = g.LUTOPT.shipped(256)
 nv = 8
 for i in range(4):
