@@ -323,9 +323,6 @@ seed_head_kernel(const uint32_t *__restrict tabs, Seed16 s, int k, unsigned long
 }
 
 // k = 256 only (W32 = 8: the 32 KiB table holds four state words' worth of plane rows at a time)
-// GW: the lookups of the LAST GW state words (8 nibbles each) go to the table in global memory instead of LDS -- the two paths add
-// (LDS 128 B per clock and CU, the vector cache 64): see awgn_seed_tail_planes_launch for what was measured
-template <int GW>
 __global__ void __launch_bounds__(256, 4)       // <= 128 registers: the 1022 blocks of a 1e9-bit trial are resident together, four per CU
 seed_tail_planes_kernel(const uint32_t *__restrict top, unsigned long long G, unsigned long long stride, const uint32_t *__restrict S,
                         unsigned nlanes, uint32_t *__restrict planes) {
@@ -367,9 +364,8 @@ seed_tail_planes_kernel(const uint32_t *__restrict top, unsigned long long G, un
             deposit(x, r);
         }
     } else {
-        const uint32_t *const gtab = top + (size_t)(d - 1) * nt;
         {
-            const u4 *src = reinterpret_cast<const u4 *>(gtab);
+            const u4 *src = reinterpret_cast<const u4 *>(top + (size_t)(d - 1) * nt);
             u4 *dstp = reinterpret_cast<u4 *>(tab);
             constexpr int n4 = nt / 4;
 #pragma unroll
@@ -403,14 +399,8 @@ seed_tail_planes_kernel(const uint32_t *__restrict top, unsigned long long G, un
                     const uint32_t v0 = (xw >> (4 * q)) & 15u, v1 = (xw >> (4 * q + 4)) & 15u;
 #pragma unroll
                     for (int zc = 0; zc < 2; zc++) {
-                        u4 e0, e1;
-                        if (w >= W32 - GW) {
-                            e0 = *reinterpret_cast<const u4 *>(gtab + ((n0 * 2 + zc) * 16 + v0) * 4);
-                            e1 = *reinterpret_cast<const u4 *>(gtab + ((n1 * 2 + zc) * 16 + v1) * 4);
-                        } else {
-                            e0 = *reinterpret_cast<const u4 *>(tab + ((n0 * 2 + zc) * 16 + v0) * 4);
-                            e1 = *reinterpret_cast<const u4 *>(tab + ((n1 * 2 + zc) * 16 + v1) * 4);
-                        }
+                        const u4 e0 = *reinterpret_cast<const u4 *>(tab + ((n0 * 2 + zc) * 16 + v0) * 4);
+                        const u4 e1 = *reinterpret_cast<const u4 *>(tab + ((n1 * 2 + zc) * 16 + v1) * 4);
 #pragma unroll
                         for (int zz = 0; zz < 4; zz++) y[zc * 4 + zz] = __builtin_amdgcn_bitop3_b32(y[zc * 4 + zz], e0[zz], e1[zz], 0x96);
                     }
@@ -1417,13 +1407,8 @@ int awgn_seed_tail_planes_launch(int k, const uint32_t *d_top, uint64_t G, const
     if (k != 256 || G > ((uint64_t)kSeedTopTables + 1) * 65536 || !d_top || (uint64_t)nlanes * 32 < G || nlanes % 64)
         return fail(BBB_EINVAL, "two-launch seeding: k = 256, at most 2^21 generators");
     const size_t lds = (size_t)64 * 16 * 8 * sizeof(uint32_t);                    // one table: 32 KiB
-    // (BBB_EXP_TAIL_GLOBAL_WORDS=2, experiments build: a quarter of the lookups through the vector cache)
-    if (env_knob("BBB_EXP_TAIL_GLOBAL_WORDS", 0) == 2)
-        hipLaunchKernelGGL(seed_tail_planes_kernel<2>, dim3(nlanes / 64), dim3(256), lds, st, d_top, (unsigned long long)G, 65536ull, d_states,
-                           nlanes, d_planes);
-    else
-        hipLaunchKernelGGL(seed_tail_planes_kernel<0>, dim3(nlanes / 64), dim3(256), lds, st, d_top, (unsigned long long)G, 65536ull, d_states,
-                           nlanes, d_planes);
+    hipLaunchKernelGGL(seed_tail_planes_kernel, dim3(nlanes / 64), dim3(256), lds, st, d_top, (unsigned long long)G, 65536ull, d_states,
+                       nlanes, d_planes);
     BBB_HIP(hipGetLastError());
     return BBB_OK;
 }
