@@ -7,6 +7,9 @@ import basebandboard_amd as bbb
 from basebandboard_amd import _lib
 if len(sys.argv) > 1 and sys.argv[1] == "exp":
     _lib.select_build("experiments")
+elif len(sys.argv) > 1 and sys.argv[1].endswith(".so"):      # a one-off variant library (experiments/build_variant.py)
+    import pathlib
+    _lib.LIB_PATH = pathlib.Path(sys.argv[1]).resolve()
 N = 1_000_000_000
 dev = "cuda:0"
 ev = lambda: torch.cuda.Event(enable_timing=True)
