@@ -89,3 +89,11 @@ for mb in 64 16; do
   $B mallread$mb $F "$SB" "        const char *const sb = reinterpret_cast<const char *>(stage) + ((((wabs * L + step0) * 128 + p.q8 * 8) * 16) & ((${mb}ull << 20) - 1));"
 done
 # (split8: every 16-byte staging store as two 8-byte stores -- twice the store instructions, the same bytes; built by hand, see profiles/r05_stream_variants.log)
+# the mover's ACCESS PATTERN: every unit written / read as one contiguous 32 KiB block (wrong places, the same bytes)
+P1C='                    *reinterpret_cast<u32x4 *>(dst + ((unsigned long long)(u0 + it) * 32768ull + ((k * 4 + wv) * 8 + lq) * 128 + c2 * 16) % (nbytes_ & ~0xffffull)) = v;
+                    off += goff;'
+R1='                __builtin_amdgcn_global_load_lds((const void *)(pl + ((k & 3) * 32 * 2048 + (k >> 2) * 1024)),'
+R1C='                __builtin_amdgcn_global_load_lds((const void *)(reinterpret_cast<const char *>(stage) + (((wabs * ge.ngroups * 8 + p.q8 * ge.ngroups + p.rg) * 32768ull) % (1ull << 30)) + wv * 8192 + k * 1024 + lane * 16),'
+$B mvcontig $F "$P1" "$P1C"
+$B rdcontig $F "$R1" "$R1C"
+$B bothcontig $F "$P1" "$P1C" "$R1" "$R1C"
