@@ -53,6 +53,18 @@ HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/
 VALU_OPS_PER_SAMPLE = None       # filled from the generated network's op count
 
 
+def stream_clock_record():
+    """profiles/r05_stream_clock.json: what the sample kernel's clock is inside the noise stream as shipped, without its staging stores
+    and without the mover (round 5) -- None when the file is absent"""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_stream_clock.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        return {"source": "profiles/r05_stream_clock.json", **rec["variants"]}
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def cpu_baseline():
     """Time the oracle's k=256 fast path on this host (checker code used as the reported CPU baseline only).
     Bounded sample: every core this process may use generates 2e7 samples of the stream at its own offset
@@ -883,7 +895,10 @@ def main():
                          "streaming_fill_gb_s": round(fill_gbs, 1) if fill_gbs else None,
                          "frac_of_streaming_fill": round(achieved / fill_gbs, 4) if fill_gbs else None,
                          "true_bound": "integer VALU issue (bit-sliced XOR / majority network) and, with the guests beside it, the chip's power "
-                                       "limit (the shader clock sits at 2.1-2.2 GHz under this load, 2.37 for the kernel alone: profiles/README.md), not HBM",
+                                       "limit (the shader clock sits at 2.2 GHz under this load, 2.39 with either the staging stores or the mover's "
+                                       "traffic taken away: `clock_in_stream`), not HBM",
+                         # committed measurement (per-wave clock stamps in one-off variants of the product kernel), not taken live
+                         "clock_in_stream": stream_clock_record(),
                          "valu_lane_ops_per_sample": round(ops_per_step / 32.0, 2),
                          "valu_issued_per_step_and_wave": round(issued_per_step, 1), "valu_issued_source": issued_src,
                          "valu_net_tlaneops_s": round(net_t, 2),
