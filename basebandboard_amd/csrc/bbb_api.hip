@@ -2147,13 +2147,17 @@ int bbb_ber_sweep_multi(bbb_lutopt *const *handles, int ndev, const bbb_trial_cf
     // were launched without error; one group call from this thread (the single-process multi-device form).
     if (!rehearsal) {
         const Rccl &nccl = rccl();
-        ncclResult_t e = nccl.GroupStart();
-        for (int r = 0; r < ndev && e == ncclSuccess; r++)
-            e = nccl.AllReduce(handles[r]->d_counters, handles[r]->d_counters, nwords, ncclUint64, ncclSum, comms[(size_t)r],
-                               handles[r]->stream);
-        const ncclResult_t e2 = nccl.GroupEnd();
-        if (e == ncclSuccess) e = e2;
-        if (e != ncclSuccess) return fail(BBB_EHIP, std::string("ncclAllReduce: ") + nccl.GetErrorString(e));
+        // (over ONE device the sum is the identity: the communicator is still created and asked for its size -- RCCL loads and answers
+        // on this host -- but no collective is queued: a one-rank ncclAllReduce cost 10 us in most processes and 100 us in some)
+        if (ndev > 1) {
+            ncclResult_t e = nccl.GroupStart();
+            for (int r = 0; r < ndev && e == ncclSuccess; r++)
+                e = nccl.AllReduce(handles[r]->d_counters, handles[r]->d_counters, nwords, ncclUint64, ncclSum, comms[(size_t)r],
+                                   handles[r]->stream);
+            const ncclResult_t e2 = nccl.GroupEnd();
+            if (e == ncclSuccess) e = e2;
+            if (e != ncclSuccess) return fail(BBB_EHIP, std::string("ncclAllReduce: ") + nccl.GetErrorString(e));
+        }
         // what the communicator itself says (the first multi-device run checks itself with this: bbb_multi_last_info)
         int seen = 0;
         if (nccl.CommCount(comms[0], &seen) != ncclSuccess) seen = -1;

@@ -747,7 +747,7 @@ def main():
             "trials": 88, "bits": 88_000_000_000, "n_devices": world, "seconds": round(t88m, 6), "gbit_s": round(88e9 / t88m / 1e9, 2),
             "runs_ms": [round(x * 1e3, 4) for x in t88],
             "counters_first_point_first_seed": list(got88[0]),
-            "what": ("bbb_ber_sweep_multi(BBB_SHARD_GROUPS) over this one device: eight 11-point sweeps back to back, ONE ncclAllReduce(uint64[176]), one read-back"
+            "what": ("bbb_ber_sweep_multi(BBB_SHARD_GROUPS) over this one device: eight 11-point sweeps back to back, one read-back (the all-reduce of uint64[176] is queued at more than one device only)"
                      if world == 1 else
                      f"one process per GPU: rank r runs groups r, r + {world}, ... (bbb_sweep_shard, BBB_SHARD_GROUPS) through bbb_ber_trials_dev, ONE all-reduce of int64[88, 2]"),
             "scaling": "strong: the SAME 88 trials at every N; speed-up at N = this record's seconds at N = 1 / at N"}
@@ -767,7 +767,8 @@ def main():
             extra["ber_sweep_multi_c_abi"] = {"n_devices": 1, "equals_single_device_counters": [list(x) for x in got0] == tot,
                                               "gbit_s": round(11e9 / tm / 1e9, 2), "seconds": round(tm, 6), "calls_ms": [round(x * 1e3, 4) for x in tmi],
                                               "what": "ONE isolated 11-point sweep through bbb_ber_sweep_multi (median of five, each alone)",
-                                              "reduce": "ncclAllReduce(ncclUint64, ncclSum) of uint64[22] inside bbb_ber_sweep_multi",
+                                              "reduce": "ncclAllReduce(ncclUint64, ncclSum) of uint64[22] inside bbb_ber_sweep_multi at more than one device; over ONE device the "
+                                                        "communicator is created and asked for its size, the sum is the identity and no collective is queued",
                                               **multi_info()}
             allreduce_8_s = 30e-6
             extra["ber_sweep_88"]["projected_8_gpu"] = {
