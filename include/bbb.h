@@ -71,6 +71,11 @@ int bbb_lutopt_load_matrix_file(const char *path, int *k, uint16_t **taps, uint3
 int bbb_lutopt_create(bbb_lutopt **h, int k, const uint16_t *taps, const uint32_t *row_off,
                       const uint64_t *init_words, int device);
 int bbb_lutopt_destroy(bbb_lutopt *h);
+/* Bind the handle to a HIP stream (NULL = the default stream): every later call is ordered on it like a kernel launch -- behind what the
+ * caller had queued there, in front of what the caller queues next.  The library orders ITS OWN work across a re-bind (kernels, staging
+ * slots, start-state buffers of earlier calls, whichever stream they were made on).  The CALLER's work is the caller's to order, as with
+ * any stream-ordered library: a buffer that was filled, or is still being read, under one stream must not be handed to a call under
+ * another stream without an event between the two (tests/test_gpu_staged.py's random mix does exactly that). */
 int bbb_lutopt_set_stream(bbb_lutopt *h, void *hip_stream);
 /* 1 when the handle runs the generated straight-line kernel (the n256 matrix of
  * gateware/bbb/rng_recurrences.py:172-259 used by tx.py:70), 0 for the table-driven one. */

@@ -294,6 +294,12 @@ def test_random_mix_of_calls_on_one_staged_handle(gpu, oracle, seed):
     d = gpu.CLTGRNG(y.urng)
     side = torch.cuda.Stream()
     bufs = [torch.empty(BIG + 8192, dtype=torch.int8, device="cuda") for _ in range(2)]
+    # The library orders ITS OWN work when the caller moves to another stream (include/bbb.h, bbb_lutopt_set_stream); the caller's own
+    # reads of a buffer are the caller's to order, as with any stream-ordered library: a fill into bufs[b] first waits for the copy that
+    # last read bufs[b] -- on whichever stream that was.  (Round 5's 300-seed soak failed on seed 202 without this: the snapshot of a
+    # fill on the main stream, queued behind two transmitter calls, held the samples of the fill after next, made on the idle side
+    # stream into the same buffer: profiles/r05_fail_soak_seed.log.)
+    buf_read = [None, None]
     pos, checks = 16, []
     u.set_staged(True, look_ahead=2)
     for it in range(120):
@@ -301,10 +307,14 @@ def test_random_mix_of_calls_on_one_staged_handle(gpu, oracle, seed):
         n = BIG + 16 * int(rng.integers(0, 512))
         if op < 5:                                          # the next stretch of the stream, usually hinted
             out = bufs[it & 1][:n]
-            ctx = torch.cuda.stream(side) if rng.integers(0, 4) == 0 else torch.cuda.stream(torch.cuda.current_stream())
-            with ctx:
+            st = side if rng.integers(0, 4) == 0 else torch.cuda.current_stream()
+            with torch.cuda.stream(st):
+                if buf_read[it & 1] is not None:
+                    st.wait_event(buf_read[it & 1])
                 g.generate(n, first_step=pos, out=out)
                 snap = out.clone()
+                buf_read[it & 1] = torch.cuda.Event()
+                buf_read[it & 1].record(st)
             if rng.integers(0, 3):
                 g.prefetch(n, first_step=pos + n)
             checks.append(("awgn", n, pos, snap))
