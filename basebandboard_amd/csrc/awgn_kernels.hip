@@ -862,7 +862,12 @@ struct UnplaneGeom {                 // host computed (unplane_launch_with)
     unsigned per_block;              // a block takes the units [per_block * blockIdx.x, + per_block) of the order (w, q8, rg)
 };
 
-template <bool TXM>
+// NOWRAP (shaping mover only, round 5): the host has shown that no sample can leave the 12-bit range -- max over the phases of
+// sum |coeffs| + 128 noise_var <= 2047 (unplane_tx_nowrap: true of every coefficient set the reference ships up to noise_var 11) -- so
+// wrap12 is the identity, the table holds shaped - 128 noise_var itself instead of 16 times it and the V_PK_ASHRREV_I16 behind every
+// V_PK_MAD_U16 goes: 64 of the mover's 634 vector instructions per unit, and 4.2 % of the transmitter stream's time, same box
+// (profiles/r05_stream_variants.log: the stream is bound by the instructions of everything that runs beside the noise kernel).
+template <bool TXM, bool NOWRAP = false>
 __global__ void __launch_bounds__(256, 7)      // <= 72 registers: a wave of this kernel must fit beside the sample kernel's (<= 440 of 512)
 unplane_kernel(const u32x4 *__restrict stage, char *__restrict dst, unsigned long long win_lo, unsigned long long nbytes_, unsigned L,
                unsigned long long G, UnplaneGeom ge, TxFuse tx) {
@@ -902,7 +907,7 @@ unplane_kernel(const u32x4 *__restrict stage, char *__restrict dst, unsigned lon
                 sum += ((q >> (7 - idx)) & 1) ? c : -c;
             }
             const int shaped = tx.bit_en ? ((int)((unsigned)sum << 20) >> 20) : 0;
-            TT[e] = (uint16_t)((unsigned)((shaped - 128 * tx.noise_var) * 16) & 0xffffu);
+            TT[e] = (uint16_t)((unsigned)((shaped - 128 * tx.noise_var) * (NOWRAP ? 1 : 16)) & 0xffffu);
         }
         __syncthreads();
         // sample e of a piece has phase (c0 + e) & 7 and sees the window shifted by (c0 + e) >> 3 in {0, 1, 2} data bits
@@ -1059,7 +1064,7 @@ unplane_kernel(const u32x4 *__restrict stage, char *__restrict dst, unsigned lon
         if (TXM && inseg < L) {
             // positions are relative to the window: sample p of this call = stream offset win_lo + p; dst holds int16
             int16_t *const dst16 = reinterpret_cast<int16_t *>(dst);
-            const u16x2 nv16 = {(uint16_t)(tx.noise_var * 16), (uint16_t)(tx.noise_var * 16)};
+            const u16x2 nv16 = {(uint16_t)(tx.noise_var * (NOWRAP ? 1 : 16)), (uint16_t)(tx.noise_var * (NOWRAP ? 1 : 16))};
             const uint32_t idx_mask = tx.use_bits ? 0x7fe0u : 0u;            // (no data bits: every window reads as 0)
             // where the thread's pieces sit in their generators' two window words (dma_unit): the same for all eight, their
             // positions differ by multiples of 256 L samples = 32 L data bits
@@ -1084,8 +1089,13 @@ unplane_kernel(const u32x4 *__restrict stage, char *__restrict dst, unsigned lon
                     const uint32_t s01 = w4 < 2 ? A[2 * w4] : B[2 * w4 - 4], s23 = w4 < 2 ? A[2 * w4 + 1] : B[2 * w4 - 3];
                     const u16x2 m01 = __builtin_bit_cast(u16x2, u01) * nv16 + __builtin_bit_cast(u16x2, s01);
                     const u16x2 m23 = __builtin_bit_cast(u16x2, u23) * nv16 + __builtin_bit_cast(u16x2, s23);
-                    x[2 * w4] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(i16x2, m01) >> 4);
-                    x[2 * w4 + 1] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(i16x2, m23) >> 4);
+                    if constexpr (NOWRAP) {
+                        x[2 * w4] = __builtin_bit_cast(uint32_t, m01);
+                        x[2 * w4 + 1] = __builtin_bit_cast(uint32_t, m23);
+                    } else {
+                        x[2 * w4] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(i16x2, m01) >> 4);
+                        x[2 * w4 + 1] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(i16x2, m23) >> 4);
+                    }
                 }
                 int16_t *out = dst16 + (o - win_lo);
                 if (FULL || o + 16 <= nbytes) {
@@ -1124,6 +1134,19 @@ unplane_kernel(const u32x4 *__restrict stage, char *__restrict dst, unsigned lon
     }
 }
 
+// wrap12 cannot act on shaped + g noise_var, g in [-128, 127]: |shaped| <= max over the phases of sum_idx |coeffs[8 idx + ph]| (every sign
+// pattern is one of the 256 windows), tx.py:75-81
+static bool unplane_tx_nowrap(const TxFuse &tx) {
+    int worst = 0;
+    if (tx.bit_en)
+        for (int ph = 0; ph < 8; ph++) {
+            int sum = 0;
+            for (int idx = 0; idx < 8; idx++) sum += tx.coeffs[8 * idx + ph] < 0 ? -(int)tx.coeffs[8 * idx + ph] : (int)tx.coeffs[8 * idx + ph];
+            worst = sum > worst ? sum : worst;
+        }
+    return tx.noise_var >= 0 && worst + 128 * tx.noise_var <= 2047;
+}
+
 static int unplane_launch_with(const void *stage, void *dst, uint64_t win_lo, uint64_t nbytes, unsigned L, uint64_t G, unsigned nlanes,
                                const TxFuse *tx, hipStream_t st) {
     if (win_lo & 15) return fail(BBB_EINVAL, "window must start on a 16-byte boundary of the staged stream");
@@ -1153,10 +1176,14 @@ static int unplane_launch_with(const void *stage, void *dst, uint64_t win_lo, ui
         if (dev < 0 || dev >= 64 || !attr_set[dev]) {
             BBB_HIP(hipFuncSetAttribute((const void *)unplane_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kUnplaneLds));
             BBB_HIP(hipFuncSetAttribute((const void *)unplane_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kUnplaneLdsTx));
+            BBB_HIP(hipFuncSetAttribute((const void *)unplane_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kUnplaneLdsTx));
             if (dev >= 0 && dev < 64) attr_set[dev] = true;
         }
     }
-    if (tx) {
+    if (tx && unplane_tx_nowrap(*tx)) {
+        hipLaunchKernelGGL((unplane_kernel<true, true>), dim3((unsigned)blocks), dim3(256), kUnplaneLdsTx, st, (const u32x4 *)stage, (char *)dst,
+                           (unsigned long long)win_lo, (unsigned long long)nbytes, L, (unsigned long long)G, ge, *tx);
+    } else if (tx) {
         hipLaunchKernelGGL(unplane_kernel<true>, dim3((unsigned)blocks), dim3(256), kUnplaneLdsTx, st, (const u32x4 *)stage, (char *)dst,
                            (unsigned long long)win_lo, (unsigned long long)nbytes, L, (unsigned long long)G, ge, *tx);
     } else {

@@ -350,16 +350,21 @@ def test_random_mix_of_calls_on_one_staged_handle(gpu, oracle, seed):
         assert torch.equal(got, ref), (kind, n, p)
 
 
-@pytest.mark.parametrize("bit_en,src,nv,first", [(1, 0, 8, 0), (1, 0, 15, 5), (0, 0, 3, 1001), (1, 1, 1, 17), (1, 0, 0, 12345),
-                                                 (1, 1, 8, 2047), (1, 0, 8, (1 << 31) + 3)])
-def test_staged_tx_configurations(gpu, bit_en, src, nv, first):
+@pytest.mark.parametrize("bit_en,src,nv,first,shape", [(1, 0, 8, 0, 16), (1, 0, 15, 5, 16), (0, 0, 3, 1001, 16), (1, 1, 1, 17, 16), (1, 0, 0, 12345, 16),
+                                                       (1, 1, 8, 2047, 16), (1, 0, 8, (1 << 31) + 3, 16),
+                                                       # the shaping mover's two instances (round 5): without the 12-bit wrap where the host can rule it out
+                                                       # (max over the phases of sum |coeffs| + 128 noise_var <= 2047), with it otherwise.  Coefficient set 0
+                                                       # has the largest sum the reference ships (538): noise_var 11 is the last without, 12 the first with;
+                                                       # set 31 the smallest (266): 13 / 14
+                                                       (1, 0, 11, 3, 0), (1, 0, 12, 3, 0), (1, 0, 13, 6, 31), (1, 0, 14, 6, 31), (0, 0, 15, 9, 0), (0, 0, 15, 9, 31)])
+def test_staged_tx_configurations(gpu, bit_en, src, nv, first, shape):
     """The noise kernel + shaping mover form of bbb_tx_fill_i16 over the transmitter's switches (bits off, pulse source,
     every phase c0 = (first - 17) & 7 through the start positions, noise_var 0 .. 15, a ragged length) against the
     one-kernel form, which tests/test_gpu_tx.py holds to the oracle."""
     n = BIG + 16 * 37 + 5
-    x = gpu.TX(31, bit_en, src, 16, 1, nv)
+    x = gpu.TX(31, bit_en, src, shape, 1, nv)
     x.urng.set_staged(True)
-    y = gpu.TX(31, bit_en, src, 16, 1, nv)
+    y = gpu.TX(31, bit_en, src, shape, 1, nv)
     for i in range(2):
         a = x.generate(n, first_sample=first + i * n)
         b = y.generate(n, first_sample=first + i * n)
