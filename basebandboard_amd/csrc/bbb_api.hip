@@ -98,8 +98,12 @@ struct bbb_lutopt {
     // kernel of call s still reads its own -- two buffers, each with the event of its last reader
     uint32_t *d_fbits[2] = {nullptr, nullptr}; size_t fbits_cap[2] = {0, 0};
     hipEvent_t fbits_read[2] = {nullptr, nullptr}, fbits_ready = nullptr;
-    uint32_t *d_mbits[2] = {nullptr, nullptr}; size_t mbits_cap[2] = {0, 0};   // staged TX: a call's data bits, one buffer per staging slot (written on the
-                                                                               // slot's arithmetic stream in front of the sample kernel, read by the slot's mover)
+    // staged TX: the data bits of a noise kernel's windows, written on the staging slot's arithmetic stream in front of the sample kernel, read by the
+    // slot's movers.  TWO buffers per slot, taken in turn (round 5): the bits of the slot's next kernel then do not wait for the movers of its last
+    // one -- only the sample kernel does, for the staging slot itself -- and 55 us leave the gap between two noise kernels.  The readers
+    // of the buffer taken now are the movers of the slot's kernel BEFORE last, which the last kernel -- queued on this same stream -- waited for.
+    uint32_t *d_mbits[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; size_t mbits_cap[2][2] = {{0, 0}, {0, 0}};
+    unsigned mbits_turn[2] = {0, 0};
     hipEvent_t ber_join = nullptr;       // ber_run: behind the PRBS seeding on the side stream
     // BER trials (round 5): the generators' start states from awgn_seed_head_launch / _tail_planes_launch (two launches: the first 65536 states packed,
     // u32[8][65536], then the planes [256][nlanes] directly), two buffer pairs taken in turn like the PRBS pairs; bs_read[b]: behind the
@@ -164,6 +168,7 @@ struct bbb_lutopt {
         bool valid = false; int kind = 0; uint64_t first = 0, step = 0, n = 0, win_lo = 0, L = 0, G = 0;
         unsigned nlanes = 0, left = 0; int slot = 0; bbb_tx_cfg cfg{};
         int64_t bits_m0 = 0; uint64_t bits_words64 = 0;      // transmitter: the slot's data-bit buffer starts at bit bits_m0
+        unsigned bits_buf = 0;                               // ... and is the slot's buffer of this turn
     } ahead;
     bool last_fill_tx = false;            // the last sample-kernel launch was the transmitter variant (more LDS: see bbb_awgn_prefetch)
     bool last_staged_small = false;       // the last staged sample kernel was the small-footprint placement (two guest waves fit beside it)
@@ -1007,7 +1012,7 @@ int bbb_lutopt_destroy(bbb_lutopt *h) {
     for (auto &p : h->prbs_plans) (void)hipFree(p.second.d_cols);
     for (void *p : {(void *)h->d_states, (void *)h->d_planes, (void *)h->d_pstates[0], (void *)h->d_pplanes[0], (void *)h->d_pstates[1], (void *)h->d_pplanes[1],
                     (void *)h->d_taps, (void *)h->d_row_off, (void *)h->d_counters, (void *)h->d_txnoise,
-                    (void *)h->d_txbits, (void *)h->d_fbits[0], (void *)h->d_fbits[1], (void *)h->d_mbits[0], (void *)h->d_mbits[1], (void *)h->pf.d_states, (void *)h->pf.d_planes,
+                    (void *)h->d_txbits, (void *)h->d_fbits[0], (void *)h->d_fbits[1], (void *)h->d_mbits[0][0], (void *)h->d_mbits[0][1], (void *)h->d_mbits[1][0], (void *)h->d_mbits[1][1], (void *)h->pf.d_states, (void *)h->pf.d_planes,
                     (void *)h->d_bstates[0], (void *)h->d_bstates[1], (void *)h->d_bplanes[0], (void *)h->d_bplanes[1]})
         (void)hipFree(p);
     if (h->h_counters) (void)hipHostFree(h->h_counters);
@@ -1531,19 +1536,20 @@ int bbb_tx_fill_i16(bbb_lutopt *h, const bbb_tx_cfg *cfg, int16_t *out_dev, uint
             // noise kernel instead of beside it.)
             uint64_t words64 = 0;
             uint32_t *d_bits = nullptr;
+            unsigned bits_buf = 0;
             uint32_t rel = rel_base;
             bool bits_on = use_bits;
             auto make_bits = [&](int slot, uint64_t nbits_all) -> int {
                 words64 = 2 + (nbits_all + 63) / 64 + 3;
-                // the buffer's last reader is the slot's last mover
-                if (h->mbits_cap[slot] < (size_t)words64 * 2) {
+                // the slot's OTHER buffer than last time: its readers were the movers of the slot's kernel before last; the slot's last
+                // kernel waited for them (stage_free stands for every mover of the slot so far) and was queued on this stream
+                bits_buf = h->mbits_turn[slot] ^= 1u;
+                if (h->mbits_cap[slot][bits_buf] < (size_t)words64 * 2) {
                     if (h->stage_busy[slot]) BBB_HIP(hipEventSynchronize(h->stage_free[slot]));      // growing frees the old buffer
-                    int rcg = grow(&h->d_mbits[slot], &h->mbits_cap[slot], (size_t)words64 * 2);
+                    int rcg = grow(&h->d_mbits[slot][bits_buf], &h->mbits_cap[slot][bits_buf], (size_t)words64 * 2);
                     if (rcg) return rcg;
-                } else if (h->stage_busy[slot]) {
-                    BBB_HIP(hipStreamWaitEvent(h->cs, h->stage_free[slot], 0));
                 }
-                d_bits = h->d_mbits[slot];
+                d_bits = h->d_mbits[slot][bits_buf];
                 if (!cfg->bit_en || !nbits_all) return BBB_OK;
                 BBB_HIP(hipMemsetAsync(d_bits, 0, 16, h->cs));
                 uint64_t *bits64 = (uint64_t *)d_bits + 2;
@@ -1565,7 +1571,7 @@ int bbb_tx_fill_i16(bbb_lutopt *h, const bbb_tx_cfg *cfg, int16_t *out_dev, uint
                 if (env_knob("BBB_EXP_DELIVER_HANDOVER", 0) && (rc = begin_op(h, true))) return rc;
                 const bbb_lutopt::Ahead a = h->ahead;
                 // its data bits sit in the slot's buffer, behind those of the windows before it
-                d_bits = h->d_mbits[a.slot]; words64 = a.bits_words64;
+                d_bits = h->d_mbits[a.slot][a.bits_buf]; words64 = a.bits_words64;
                 rel = (uint32_t)(FM - 7 - (a.bits_m0 - 128));
                 bits_on = cfg->bit_en != 0;
                 h->ahead.first += nsamples; h->ahead.step += nsamples;
@@ -1603,7 +1609,7 @@ int bbb_tx_fill_i16(bbb_lutopt *h, const bbb_tx_cfg *cfg, int16_t *out_dev, uint
                 a.first = first_sample + nsamples; a.step = step0 + nsamples;
                 a.n = nsamples; a.win_lo = nsamples; a.left = (unsigned)mla - 1;
                 a.L = L; a.G = G; a.nlanes = nlanes; a.slot = slot;
-                a.bits_m0 = m0; a.bits_words64 = words64;
+                a.bits_m0 = m0; a.bits_words64 = words64; a.bits_buf = bits_buf;
             }
             return BBB_OK;
         }

@@ -6,11 +6,11 @@ vector clocks and reports every access that the streams, events and host synchro
 of a buffer's last reader, a read in front of its writer.  That is the hazard the GPU cannot be sanitised for and that
 round 3's soak test met on seed 3 of 3.
 
-Four MUTANTS prove that the model sees what it has to: copies of the file with ONE ordering rule removed by exact text (the
+Five MUTANTS prove that the model sees what it has to: copies of the file with ONE ordering rule removed by exact text (the
 product source carries no test macro since round 5) -- round 3's race (an announcement that was never taken leaves its seeding
 on one arithmetic stream, the next seeding goes to the other), the round-2 advisor's case (a prefetch's "the seeding waited for
 this slot's mover" outliving later movers on the slot), round 4's rule that a slot's "free" event stands for ALL movers that read
-it, and round 5's turn-taking of the BER trials' generator buffers -- all must be FOUND; the scheduler as it stands must come
+it, round 5's turn-taking of the BER trials' generator buffers and of the transmitter's data-bit buffers -- all must be FOUND; the scheduler as it stands must come
 through >= 10 000 sequences clean, under AddressSanitizer + UndefinedBehaviorSanitizer (leaks included) and under ThreadSanitizer."""
 import json
 import subprocess
@@ -46,6 +46,9 @@ MUTANTS = {
     # round 5: a BER trial's generator buffers are taken in turn; the seeding of trial s + 2 must wait for the kernel of trial s
     "ber_buffer_reuse": [("""            if (h->bs_pending[sb]) BBB_HIP(hipStreamWaitEvent(ss, h->bs_read[sb], 0));    // the trial before last read this pair
 """, "")],
+    # round 5: the transmitter's data bits take the staging slot's two bit buffers in turn INSTEAD of waiting for the slot's last mover;
+    # without the turn the bits of the slot's next kernel are written while that mover still reads them
+    "tx_bits_turn": [("bits_buf = h->mbits_turn[slot] ^= 1u;", "bits_buf = 0;")],
 }
 
 
@@ -106,6 +109,7 @@ def test_scheduler_under_thread_sanitizer(exes):
     ("stale_skip", "hints", "awgn256_planes_kernel"),
     ("mover_chain", "all", "awgn256_planes_kernel"),
     ("ber_buffer_reuse", "all", "seed_"),
+    ("tx_bits_turn", "all", "memset"),
 ])
 def test_the_model_finds_the_races_of_rounds_two_and_three(exes, macro, mode, what):
     """The scheduler with one of its ordering rules taken out: the model must report unordered accesses, and of the kind the
