@@ -47,7 +47,7 @@ def main():
                 "total": a["WRITE_SIZE"]["avg"] * 1024 + a["FETCH_SIZE"]["avg"] * 1024 * 2, "launches": a["WRITE_SIZE"]["launches"]}
 
     sk = next((k for k in res["kernels"] if "awgn256_planes_kernel" in k), None)
-    mv = next((k for k in res["kernels"] if "unplane_kernel<false>" in k), None)
+    mv = next((k for k in res["kernels"] if "unplane_kernel<false" in k), None)      # (<false> until round 5, <false, false> since the no-wrap parameter)
     if sk:
         rec = {"kernel": sk, "hbm_bytes_per_launch": hbm(sk)}
         a = res["kernels"][sk]
