@@ -278,8 +278,10 @@ def test_look_ahead_at_the_bench_size(gpu):
     assert torch.equal(buf, ref)
 
 
-# (BBB_SOAK_SEEDS=N: seeds 1..N instead of the three of a normal run -- after a change of the scheduler, once, on the GPU)
-@pytest.mark.parametrize("seed", list(range(1, 1 + int(os.environ.get("BBB_SOAK_SEEDS", "3")))))
+# (BBB_SOAK_SEEDS=N: seeds 1..N instead of the three of a normal run -- after a change of the scheduler, once, on the GPU;
+# BBB_SOAK_FIRST=F: seeds F..F+N-1, for a soak split over several calls)
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("BBB_SOAK_FIRST", "1")),
+                                            int(os.environ.get("BBB_SOAK_FIRST", "1")) + int(os.environ.get("BBB_SOAK_SEEDS", "3")))))
 def test_random_mix_of_calls_on_one_staged_handle(gpu, oracle, seed):
     """Soak: a random sequence of noise fills (sequential and not, hinted and not, two output buffers and two caller
     streams), TX fills, BER trials and level changes on ONE handle; every output equals what a fresh handle in the
